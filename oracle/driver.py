@@ -1,0 +1,327 @@
+"""ORACLE (test infrastructure only) — orchestration of the CPU restatement.
+
+Mirrors, in Python over oracle/_build/liblaghos_oracle.so:
+  * LagrangianHydroOperator ctor/Mult/GetTimeStepEstimate/ResetTimeStepEstimate
+    (/root/reference/laghos_solver.cpp:104-294, :308-327, :527-540)
+  * RK4Solver (upstream MFEM) and RK2AvgSolver (laghos_solver.cpp:1447-1487)
+  * the time loop with adaptive dt control (laghos.cpp:706-778) and the |e|
+    report / --checks probe points (laghos.cpp:792-839, :903-919)
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this.
+"""
+import ctypes
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+from .fem import Problem
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+c_dp = ctypes.POINTER(ctypes.c_double)
+c_ip = ctypes.POINTER(ctypes.c_int)
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "_build", "liblaghos_oracle.so")
+    srcs = [os.path.join(_HERE, f) for f in ("laghos_oracle.cpp", "smallmat.hpp", "Makefile")]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", _HERE], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = ctypes.CDLL(build())
+        L = _LIB
+        L.lgo_create.restype = ctypes.c_void_p
+        for name in ("lgo_stressJinvT", "lgo_Jac0inv", "lgo_rho0DetJ0w", "lgo_massD", "lgo_diagV",
+                     "lgo_q_dx", "lgo_q_dv", "lgo_q_e"):
+            getattr(L, name).restype = c_dp
+            getattr(L, name).argtypes = [ctypes.c_void_p]
+        for name in ("lgo_get_h0", "lgo_get_dt_est"):
+            getattr(L, name).restype = ctypes.c_double
+            getattr(L, name).argtypes = [ctypes.c_void_p]
+        L.lgo_set_h0.argtypes = [ctypes.c_void_p, ctypes.c_double]
+        L.lgo_set_dt_est.argtypes = [ctypes.c_void_p, ctypes.c_double]
+        L.lgo_setup_rho0detj0.restype = ctypes.c_double
+        L.lgo_internal_energy.restype = ctypes.c_double
+        L.lgo_kinetic_energy.restype = ctypes.c_double
+        L.lgo_sv3.restype = ctypes.c_double
+        L.lgo_sv2.restype = ctypes.c_double
+        L.lgo_cg.restype = ctypes.c_int
+    return _LIB
+
+
+def _dp(a):
+    assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(c_dp)
+
+
+def _ip(a):
+    assert a.dtype == np.int32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(c_ip)
+
+
+HALO_FN = ctypes.CFUNCTYPE(None, c_dp, ctypes.c_int, ctypes.c_void_p)
+ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_void_p)
+
+
+class Hydro:
+    """The oracle's LagrangianHydroOperator (PA branch, dim >= 2)."""
+
+    def __init__(self, prob: Problem, cfl=0.5, cg_tol=1e-8, cg_max_iter=300, comm=None):
+        self.p = prob
+        self.L = L = lib()
+        self.cg_tol, self.cg_max_iter = cg_tol, cg_max_iter
+        self.comm = comm
+        S, rho_l2, gamma, rho0_q = prob.initial_state()
+        self.S0 = S
+        self._keep = dict(
+            h1map=np.ascontiguousarray(prob.h1map.reshape(-1)),
+            B=np.ascontiguousarray(prob.B.T.reshape(-1)),    # (Q,D) q fastest
+            G=np.ascontiguousarray(prob.G.T.reshape(-1)),
+            Bl=np.ascontiguousarray(prob.Bl.T.reshape(-1)),
+            W=np.ascontiguousarray(prob.W),
+            gamma=np.ascontiguousarray(gamma, dtype=np.float64),
+            essc=np.array([len(e) for e in prob.ess] + [0] * (3 - prob.dim), dtype=np.int32),
+            ess=[np.ascontiguousarray(e) for e in prob.ess] + [np.zeros(1, np.int32)] * (3 - prob.dim),
+            owner=np.ascontiguousarray(prob.owner),
+        )
+        k = self._keep
+        ess = [e if len(e) else np.zeros(1, np.int32) for e in k["ess"]]
+        self.h = ctypes.c_void_p(L.lgo_create(
+            prob.dim, prob.NE, prob.D1D, prob.Q1D, prob.L1D, prob.N, _ip(k["h1map"]),
+            _dp(k["B"]), _dp(k["G"]), _dp(k["Bl"]), _dp(k["W"]), _dp(k["gamma"]), _ip(k["essc"]),
+            _ip(ess[0]), _ip(ess[1]), _ip(ess[2]), _dp(k["owner"]),
+            int(prob.use_viscosity()), 0, ctypes.c_double(cfl), prob.order_v))
+        if comm is not None:
+            self._install_comm(comm)
+        # Rho0DetJ0Vol + h0 (laghos_solver.cpp:223-262)
+        x0 = np.ascontiguousarray(S[:prob.H1V])
+        vol = L.lgo_setup_rho0detj0(self.h, _dp(x0), _dp(np.ascontiguousarray(rho_l2)),
+                                    _dp(np.ascontiguousarray(rho0_q)))
+        ne = float(prob.NE)
+        if comm is not None:
+            vol = comm.allreduce_sum(vol)
+            ne = comm.allreduce_sum(ne)
+        self.volume = vol
+        h0 = (vol / ne) ** (1.0 / prob.dim) / prob.order_v
+        L.lgo_set_h0(self.h, ctypes.c_double(h0))
+        L.lgo_mass_assemble_diag(self.h)  # OperatorJacobiSmoother (laghos_solver.cpp:266-270)
+        self.source_type = prob.source_type()
+        self.qdata_is_current = False
+
+    def _install_comm(self, comm):
+        prob = self.p
+
+        def halo(ptr, ncomp, _user):
+            arr = np.ctypeslib.as_array(ptr, shape=(ncomp * prob.N,))
+            comm.halo_sum(arr, ncomp)
+
+        def allred(v, op, _user):
+            return comm.allreduce_sum(v) if op == 0 else comm.allreduce_min(v)
+
+        self._halo_cb, self._ar_cb = HALO_FN(halo), ALLREDUCE_FN(allred)
+        self.L.lgo_set_comm_hooks(self._halo_cb, self._ar_cb, None)
+
+    def close(self):
+        if self.h:
+            self.L.lgo_set_comm_hooks(None, None, None)
+            self.L.lgo_destroy(self.h)
+            self.h = None
+
+    # -- views on QuadratureData ------------------------------------------------
+    def _view(self, fn, n):
+        return np.ctypeslib.as_array(getattr(self.L, fn)(self.h), shape=(n,))
+
+    @property
+    def stressJinvT(self):
+        return self._view("lgo_stressJinvT", self.p.NE * self.p.NQ * self.p.dim ** 2)
+
+    @property
+    def Jac0inv(self):
+        return self._view("lgo_Jac0inv", self.p.NE * self.p.NQ * self.p.dim ** 2)
+
+    @property
+    def rho0DetJ0w(self):
+        return self._view("lgo_rho0DetJ0w", self.p.NE * self.p.NQ)
+
+    @property
+    def massD(self):
+        return self._view("lgo_massD", self.p.NE * self.p.NQ)
+
+    @property
+    def diagV(self):
+        return self._view("lgo_diagV", self.p.N)
+
+    @property
+    def h0(self):
+        return self.L.lgo_get_h0(self.h)
+
+    # -- reference API ------------------------------------------------------------
+    def reset_time_step_estimate(self):
+        self.L.lgo_set_dt_est(self.h, ctypes.c_double(np.inf))
+
+    def update_quadrature_data(self, S):
+        """laghos_solver.cpp:807-814: no-op while the quadrature data is current."""
+        if self.qdata_is_current:
+            return
+        self.qdata_is_current = True
+        self.L.lgo_qupdate(self.h, _dp(S))
+
+    def reset_quadrature_data(self):
+        self.qdata_is_current = False
+
+    def get_time_step_estimate(self, S):
+        """laghos_solver.cpp:527-535."""
+        self.update_quadrature_data(S)
+        dt = self.L.lgo_get_dt_est(self.h)
+        if self.comm is not None:
+            dt = self.comm.allreduce_min(dt)
+        return dt
+
+    def mult(self, S, dS):
+        # SolveVelocity's UpdateQuadratureData (:332) honours qdata_is_current (:809)
+        self.update_quadrature_data(S)
+        src = None
+        if self.source_type == 1:
+            src = np.empty(self.p.L2V)
+            self.L.lgo_tg_source_2d(self.h, _dp(S), _dp(src))
+        self.L.lgo_hydro_mult(self.h, _dp(S), _dp(dS), ctypes.c_double(self.cg_tol),
+                              self.cg_max_iter, _dp(src) if src is not None else None, 1)
+        self.qdata_is_current = False  # :326
+
+    def force_mult(self, x_l2):
+        y = np.empty(self.p.H1V)
+        self.L.lgo_force_mult(self.h, _dp(x_l2), _dp(y))
+        return y
+
+    def force_mult_transpose(self, v):
+        y = np.empty(self.p.L2V)
+        self.L.lgo_force_mult_transpose(self.h, _dp(v), _dp(y))
+        return y
+
+    def mass_mult(self, space, x, comp=-1, full=False):
+        y = np.empty_like(x)
+        self.L.lgo_mass_set_ess(self.h, comp)
+        self.L.lgo_mass_mult(self.h, space, int(full), _dp(x), _dp(y))
+        return y
+
+    def cg(self, space, b, x=None, comp=-1, rel_tol=None, max_iter=None):
+        x = np.zeros_like(b) if x is None else x
+        self.L.lgo_mass_set_ess(self.h, comp)
+        it = self.L.lgo_cg(self.h, space, _dp(b), _dp(x),
+                           ctypes.c_double(self.cg_tol if rel_tol is None else rel_tol),
+                           self.cg_max_iter if max_iter is None else max_iter)
+        return x, it
+
+    def internal_energy(self, S):
+        e = np.ascontiguousarray(S[2 * self.p.H1V:])
+        return self.L.lgo_internal_energy(self.h, _dp(e))
+
+    def kinetic_energy(self, S):
+        v = np.ascontiguousarray(S[self.p.H1V:2 * self.p.H1V])
+        return self.L.lgo_kinetic_energy(self.h, _dp(v))
+
+    def timers(self):
+        t = (ctypes.c_double * 4)()
+        c = (ctypes.c_long * 3)()
+        self.L.lgo_get_timers(self.h, t, c)
+        return dict(cgH1=t[0], cgL2=t[1], force=t[2], qdata=t[3], H1iter=c[0], L2iter=c[1],
+                    quad_tstep=c[2])
+
+    def reset_timers(self):
+        self.L.lgo_reset_timers(self.h)
+
+    def e_norm(self, S):
+        e = S[2 * self.p.H1V:]
+        n2 = float(np.dot(e, e))
+        if self.comm is not None:
+            n2 = self.comm.allreduce_sum(n2)
+        return np.sqrt(n2)
+
+
+def rk4_step(hydro, S, t, dt, work):
+    """Classical RK4 exactly as upstream RK4Solver::Step."""
+    k, y, z = work
+    hydro.mult(S, k)
+    np.add(S, (dt / 2) * k, out=y)
+    np.add(S, (dt / 6) * k, out=z)
+    hydro.mult(y, k)
+    np.add(S, (dt / 2) * k, out=y)
+    z += (dt / 3) * k
+    hydro.mult(y, k)
+    np.add(S, dt * k, out=y)
+    z += (dt / 3) * k
+    hydro.mult(y, k)
+    np.add(z, (dt / 6) * k, out=S)
+    return t + dt
+
+
+def run(prob: Problem, t_final=0.6, cfl=0.5, cg_tol=1e-8, cg_max_iter=300, max_steps=-1,
+        vis_steps=5, probe_steps=(), verbose=False, comm=None, hydro=None):
+    """The reference time loop (laghos.cpp:706-778).  Returns a dict with the last
+    printed (step, t, dt, |e|), |e| at each step in probe_steps, and the FOM data."""
+    own = hydro is None
+    if own:
+        hydro = Hydro(prob, cfl=cfl, cg_tol=cg_tol, cg_max_iter=cg_max_iter, comm=comm)
+    S = hydro.S0.copy()
+    work = (np.empty_like(S), np.empty_like(S), np.empty_like(S))
+    hydro.reset_time_step_estimate()
+    t = 0.0
+    dt = hydro.get_time_step_estimate(S)
+    last_step = False
+    steps = 0
+    S_old = S.copy()
+    probes = {}
+    last = None
+    repeats = 0
+    e_init = hydro.internal_energy(S) + hydro.kinetic_energy(S)
+    ti = 1
+    while not last_step:
+        if t + dt >= t_final:
+            dt = t_final - t
+            last_step = True
+        if steps == max_steps:
+            last_step = True
+        S_old[:] = S
+        t_old = t
+        hydro.reset_time_step_estimate()
+        t = rk4_step(hydro, S, t, dt, work)
+        steps += 1
+        dt_est = hydro.get_time_step_estimate(S)
+        if dt_est < dt:
+            dt *= 0.85
+            if dt < np.finfo(float).eps:
+                raise RuntimeError("The time step crashed!")
+            t = t_old
+            S[:] = S_old
+            hydro.reset_quadrature_data()
+            repeats += 1
+            if verbose:
+                print(f"Repeating step {ti}")
+            if steps < max_steps:
+                last_step = False
+            continue  # ti unchanged (ti--; continue; ti++)
+        elif dt_est > 1.25 * dt:
+            dt *= 1.02
+        if last_step or (ti % vis_steps) == 0:
+            en = hydro.e_norm(S)
+            last = dict(step=ti, t=t, dt=dt, e_norm=en)
+            if verbose:
+                print(f"step {ti:5d},\tt = {t:.4f},\tdt = {dt:.6f},\t|e| = {en:.10e}")
+                sys.stdout.flush()
+        if ti in probe_steps:
+            probes[ti] = hydro.e_norm(S)
+        ti += 1
+    e_final = hydro.internal_energy(S) + hydro.kinetic_energy(S)
+    out = dict(last=last, probes=probes, steps=steps, repeats=repeats, S=S,
+               energy_diff=abs(e_init - e_final), timers=hydro.timers())
+    if own:
+        hydro.close()
+    return out

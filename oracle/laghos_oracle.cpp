@@ -1,0 +1,1510 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY.
+//
+// CPU restatement of the Laghos partial-assembly hot path.  Only tests/,
+// __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
+// library; the product (laghos_amd/) never links, imports or calls it.
+//
+// What is restated, and from where (all paths relative to /root/reference):
+//   ForceMult{2D,3D}            laghos_assembly.cpp:145-294, :296-514
+//   ForceMultTranspose{2D,3D}   laghos_assembly.cpp:567-713, :715-924
+//   ForcePAOperator::Mult/T     laghos_assembly.cpp:557-565, :965-973
+//   MassPAOperator              laghos_assembly.cpp:80-121  (PA mass apply itself
+//                               is upstream MFEM MassIntegrator::AddMultPA; the
+//                               math is cross-checked with amr/laghos_assembly.cpp:878-963)
+//   QUpdateBody / QKernel       laghos_solver.cpp:1042-1168, :1263-1352
+//   QUpdate::UpdateQuadratureData laghos_solver.cpp:1354-1411 (E-restriction +
+//                               QuadratureInterpolator::Derivatives/Values are upstream)
+//   Rho0DetJ0Vol                laghos_solver.cpp:1170-1261
+//   CGSolver / Jacobi           configured laghos_solver.cpp:264-284 (algorithm
+//                               upstream MFEM linalg/solvers.cpp, restated)
+//   ComputeVolumeIntegral etc.  laghos_solver.cpp:565-697
+//
+// Upstream MFEM (branch master, unpinned: makefile:307-314) is not available in
+// this image, so this oracle is pinned end-to-end against the reference's own
+// golden values: the `--checks` table (laghos.cpp:1441-1463, rel 1e-13 there)
+// and the README / `make tests` runs (README.md:225-235, makefile:271-278).
+// See tests/test_oracle_golden.py.  The reference itself is unbuildable here
+// (needs mfem.hpp + hypre + MPI); no stand-in headers are written.
+//
+// Loop structure follows the host expansion of the reference's MFEM_FORALL
+// kernels (MFEM_FOREACH_THREAD -> plain for), so operation order inside an
+// element matches the reference CPU `-pa` path.  Elements are independent and
+// are distributed over OpenMP threads (one thread plays one MPI rank's loop).
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <vector>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#include "smallmat.hpp"
+
+namespace
+{
+
+// ---------------------------------------------------------------------------
+// Force kernels.  Tables: B_l2 (Q1D x L1D, q fastest), Bt/Gt of H1 (D1D x Q1D,
+// d fastest), B/G of H1 (Q1D x D1D, q fastest), Bt_l2 (L1D x Q1D).
+// sJit(q, e, gd, c) = stressJinvT[q + NQ*(e + NE*(gd + DIM*c))].
+// ---------------------------------------------------------------------------
+
+// laghos_assembly.cpp:145-294
+template <int D1D, int Q1D, int L1D>
+void ForceMult2D(const int NE, const double *b_, const double *bt_, const double *gt_,
+                 const double *sJit_, const double *x, double *y)
+{
+   constexpr int DIM = 2, NQ = Q1D * Q1D;
+   const double eps1 = std::numeric_limits<double>::epsilon();
+   const double eps2 = eps1 * eps1;
+#pragma omp parallel for schedule(static)
+   for (int e = 0; e < NE; e++)
+   {
+      double B[Q1D][L1D], Bt[D1D][Q1D], Gt[D1D][Q1D];
+      double E[L1D][L1D], LQ0[D1D][Q1D], LQ1[D1D][Q1D];
+      double QQ[Q1D][Q1D], QQ0[Q1D][Q1D], QQ1[Q1D][Q1D];
+      for (int q = 0; q < Q1D; q++)
+      {
+         for (int l = 0; l < L1D; l++) { B[q][l] = b_[q + Q1D * l]; }
+         for (int d = 0; d < D1D; d++)
+         {
+            Bt[d][q] = bt_[d + D1D * q];
+            Gt[d][q] = gt_[d + D1D * q];
+         }
+      }
+      for (int lx = 0; lx < L1D; lx++)
+         for (int ly = 0; ly < L1D; ly++) { E[lx][ly] = x[lx + L1D * (ly + L1D * e)]; }
+      for (int ly = 0; ly < L1D; ly++)
+         for (int qx = 0; qx < Q1D; qx++)
+         {
+            double u = 0.0;
+            for (int lx = 0; lx < L1D; ++lx) { u += B[qx][lx] * E[lx][ly]; }
+            LQ0[ly][qx] = u;
+         }
+      for (int qy = 0; qy < Q1D; qy++)
+         for (int qx = 0; qx < Q1D; qx++)
+         {
+            double u = 0.0;
+            for (int ly = 0; ly < L1D; ++ly) { u += B[qy][ly] * LQ0[ly][qx]; }
+            QQ[qy][qx] = u;
+         }
+      for (int c = 0; c < DIM; ++c)
+      {
+         for (int qy = 0; qy < Q1D; qy++)
+            for (int qx = 0; qx < Q1D; qx++)
+            {
+               const int q = qx + Q1D * qy;
+               const double s0 = sJit_[q + NQ * (e + (size_t)NE * (0 + DIM * c))];
+               const double s1 = sJit_[q + NQ * (e + (size_t)NE * (1 + DIM * c))];
+               QQ0[qy][qx] = QQ[qy][qx] * s0;
+               QQ1[qy][qx] = QQ[qy][qx] * s1;
+            }
+         for (int qy = 0; qy < Q1D; qy++)
+            for (int dx = 0; dx < D1D; dx++)
+            {
+               double u = 0.0, v = 0.0;
+               for (int qx = 0; qx < Q1D; ++qx)
+               {
+                  u += Gt[dx][qx] * QQ0[qy][qx];
+                  v += Bt[dx][qx] * QQ1[qy][qx];
+               }
+               LQ0[dx][qy] = u;
+               LQ1[dx][qy] = v;
+            }
+         for (int dy = 0; dy < D1D; dy++)
+            for (int dx = 0; dx < D1D; dx++)
+            {
+               double u = 0.0, v = 0.0;
+               for (int qy = 0; qy < Q1D; ++qy)
+               {
+                  u += LQ0[dx][qy] * Bt[dy][qy];
+                  v += LQ1[dx][qy] * Gt[dy][qy];
+               }
+               y[dx + D1D * (dy + D1D * (c + DIM * (size_t)e))] = u + v;
+            }
+      }
+      for (int c = 0; c < DIM; ++c)
+         for (int dy = 0; dy < D1D; dy++)
+            for (int dx = 0; dx < D1D; dx++)
+            {
+               double &v = y[dx + D1D * (dy + D1D * (c + DIM * (size_t)e))];
+               if (std::fabs(v) < eps2) { v = 0.0; }
+            }
+   }
+}
+
+// laghos_assembly.cpp:296-514
+template <int D1D, int Q1D, int L1D>
+void ForceMult3D(const int NE, const double *b_, const double *bt_, const double *gt_,
+                 const double *sJit_, const double *x, double *y)
+{
+   constexpr int DIM = 3, NQ = Q1D * Q1D * Q1D;
+   const double eps1 = std::numeric_limits<double>::epsilon();
+   const double eps2 = eps1 * eps1;
+#pragma omp parallel for schedule(static)
+   for (int e = 0; e < NE; e++)
+   {
+      double B[Q1D][L1D], Bt[D1D][Q1D], Gt[D1D][Q1D];
+      double E[L1D][L1D][L1D];
+      double sm0[3][Q1D * Q1D * Q1D], sm1[3][Q1D * Q1D * Q1D];
+      double(*MMQ0)[D1D][Q1D] = (double(*)[D1D][Q1D])(sm0 + 0);
+      double(*MMQ1)[D1D][Q1D] = (double(*)[D1D][Q1D])(sm0 + 1);
+      double(*MMQ2)[D1D][Q1D] = (double(*)[D1D][Q1D])(sm0 + 2);
+      double(*MQQ0)[Q1D][Q1D] = (double(*)[Q1D][Q1D])(sm1 + 0);
+      double(*MQQ1)[Q1D][Q1D] = (double(*)[Q1D][Q1D])(sm1 + 1);
+      double(*MQQ2)[Q1D][Q1D] = (double(*)[Q1D][Q1D])(sm1 + 2);
+      double QQQ[Q1D][Q1D][Q1D];
+      double(*QQQ0)[Q1D][Q1D] = (double(*)[Q1D][Q1D])(sm0 + 0);
+      double(*QQQ1)[Q1D][Q1D] = (double(*)[Q1D][Q1D])(sm0 + 1);
+      double(*QQQ2)[Q1D][Q1D] = (double(*)[Q1D][Q1D])(sm0 + 2);
+      for (int q = 0; q < Q1D; q++)
+      {
+         for (int l = 0; l < L1D; l++) { B[q][l] = b_[q + Q1D * l]; }
+         for (int d = 0; d < D1D; d++)
+         {
+            Bt[d][q] = bt_[d + D1D * q];
+            Gt[d][q] = gt_[d + D1D * q];
+         }
+      }
+      for (int lx = 0; lx < L1D; lx++)
+         for (int ly = 0; ly < L1D; ly++)
+            for (int lz = 0; lz < L1D; lz++)
+            {
+               E[lx][ly][lz] = x[lx + L1D * (ly + L1D * (lz + L1D * (size_t)e))];
+            }
+      for (int lz = 0; lz < L1D; lz++)
+         for (int ly = 0; ly < L1D; ly++)
+            for (int qx = 0; qx < Q1D; qx++)
+            {
+               double u = 0.0;
+               for (int lx = 0; lx < L1D; ++lx) { u += B[qx][lx] * E[lx][ly][lz]; }
+               MMQ0[lz][ly][qx] = u;
+            }
+      for (int lz = 0; lz < L1D; lz++)
+         for (int qy = 0; qy < Q1D; qy++)
+            for (int qx = 0; qx < Q1D; qx++)
+            {
+               double u = 0.0;
+               for (int ly = 0; ly < L1D; ++ly) { u += B[qy][ly] * MMQ0[lz][ly][qx]; }
+               MQQ0[lz][qy][qx] = u;
+            }
+      for (int qz = 0; qz < Q1D; qz++)
+         for (int qy = 0; qy < Q1D; qy++)
+            for (int qx = 0; qx < Q1D; qx++)
+            {
+               double u = 0.0;
+               for (int lz = 0; lz < L1D; ++lz) { u += B[qz][lz] * MQQ0[lz][qy][qx]; }
+               QQQ[qz][qy][qx] = u;
+            }
+      for (int c = 0; c < 3; ++c)
+      {
+         for (int qz = 0; qz < Q1D; qz++)
+            for (int qy = 0; qy < Q1D; qy++)
+               for (int qx = 0; qx < Q1D; qx++)
+               {
+                  const int q = qx + Q1D * (qy + Q1D * qz);
+                  const double s0 = sJit_[q + NQ * (e + (size_t)NE * (0 + DIM * c))];
+                  const double s1 = sJit_[q + NQ * (e + (size_t)NE * (1 + DIM * c))];
+                  const double s2 = sJit_[q + NQ * (e + (size_t)NE * (2 + DIM * c))];
+                  QQQ0[qz][qy][qx] = QQQ[qz][qy][qx] * s0;
+                  QQQ1[qz][qy][qx] = QQQ[qz][qy][qx] * s1;
+                  QQQ2[qz][qy][qx] = QQQ[qz][qy][qx] * s2;
+               }
+         for (int qz = 0; qz < Q1D; qz++)
+            for (int qy = 0; qy < Q1D; qy++)
+               for (int hx = 0; hx < D1D; hx++)
+               {
+                  double u = 0.0, v = 0.0, w = 0.0;
+                  for (int qx = 0; qx < Q1D; ++qx)
+                  {
+                     u += Gt[hx][qx] * QQQ0[qz][qy][qx];
+                     v += Bt[hx][qx] * QQQ1[qz][qy][qx];
+                     w += Bt[hx][qx] * QQQ2[qz][qy][qx];
+                  }
+                  MQQ0[hx][qy][qz] = u;
+                  MQQ1[hx][qy][qz] = v;
+                  MQQ2[hx][qy][qz] = w;
+               }
+         for (int qz = 0; qz < Q1D; qz++)
+            for (int hy = 0; hy < D1D; hy++)
+               for (int hx = 0; hx < D1D; hx++)
+               {
+                  double u = 0.0, v = 0.0, w = 0.0;
+                  for (int qy = 0; qy < Q1D; ++qy)
+                  {
+                     u += MQQ0[hx][qy][qz] * Bt[hy][qy];
+                     v += MQQ1[hx][qy][qz] * Gt[hy][qy];
+                     w += MQQ2[hx][qy][qz] * Bt[hy][qy];
+                  }
+                  MMQ0[hx][hy][qz] = u;
+                  MMQ1[hx][hy][qz] = v;
+                  MMQ2[hx][hy][qz] = w;
+               }
+         for (int hz = 0; hz < D1D; hz++)
+            for (int hy = 0; hy < D1D; hy++)
+               for (int hx = 0; hx < D1D; hx++)
+               {
+                  double u = 0.0, v = 0.0, w = 0.0;
+                  for (int qz = 0; qz < Q1D; ++qz)
+                  {
+                     u += MMQ0[hx][hy][qz] * Bt[hz][qz];
+                     v += MMQ1[hx][hy][qz] * Bt[hz][qz];
+                     w += MMQ2[hx][hy][qz] * Gt[hz][qz];
+                  }
+                  y[hx + D1D * (hy + D1D * (hz + D1D * (c + DIM * (size_t)e)))] = u + v + w;
+               }
+      }
+      for (int i = 0; i < D1D * D1D * D1D * DIM; i++)
+      {
+         double &v = y[i + (size_t)D1D * D1D * D1D * DIM * e];
+         if (std::fabs(v) < eps2) { v = 0.0; }
+      }
+   }
+}
+
+// laghos_assembly.cpp:567-713
+template <int D1D, int Q1D, int L1D>
+void ForceMultTranspose2D(const int NE, const double *bt_, const double *b_, const double *g_,
+                          const double *sJit_, const double *x, double *y)
+{
+   constexpr int DIM = 2, NQ = Q1D * Q1D;
+#pragma omp parallel for schedule(static)
+   for (int e = 0; e < NE; e++)
+   {
+      double Bt[L1D][Q1D], B[Q1D][D1D], G[Q1D][D1D];
+      double V[D1D][D1D], DQ0[D1D][Q1D], DQ1[D1D][Q1D];
+      double QQ[Q1D][Q1D], QQ0[Q1D][Q1D], QQ1[Q1D][Q1D], QL[Q1D][L1D];
+      for (int q = 0; q < Q1D; q++)
+      {
+         for (int h = 0; h < D1D; h++)
+         {
+            B[q][h] = b_[q + Q1D * h];
+            G[q][h] = g_[q + Q1D * h];
+         }
+         for (int l = 0; l < L1D; l++) { Bt[l][q] = bt_[l + L1D * q]; }
+      }
+      for (int qy = 0; qy < Q1D; qy++)
+         for (int qx = 0; qx < Q1D; qx++) { QQ[qy][qx] = 0.0; }
+      for (int c = 0; c < DIM; ++c)
+      {
+         for (int dx = 0; dx < D1D; dx++)
+            for (int dy = 0; dy < D1D; dy++)
+            {
+               V[dx][dy] = x[dx + D1D * (dy + D1D * (c + DIM * (size_t)e))];
+            }
+         for (int dy = 0; dy < D1D; dy++)
+            for (int qx = 0; qx < Q1D; qx++)
+            {
+               double u = 0.0, v = 0.0;
+               for (int dx = 0; dx < D1D; ++dx)
+               {
+                  const double input = V[dx][dy];
+                  u += B[qx][dx] * input;
+                  v += G[qx][dx] * input;
+               }
+               DQ0[dy][qx] = u;
+               DQ1[dy][qx] = v;
+            }
+         for (int qy = 0; qy < Q1D; qy++)
+            for (int qx = 0; qx < Q1D; qx++)
+            {
+               double u = 0.0, v = 0.0;
+               for (int dy = 0; dy < D1D; ++dy)
+               {
+                  u += DQ1[dy][qx] * B[qy][dy];
+                  v += DQ0[dy][qx] * G[qy][dy];
+               }
+               QQ0[qy][qx] = u;
+               QQ1[qy][qx] = v;
+            }
+         for (int qy = 0; qy < Q1D; qy++)
+            for (int qx = 0; qx < Q1D; qx++)
+            {
+               const int q = qx + Q1D * qy;
+               const double esx = QQ0[qy][qx] * sJit_[q + NQ * (e + (size_t)NE * (0 + DIM * c))];
+               const double esy = QQ1[qy][qx] * sJit_[q + NQ * (e + (size_t)NE * (1 + DIM * c))];
+               QQ[qy][qx] += esx + esy;
+            }
+      }
+      for (int qy = 0; qy < Q1D; qy++)
+         for (int lx = 0; lx < L1D; lx++)
+         {
+            double u = 0.0;
+            for (int qx = 0; qx < Q1D; ++qx) { u += QQ[qy][qx] * Bt[lx][qx]; }
+            QL[qy][lx] = u;
+         }
+      for (int ly = 0; ly < L1D; ly++)
+         for (int lx = 0; lx < L1D; lx++)
+         {
+            double u = 0.0;
+            for (int qy = 0; qy < Q1D; ++qy) { u += QL[qy][lx] * Bt[ly][qy]; }
+            y[lx + L1D * (ly + L1D * (size_t)e)] = u;
+         }
+   }
+}
+
+// laghos_assembly.cpp:715-924
+template <int D1D, int Q1D, int L1D>
+void ForceMultTranspose3D(const int NE, const double *bt_, const double *b_, const double *g_,
+                          const double *sJit_, const double *v_, double *e_)
+{
+   constexpr int DIM = 3, NQ = Q1D * Q1D * Q1D;
+#pragma omp parallel for schedule(static)
+   for (int e = 0; e < NE; e++)
+   {
+      double Bt[L1D][Q1D], B[Q1D][D1D], G[Q1D][D1D];
+      double sm0[3][Q1D * Q1D * Q1D], sm1[3][Q1D * Q1D * Q1D];
+      double(*V)[D1D][D1D] = (double(*)[D1D][D1D])(sm0 + 0);
+      double(*MMQ0)[D1D][Q1D] = (double(*)[D1D][Q1D])(sm0 + 1);
+      double(*MMQ1)[D1D][Q1D] = (double(*)[D1D][Q1D])(sm0 + 2);
+      double(*MQQ0)[Q1D][Q1D] = (double(*)[Q1D][Q1D])(sm1 + 0);
+      double(*MQQ1)[Q1D][Q1D] = (double(*)[Q1D][Q1D])(sm1 + 1);
+      double(*MQQ2)[Q1D][Q1D] = (double(*)[Q1D][Q1D])(sm1 + 2);
+      double(*QQQ0)[Q1D][Q1D] = (double(*)[Q1D][Q1D])(sm0 + 0);
+      double(*QQQ1)[Q1D][Q1D] = (double(*)[Q1D][Q1D])(sm0 + 1);
+      double(*QQQ2)[Q1D][Q1D] = (double(*)[Q1D][Q1D])(sm0 + 2);
+      double QQQ[Q1D][Q1D][Q1D];
+      // The reference reuses sm1 (MQQ0 as [Q][Q][L], sm0+1 as MMQ0 [Q][L][L]) in
+      // the final L2 test stage; separate scratch here is value-identical.
+      double T1[Q1D][Q1D][L1D], T2[Q1D][L1D][L1D];
+      for (int q = 0; q < Q1D; q++)
+      {
+         for (int h = 0; h < D1D; h++)
+         {
+            B[q][h] = b_[q + Q1D * h];
+            G[q][h] = g_[q + Q1D * h];
+         }
+         for (int l = 0; l < L1D; l++) { Bt[l][q] = bt_[l + L1D * q]; }
+      }
+      for (int qz = 0; qz < Q1D; qz++)
+         for (int qy = 0; qy < Q1D; qy++)
+            for (int qx = 0; qx < Q1D; qx++) { QQQ[qz][qy][qx] = 0.0; }
+      for (int c = 0; c < DIM; ++c)
+      {
+         for (int dx = 0; dx < D1D; dx++)
+            for (int dy = 0; dy < D1D; dy++)
+               for (int dz = 0; dz < D1D; dz++)
+               {
+                  V[dx][dy][dz] = v_[dx + D1D * (dy + D1D * (dz + D1D * (c + DIM * (size_t)e)))];
+               }
+         for (int dz = 0; dz < D1D; dz++)
+            for (int dy = 0; dy < D1D; dy++)
+               for (int qx = 0; qx < Q1D; qx++)
+               {
+                  double u = 0.0, v = 0.0;
+                  for (int dx = 0; dx < D1D; ++dx)
+                  {
+                     const double input = V[dx][dy][dz];
+                     u += G[qx][dx] * input;
+                     v += B[qx][dx] * input;
+                  }
+                  MMQ0[dz][dy][qx] = u;
+                  MMQ1[dz][dy][qx] = v;
+               }
+         for (int dz = 0; dz < D1D; dz++)
+            for (int qy = 0; qy < Q1D; qy++)
+               for (int qx = 0; qx < Q1D; qx++)
+               {
+                  double u = 0.0, v = 0.0, w = 0.0;
+                  for (int dy = 0; dy < D1D; ++dy)
+                  {
+                     u += MMQ0[dz][dy][qx] * B[qy][dy];
+                     v += MMQ1[dz][dy][qx] * G[qy][dy];
+                     w += MMQ1[dz][dy][qx] * B[qy][dy];
+                  }
+                  MQQ0[dz][qy][qx] = u;
+                  MQQ1[dz][qy][qx] = v;
+                  MQQ2[dz][qy][qx] = w;
+               }
+         for (int qz = 0; qz < Q1D; qz++)
+            for (int qy = 0; qy < Q1D; qy++)
+               for (int qx = 0; qx < Q1D; qx++)
+               {
+                  double u = 0.0, v = 0.0, w = 0.0;
+                  for (int dz = 0; dz < D1D; ++dz)
+                  {
+                     u += MQQ0[dz][qy][qx] * B[qz][dz];
+                     v += MQQ1[dz][qy][qx] * B[qz][dz];
+                     w += MQQ2[dz][qy][qx] * G[qz][dz];
+                  }
+                  QQQ0[qz][qy][qx] = u;
+                  QQQ1[qz][qy][qx] = v;
+                  QQQ2[qz][qy][qx] = w;
+               }
+         for (int qz = 0; qz < Q1D; qz++)
+            for (int qy = 0; qy < Q1D; qy++)
+               for (int qx = 0; qx < Q1D; qx++)
+               {
+                  const int q = qx + Q1D * (qy + Q1D * qz);
+                  const double esx = QQQ0[qz][qy][qx] * sJit_[q + NQ * (e + (size_t)NE * (0 + DIM * c))];
+                  const double esy = QQQ1[qz][qy][qx] * sJit_[q + NQ * (e + (size_t)NE * (1 + DIM * c))];
+                  const double esz = QQQ2[qz][qy][qx] * sJit_[q + NQ * (e + (size_t)NE * (2 + DIM * c))];
+                  QQQ[qz][qy][qx] += esx + esy + esz;
+               }
+      }
+      for (int qz = 0; qz < Q1D; qz++)
+         for (int qy = 0; qy < Q1D; qy++)
+            for (int lx = 0; lx < L1D; lx++)
+            {
+               double u = 0.0;
+               for (int qx = 0; qx < Q1D; ++qx) { u += QQQ[qz][qy][qx] * Bt[lx][qx]; }
+               T1[qz][qy][lx] = u;
+            }
+      for (int qz = 0; qz < Q1D; qz++)
+         for (int ly = 0; ly < L1D; ly++)
+            for (int lx = 0; lx < L1D; lx++)
+            {
+               double u = 0.0;
+               for (int qy = 0; qy < Q1D; ++qy) { u += T1[qz][qy][lx] * Bt[ly][qy]; }
+               T2[qz][ly][lx] = u;
+            }
+      for (int lz = 0; lz < L1D; lz++)
+         for (int ly = 0; ly < L1D; ly++)
+            for (int lx = 0; lx < L1D; lx++)
+            {
+               double u = 0.0;
+               for (int qz = 0; qz < Q1D; ++qz) { u += T2[qz][ly][lx] * Bt[lz][qz]; }
+               e_[lx + L1D * (ly + L1D * (lz + L1D * (size_t)e))] = u;
+            }
+   }
+}
+
+// ---------------------------------------------------------------------------
+// PA mass apply y_e = B^T diag(D_e) B x_e (upstream MassIntegrator::AddMultPA;
+// contraction order x, y, z then back as in MFEM's PAMassApply; the same math
+// is written out in amr/laghos_assembly.cpp:878-963).  B is (Q1D x N1D), q
+// fastest.  Works for the scalar H1 space (N1D=D1D) and for L2 (N1D=L1D).
+// ---------------------------------------------------------------------------
+template <int DIM, int N1D, int Q1D>
+void MassApplyE(const int NE, const double *b_, const double *D, const double *x, double *y)
+{
+   constexpr int ND = (DIM == 2) ? N1D * N1D : N1D * N1D * N1D;
+   constexpr int NQ = (DIM == 2) ? Q1D * Q1D : Q1D * Q1D * Q1D;
+#pragma omp parallel for schedule(static)
+   for (int e = 0; e < NE; e++)
+   {
+      double B[Q1D][N1D];
+      for (int q = 0; q < Q1D; q++)
+         for (int d = 0; d < N1D; d++) { B[q][d] = b_[q + Q1D * d]; }
+      const double *X = x + (size_t)ND * e;
+      const double *De = D + (size_t)NQ * e;
+      double *Y = y + (size_t)ND * e;
+      if (DIM == 2)
+      {
+         double DQ[N1D][Q1D], QQ[Q1D][Q1D];
+         for (int dy = 0; dy < N1D; dy++)
+            for (int qx = 0; qx < Q1D; qx++)
+            {
+               double u = 0.0;
+               for (int dx = 0; dx < N1D; dx++) { u += B[qx][dx] * X[dx + N1D * dy]; }
+               DQ[dy][qx] = u;
+            }
+         for (int qy = 0; qy < Q1D; qy++)
+            for (int qx = 0; qx < Q1D; qx++)
+            {
+               double u = 0.0;
+               for (int dy = 0; dy < N1D; dy++) { u += B[qy][dy] * DQ[dy][qx]; }
+               QQ[qy][qx] = u * De[qx + Q1D * qy];
+            }
+         for (int qy = 0; qy < Q1D; qy++)
+            for (int dx = 0; dx < N1D; dx++)
+            {
+               double u = 0.0;
+               for (int qx = 0; qx < Q1D; qx++) { u += B[qx][dx] * QQ[qy][qx]; }
+               DQ[dx][qy] = u;
+            }
+         for (int dy = 0; dy < N1D; dy++)
+            for (int dx = 0; dx < N1D; dx++)
+            {
+               double u = 0.0;
+               for (int qy = 0; qy < Q1D; qy++) { u += B[qy][dy] * DQ[dx][qy]; }
+               Y[dx + N1D * dy] = u;
+            }
+      }
+      else
+      {
+         double DDQ[N1D][N1D][Q1D], DQQ[N1D][Q1D][Q1D], QQQ[Q1D][Q1D][Q1D];
+         for (int dz = 0; dz < N1D; dz++)
+            for (int dy = 0; dy < N1D; dy++)
+               for (int qx = 0; qx < Q1D; qx++)
+               {
+                  double u = 0.0;
+                  for (int dx = 0; dx < N1D; dx++) { u += B[qx][dx] * X[dx + N1D * (dy + N1D * dz)]; }
+                  DDQ[dz][dy][qx] = u;
+               }
+         for (int dz = 0; dz < N1D; dz++)
+            for (int qy = 0; qy < Q1D; qy++)
+               for (int qx = 0; qx < Q1D; qx++)
+               {
+                  double u = 0.0;
+                  for (int dy = 0; dy < N1D; dy++) { u += B[qy][dy] * DDQ[dz][dy][qx]; }
+                  DQQ[dz][qy][qx] = u;
+               }
+         for (int qz = 0; qz < Q1D; qz++)
+            for (int qy = 0; qy < Q1D; qy++)
+               for (int qx = 0; qx < Q1D; qx++)
+               {
+                  double u = 0.0;
+                  for (int dz = 0; dz < N1D; dz++) { u += B[qz][dz] * DQQ[dz][qy][qx]; }
+                  QQQ[qz][qy][qx] = u * De[qx + Q1D * (qy + Q1D * qz)];
+               }
+         // back: x, then y, then z
+         double QQD[Q1D][Q1D][N1D], QDD[Q1D][N1D][N1D];
+         for (int qz = 0; qz < Q1D; qz++)
+            for (int qy = 0; qy < Q1D; qy++)
+               for (int dx = 0; dx < N1D; dx++)
+               {
+                  double u = 0.0;
+                  for (int qx = 0; qx < Q1D; qx++) { u += B[qx][dx] * QQQ[qz][qy][qx]; }
+                  QQD[qz][qy][dx] = u;
+               }
+         for (int qz = 0; qz < Q1D; qz++)
+            for (int dy = 0; dy < N1D; dy++)
+               for (int dx = 0; dx < N1D; dx++)
+               {
+                  double u = 0.0;
+                  for (int qy = 0; qy < Q1D; qy++) { u += B[qy][dy] * QQD[qz][qy][dx]; }
+                  QDD[qz][dy][dx] = u;
+               }
+         for (int dz = 0; dz < N1D; dz++)
+            for (int dy = 0; dy < N1D; dy++)
+               for (int dx = 0; dx < N1D; dx++)
+               {
+                  double u = 0.0;
+                  for (int qz = 0; qz < Q1D; qz++) { u += B[qz][dz] * QDD[qz][dy][dx]; }
+                  Y[dx + N1D * (dy + N1D * dz)] = u;
+               }
+      }
+   }
+}
+
+// diag_e[d] = sum_q B(q,d)^2 D_e[q]   (upstream MassIntegrator::AssembleDiagonalPA)
+template <int DIM, int N1D, int Q1D>
+void MassDiagE(const int NE, const double *b_, const double *D, double *y)
+{
+   constexpr int ND = (DIM == 2) ? N1D * N1D : N1D * N1D * N1D;
+   constexpr int NQ = (DIM == 2) ? Q1D * Q1D : Q1D * Q1D * Q1D;
+#pragma omp parallel for schedule(static)
+   for (int e = 0; e < NE; e++)
+   {
+      const double *De = D + (size_t)NQ * e;
+      double *Y = y + (size_t)ND * e;
+      if (DIM == 2)
+      {
+         for (int dy = 0; dy < N1D; dy++)
+            for (int dx = 0; dx < N1D; dx++)
+            {
+               double s = 0.0;
+               for (int qy = 0; qy < Q1D; qy++)
+                  for (int qx = 0; qx < Q1D; qx++)
+                  {
+                     const double bx = b_[qx + Q1D * dx], by = b_[qy + Q1D * dy];
+                     s += bx * bx * by * by * De[qx + Q1D * qy];
+                  }
+               Y[dx + N1D * dy] = s;
+            }
+      }
+      else
+      {
+         for (int dz = 0; dz < N1D; dz++)
+            for (int dy = 0; dy < N1D; dy++)
+               for (int dx = 0; dx < N1D; dx++)
+               {
+                  double s = 0.0;
+                  for (int qz = 0; qz < Q1D; qz++)
+                     for (int qy = 0; qy < Q1D; qy++)
+                        for (int qx = 0; qx < Q1D; qx++)
+                        {
+                           const double bx = b_[qx + Q1D * dx], by = b_[qy + Q1D * dy],
+                                        bz = b_[qz + Q1D * dz];
+                           s += bx * bx * by * by * bz * bz * De[qx + Q1D * (qy + Q1D * qz)];
+                        }
+                  Y[dx + N1D * (dy + N1D * dz)] = s;
+               }
+      }
+   }
+}
+
+// ---------------------------------------------------------------------------
+// QuadratureInterpolator (upstream) restated.  E-vector X(d, c, e) with d
+// lexicographic; outputs byVDIM:
+//   values       q_val[c + VDIM*(q + NQ*e)]
+//   derivatives  q_der[c + VDIM*(dd + DIM*(q + NQ*e))] = d u_c / d xi_dd
+// (laghos_solver.cpp:1366-1373; consumers :1077, :1094).
+// ---------------------------------------------------------------------------
+template <int DIM, int N1D, int Q1D>
+void InterpE(const int NE, const int VDIM, const double *b_, const double *g_, const double *x,
+             double *q_val, double *q_der)
+{
+   constexpr int ND = (DIM == 2) ? N1D * N1D : N1D * N1D * N1D;
+   constexpr int NQ = (DIM == 2) ? Q1D * Q1D : Q1D * Q1D * Q1D;
+#pragma omp parallel for schedule(static)
+   for (int e = 0; e < NE; e++)
+   {
+      double B[Q1D][N1D], G[Q1D][N1D];
+      for (int q = 0; q < Q1D; q++)
+         for (int d = 0; d < N1D; d++)
+         {
+            B[q][d] = b_[q + Q1D * d];
+            G[q][d] = g_ ? g_[q + Q1D * d] : 0.0;
+         }
+      for (int c = 0; c < VDIM; c++)
+      {
+         const double *X = x + (size_t)ND * (c + VDIM * (size_t)e);
+         if (DIM == 2)
+         {
+            double Bx[N1D][Q1D], Gx[N1D][Q1D];
+            for (int dy = 0; dy < N1D; dy++)
+               for (int qx = 0; qx < Q1D; qx++)
+               {
+                  double u = 0.0, v = 0.0;
+                  for (int dx = 0; dx < N1D; dx++)
+                  {
+                     const double s = X[dx + N1D * dy];
+                     u += B[qx][dx] * s;
+                     v += G[qx][dx] * s;
+                  }
+                  Bx[dy][qx] = u;
+                  Gx[dy][qx] = v;
+               }
+            for (int qy = 0; qy < Q1D; qy++)
+               for (int qx = 0; qx < Q1D; qx++)
+               {
+                  double val = 0.0, d0 = 0.0, d1 = 0.0;
+                  for (int dy = 0; dy < N1D; dy++)
+                  {
+                     val += B[qy][dy] * Bx[dy][qx];
+                     d0 += B[qy][dy] * Gx[dy][qx];
+                     d1 += G[qy][dy] * Bx[dy][qx];
+                  }
+                  const size_t q = qx + Q1D * qy;
+                  if (q_val) { q_val[c + VDIM * (q + NQ * (size_t)e)] = val; }
+                  if (q_der)
+                  {
+                     q_der[c + VDIM * (0 + DIM * (q + NQ * (size_t)e))] = d0;
+                     q_der[c + VDIM * (1 + DIM * (q + NQ * (size_t)e))] = d1;
+                  }
+               }
+         }
+         else
+         {
+            double Bx[N1D][N1D][Q1D], Gx[N1D][N1D][Q1D];
+            double BB[N1D][Q1D][Q1D], GB[N1D][Q1D][Q1D], BG[N1D][Q1D][Q1D];
+            for (int dz = 0; dz < N1D; dz++)
+               for (int dy = 0; dy < N1D; dy++)
+                  for (int qx = 0; qx < Q1D; qx++)
+                  {
+                     double u = 0.0, v = 0.0;
+                     for (int dx = 0; dx < N1D; dx++)
+                     {
+                        const double s = X[dx + N1D * (dy + N1D * dz)];
+                        u += B[qx][dx] * s;
+                        v += G[qx][dx] * s;
+                     }
+                     Bx[dz][dy][qx] = u;
+                     Gx[dz][dy][qx] = v;
+                  }
+            for (int dz = 0; dz < N1D; dz++)
+               for (int qy = 0; qy < Q1D; qy++)
+                  for (int qx = 0; qx < Q1D; qx++)
+                  {
+                     double bb = 0.0, gb = 0.0, bg = 0.0;
+                     for (int dy = 0; dy < N1D; dy++)
+                     {
+                        bb += B[qy][dy] * Bx[dz][dy][qx];
+                        gb += B[qy][dy] * Gx[dz][dy][qx];
+                        bg += G[qy][dy] * Bx[dz][dy][qx];
+                     }
+                     BB[dz][qy][qx] = bb;
+                     GB[dz][qy][qx] = gb;
+                     BG[dz][qy][qx] = bg;
+                  }
+            for (int qz = 0; qz < Q1D; qz++)
+               for (int qy = 0; qy < Q1D; qy++)
+                  for (int qx = 0; qx < Q1D; qx++)
+                  {
+                     double val = 0.0, d0 = 0.0, d1 = 0.0, d2 = 0.0;
+                     for (int dz = 0; dz < N1D; dz++)
+                     {
+                        val += B[qz][dz] * BB[dz][qy][qx];
+                        d0 += B[qz][dz] * GB[dz][qy][qx];
+                        d1 += B[qz][dz] * BG[dz][qy][qx];
+                        d2 += G[qz][dz] * BB[dz][qy][qx];
+                     }
+                     const size_t q = qx + Q1D * (qy + Q1D * qz);
+                     if (q_val) { q_val[c + VDIM * (q + NQ * (size_t)e)] = val; }
+                     if (q_der)
+                     {
+                        q_der[c + VDIM * (0 + DIM * (q + NQ * (size_t)e))] = d0;
+                        q_der[c + VDIM * (1 + DIM * (q + NQ * (size_t)e))] = d1;
+                        q_der[c + VDIM * (2 + DIM * (q + NQ * (size_t)e))] = d2;
+                     }
+                  }
+         }
+      }
+   }
+}
+
+// laghos_solver.cpp:799-805
+inline double smooth_step_01(double x, double eps)
+{
+   const double y = (x + eps) / (2.0 * eps);
+   if (y < 0.0) { return 0.0; }
+   if (y > 1.0) { return 1.0; }
+   return (3.0 - 2.0 * y) * y * y;
+}
+// laghos_solver.cpp:987-1040
+template <int N> inline double Trace(const double *d)
+{
+   double t = 0.0;
+   for (int i = 0; i < N; i++) { t += d[i + i * N]; }
+   return t;
+}
+template <int N> inline double FNorm(const double *data)
+{
+   constexpr int hw = N * N;
+   double max_norm = 0.0, entry, fnorm2;
+   for (int i = 0; i < hw; i++)
+   {
+      entry = std::fabs(data[i]);
+      if (entry > max_norm) { max_norm = entry; }
+   }
+   if (max_norm == 0.0) { return 0.0; }
+   fnorm2 = 0.0;
+   for (int i = 0; i < hw; i++)
+   {
+      entry = data[i] / max_norm;
+      fnorm2 += entry * entry;
+   }
+   return max_norm * std::sqrt(fnorm2);
+}
+
+// laghos_solver.cpp:1042-1168 (QUpdateBody) driven as QKernel :1263-1352
+template <int DIM>
+void QKernel(const int NE, const int NQ, const bool use_viscosity, const bool use_vorticity,
+             const double h0, const double h1order, const double cfl, const double infinity,
+             const double *d_gamma, const double *d_weights, const double *d_Jacobians,
+             const double *d_rho0DetJ0w, const double *d_e_quads, const double *d_grad_v_ext,
+             const double *d_Jac0inv, double *d_dt_est, double *d_stressJinvT)
+{
+   constexpr int DIM2 = DIM * DIM;
+#pragma omp parallel for schedule(static)
+   for (int e = 0; e < NE; e++)
+   {
+      double Jinv[DIM2], stress[DIM2], sgrad_v[DIM2], eig_val_data[3], eig_vec_data[9];
+      double compr_dir[DIM], Jpi[DIM2], ph_dir[DIM], stressJiT[DIM2];
+      for (int q = 0; q < NQ; q++)
+      {
+         double min_detJ = infinity;
+         const size_t eq = (size_t)e * NQ + q;
+         const double gamma = d_gamma[e];
+         const double weight = d_weights[q];
+         const double inv_weight = 1. / weight;
+         const double *J = d_Jacobians + DIM2 * eq;
+         const double detJ = sm::Det<DIM>(J);
+         min_detJ = std::fmin(min_detJ, detJ);
+         sm::CalcInverse<DIM>(J, Jinv);
+         const double R = inv_weight * d_rho0DetJ0w[eq] / detJ;
+         const double E = std::fmax(0.0, d_e_quads[eq]);
+         const double P = (gamma - 1.0) * R * E;
+         const double S = std::sqrt(gamma * (gamma - 1.0) * E);
+         for (int k = 0; k < DIM2; k++) { stress[k] = 0.0; }
+         for (int d = 0; d < DIM; d++) { stress[d * DIM + d] = -P; }
+         double visc_coeff = 0.0;
+         if (use_viscosity)
+         {
+            const double *dV = d_grad_v_ext + DIM2 * eq;
+            sm::Mult(DIM, DIM, DIM, dV, Jinv, sgrad_v);
+            double vorticity_coeff = 1.0;
+            if (use_vorticity)
+            {
+               const double grad_norm = FNorm<DIM>(sgrad_v);
+               const double div_v = std::fabs(Trace<DIM>(sgrad_v));
+               vorticity_coeff = (grad_norm > 0.0) ? div_v / grad_norm : 1.0;
+            }
+            sm::Symmetrize(DIM, sgrad_v);
+            sm::CalcEigenvalues<DIM>(sgrad_v, eig_val_data, eig_vec_data);
+            for (int k = 0; k < DIM; k++) { compr_dir[k] = eig_vec_data[k]; }
+            sm::Mult(DIM, DIM, DIM, J, d_Jac0inv + eq * DIM * DIM, Jpi);
+            sm::MultV(DIM, DIM, Jpi, compr_dir, ph_dir);
+            const double ph_dir_nl2 = sm::Norml2(DIM, ph_dir);
+            const double compr_dir_nl2 = sm::Norml2(DIM, compr_dir);
+            const double H = h0 * ph_dir_nl2 / compr_dir_nl2;
+            const double mu = eig_val_data[0];
+            visc_coeff = 2.0 * R * H * H * std::fabs(mu);
+            const double eps = 1e-12;
+            visc_coeff += 0.5 * R * H * S * vorticity_coeff * (1.0 - smooth_step_01(mu - 2.0 * eps, eps));
+            sm::Add(DIM, DIM, visc_coeff, stress, sgrad_v, stress);
+         }
+         const double sv = sm::CalcSingularvalue<DIM>(J, DIM - 1);
+         const double h_min = sv / h1order;
+         const double ih_min = 1. / h_min;
+         const double irho_ih_min_sq = ih_min * ih_min / R;
+         const double idt = S * ih_min + 2.5 * visc_coeff * irho_ih_min_sq;
+         if (min_detJ < 0.0) { d_dt_est[eq] = 0.0; }
+         else
+         {
+            if (idt > 0.0)
+            {
+               const double cfl_inv_dt = cfl / idt;
+               d_dt_est[eq] = std::fmin(d_dt_est[eq], cfl_inv_dt);
+            }
+         }
+         sm::MultABt(DIM, DIM, DIM, stress, Jinv, stressJiT);
+         for (int k = 0; k < DIM2; k++) { stressJiT[k] *= weight * detJ; }
+         for (int vd = 0; vd < DIM; vd++)
+            for (int gd = 0; gd < DIM; gd++)
+            {
+               const size_t offset = eq + (size_t)NQ * NE * (gd + vd * DIM);
+               d_stressJinvT[offset] = stressJiT[vd + gd * DIM];
+            }
+      }
+   }
+}
+
+// ---------------------------------------------------------------------------
+// Context: plays the role of LagrangianHydroOperator's owned state
+// (laghos_solver.hpp:97-205): spaces (as dof maps), tables, QuadratureData,
+// PA operators, CG work vectors.
+// ---------------------------------------------------------------------------
+struct Ctx
+{
+   int dim, NE, D1D, Q1D, L1D, ND, NQ, NL;
+   int N;           // scalar H1 nodes (local)
+   int H1V, L2V;    // vector sizes
+   std::vector<int> h1map;             // NE x ND -> scalar node
+   std::vector<double> B, G, Bt, Gt;   // H1: B,G (Q x D, q fastest), Bt,Gt (D x Q)
+   std::vector<double> Bl, Blt;        // L2: B (Q x L), Bt (L x Q)
+   std::vector<double> W;              // NQ weights
+   std::vector<double> gamma;          // NE
+   std::vector<int> ess[3];            // essential scalar nodes per component
+   std::vector<double> owner;          // N: 1.0 if this rank owns the node (dot products)
+   bool visc, vort;
+   double cfl, h0;
+   int order_v;
+   // QuadratureData (laghos_assembly.hpp:31-62)
+   std::vector<double> Jac0inv, stressJinvT, rho0DetJ0w;
+   double dt_est;
+   // mass PA data D = w*detJ0*rho0(x_q) (laghos_assembly.cpp:92-95), shared by H1c and L2
+   std::vector<double> massD;
+   std::vector<double> diagV;          // Jacobi diagonal of the scalar H1 mass
+   int cur_ess;                        // component whose ess list is active (-1 none)
+   // scratch
+   std::vector<double> XE, YE, q_dx, q_dv, q_e, q_dt, e_vec;
+   std::vector<double> cg_r, cg_z, cg_d;
+   // timers (laghos_solver.hpp:39-56)
+   double t_force, t_cgH1, t_cgL2, t_qdata;
+   long H1iter, L2iter, quad_tstep;
+};
+
+double now()
+{
+#ifdef _OPENMP
+   return omp_get_wtime();
+#else
+   return (double)clock() / CLOCKS_PER_SEC;
+#endif
+}
+
+[[noreturn]] void unknown_kernel(int id)
+{
+   // laghos_assembly.cpp:549-553
+   std::fprintf(stderr, "Unknown kernel 0x%x\n", id);
+   std::abort();
+}
+
+#define LGO_DISPATCH_2D(FN, id, ...)                                   \
+   switch (id)                                                         \
+   {                                                                   \
+      case 0x222: FN<2, 2, 1>(__VA_ARGS__); break;                     \
+      case 0x234: FN<3, 4, 2>(__VA_ARGS__); break;                     \
+      case 0x246: FN<4, 6, 3>(__VA_ARGS__); break;                     \
+      case 0x258: FN<5, 8, 4>(__VA_ARGS__); break;                     \
+      case 0x26A: FN<6, 10, 5>(__VA_ARGS__); break;                    \
+      default: unknown_kernel(id);                                     \
+   }
+// 0x36A (Q5/Q4 in 3D) is NOT instantiated by the reference
+// (laghos_assembly.cpp:544-547); it is an extension here for BASELINE config 5.
+#define LGO_DISPATCH_3D(FN, id, ...)                                   \
+   switch (id)                                                         \
+   {                                                                   \
+      case 0x322: FN<2, 2, 1>(__VA_ARGS__); break;                     \
+      case 0x334: FN<3, 4, 2>(__VA_ARGS__); break;                     \
+      case 0x346: FN<4, 6, 3>(__VA_ARGS__); break;                     \
+      case 0x358: FN<5, 8, 4>(__VA_ARGS__); break;                     \
+      case 0x36A: FN<6, 10, 5>(__VA_ARGS__); break;                    \
+      default: unknown_kernel(id);                                     \
+   }
+
+void force_mult_E(const Ctx &c, const double *sJit, const double *XE, double *YE)
+{
+   const int id = (c.dim << 8) | (c.D1D << 4) | c.Q1D;
+   if (c.dim == 2) { LGO_DISPATCH_2D(ForceMult2D, id, c.NE, c.Bl.data(), c.Bt.data(), c.Gt.data(), sJit, XE, YE); }
+   else { LGO_DISPATCH_3D(ForceMult3D, id, c.NE, c.Bl.data(), c.Bt.data(), c.Gt.data(), sJit, XE, YE); }
+}
+void force_mult_t_E(const Ctx &c, const double *sJit, const double *YE, double *XE)
+{
+   const int id = (c.dim << 8) | (c.D1D << 4) | c.Q1D;
+   if (c.dim == 2) { LGO_DISPATCH_2D(ForceMultTranspose2D, id, c.NE, c.Blt.data(), c.B.data(), c.G.data(), sJit, YE, XE); }
+   else { LGO_DISPATCH_3D(ForceMultTranspose3D, id, c.NE, c.Blt.data(), c.B.data(), c.G.data(), sJit, YE, XE); }
+}
+
+template <int DIM> void mass_apply_dispatch(int N1D, int Q1D, int NE, const double *b, const double *D, const double *x, double *y)
+{
+   const int id = (N1D << 4) | Q1D;
+   switch (id)
+   {
+      case 0x12: MassApplyE<DIM, 1, 2>(NE, b, D, x, y); break;
+      case 0x22: MassApplyE<DIM, 2, 2>(NE, b, D, x, y); break;
+      case 0x24: MassApplyE<DIM, 2, 4>(NE, b, D, x, y); break;
+      case 0x34: MassApplyE<DIM, 3, 4>(NE, b, D, x, y); break;
+      case 0x36: MassApplyE<DIM, 3, 6>(NE, b, D, x, y); break;
+      case 0x46: MassApplyE<DIM, 4, 6>(NE, b, D, x, y); break;
+      case 0x48: MassApplyE<DIM, 4, 8>(NE, b, D, x, y); break;
+      case 0x58: MassApplyE<DIM, 5, 8>(NE, b, D, x, y); break;
+      case 0x5A: MassApplyE<DIM, 5, 10>(NE, b, D, x, y); break;
+      case 0x6A: MassApplyE<DIM, 6, 10>(NE, b, D, x, y); break;
+      default: unknown_kernel(id);
+   }
+}
+template <int DIM> void mass_diag_dispatch(int N1D, int Q1D, int NE, const double *b, const double *D, double *y)
+{
+   const int id = (N1D << 4) | Q1D;
+   switch (id)
+   {
+      case 0x22: MassDiagE<DIM, 2, 2>(NE, b, D, y); break;
+      case 0x34: MassDiagE<DIM, 3, 4>(NE, b, D, y); break;
+      case 0x46: MassDiagE<DIM, 4, 6>(NE, b, D, y); break;
+      case 0x58: MassDiagE<DIM, 5, 8>(NE, b, D, y); break;
+      case 0x6A: MassDiagE<DIM, 6, 10>(NE, b, D, y); break;
+      default: unknown_kernel(id);
+   }
+}
+template <int DIM> void interp_dispatch(int N1D, int Q1D, int NE, int VDIM, const double *b, const double *g, const double *x, double *qv, double *qd)
+{
+   const int id = (N1D << 4) | Q1D;
+   switch (id)
+   {
+      case 0x12: InterpE<DIM, 1, 2>(NE, VDIM, b, g, x, qv, qd); break;
+      case 0x22: InterpE<DIM, 2, 2>(NE, VDIM, b, g, x, qv, qd); break;
+      case 0x24: InterpE<DIM, 2, 4>(NE, VDIM, b, g, x, qv, qd); break;
+      case 0x34: InterpE<DIM, 3, 4>(NE, VDIM, b, g, x, qv, qd); break;
+      case 0x36: InterpE<DIM, 3, 6>(NE, VDIM, b, g, x, qv, qd); break;
+      case 0x46: InterpE<DIM, 4, 6>(NE, VDIM, b, g, x, qv, qd); break;
+      case 0x48: InterpE<DIM, 4, 8>(NE, VDIM, b, g, x, qv, qd); break;
+      case 0x58: InterpE<DIM, 5, 8>(NE, VDIM, b, g, x, qv, qd); break;
+      case 0x5A: InterpE<DIM, 5, 10>(NE, VDIM, b, g, x, qv, qd); break;
+      case 0x6A: InterpE<DIM, 6, 10>(NE, VDIM, b, g, x, qv, qd); break;
+      default: unknown_kernel(id);
+   }
+}
+
+void mass_apply_E(const Ctx &c, int space, const double *x, double *y)
+{
+   const int N1D = space == 0 ? c.D1D : c.L1D;
+   const double *b = space == 0 ? c.B.data() : c.Bl.data();
+   if (c.dim == 2) { mass_apply_dispatch<2>(N1D, c.Q1D, c.NE, b, c.massD.data(), x, y); }
+   else { mass_apply_dispatch<3>(N1D, c.Q1D, c.NE, b, c.massD.data(), x, y); }
+}
+
+// ElementRestriction (upstream), lexicographic: L -> E gather, byNODES L-vector.
+void h1_gather(const Ctx &c, int vdim, const double *xL, double *XE)
+{
+#pragma omp parallel for schedule(static)
+   for (int e = 0; e < c.NE; e++)
+      for (int cc = 0; cc < vdim; cc++)
+         for (int d = 0; d < c.ND; d++)
+         {
+            XE[d + c.ND * (cc + vdim * (size_t)e)] = xL[(size_t)cc * c.N + c.h1map[(size_t)e * c.ND + d]];
+         }
+}
+// E -> L transpose: sums element contributions in ascending element order
+// (the order of MFEM's offsets/indices table).
+void h1_scatter_add(const Ctx &c, int vdim, const double *YE, double *yL)
+{
+   std::memset(yL, 0, sizeof(double) * (size_t)vdim * c.N);
+   for (int e = 0; e < c.NE; e++)
+      for (int cc = 0; cc < vdim; cc++)
+         for (int d = 0; d < c.ND; d++)
+         {
+            yL[(size_t)cc * c.N + c.h1map[(size_t)e * c.ND + d]] += YE[d + c.ND * (cc + vdim * (size_t)e)];
+         }
+}
+
+double dot_owned(const Ctx &c, const double *a, const double *b)
+{
+   double s = 0.0;
+#pragma omp parallel for reduction(+ : s) schedule(static)
+   for (int i = 0; i < c.N; i++) { s += c.owner[i] * a[i] * b[i]; }
+   return s;
+}
+double dot_plain(size_t n, const double *a, const double *b)
+{
+   double s = 0.0;
+#pragma omp parallel for reduction(+ : s) schedule(static)
+   for (size_t i = 0; i < n; i++) { s += a[i] * b[i]; }
+   return s;
+}
+
+} // namespace
+
+extern "C"
+{
+
+// Optional hooks for multi-rank runs (tests drive them from Python over gloo):
+// sum the shared H1 nodes across ranks in-place; all-reduce a scalar (0 sum, 1 min).
+typedef void (*lgo_halo_fn)(double *vec_L, int ncomp, void *user);
+typedef double (*lgo_allreduce_fn)(double v, int op, void *user);
+static lgo_halo_fn g_halo = nullptr;
+static lgo_allreduce_fn g_allreduce = nullptr;
+static void *g_user = nullptr;
+void lgo_set_comm_hooks(lgo_halo_fn h, lgo_allreduce_fn a, void *user)
+{
+   g_halo = h;
+   g_allreduce = a;
+   g_user = user;
+}
+static double allreduce(double v, int op) { return g_allreduce ? g_allreduce(v, op, g_user) : v; }
+static void halo(double *v, int nc)
+{
+   if (g_halo) { g_halo(v, nc, g_user); }
+}
+
+void *lgo_create(int dim, int NE, int D1D, int Q1D, int L1D, int N, const int *h1map,
+                 const double *B, const double *G, const double *Bl, const double *W,
+                 const double *gamma, const int *ess_counts, const int *ess0, const int *ess1,
+                 const int *ess2, const double *owner, int visc, int vort, double cfl, int order_v)
+{
+   Ctx *c = new Ctx;
+   c->dim = dim; c->NE = NE; c->D1D = D1D; c->Q1D = Q1D; c->L1D = L1D; c->N = N;
+   c->ND = dim == 2 ? D1D * D1D : D1D * D1D * D1D;
+   c->NQ = dim == 2 ? Q1D * Q1D : Q1D * Q1D * Q1D;
+   c->NL = dim == 2 ? L1D * L1D : L1D * L1D * L1D;
+   c->H1V = dim * N;
+   c->L2V = NE * c->NL;
+   c->h1map.assign(h1map, h1map + (size_t)NE * c->ND);
+   c->B.assign(B, B + Q1D * D1D);
+   c->G.assign(G, G + Q1D * D1D);
+   c->Bt.resize(Q1D * D1D);
+   c->Gt.resize(Q1D * D1D);
+   for (int q = 0; q < Q1D; q++)
+      for (int d = 0; d < D1D; d++)
+      {
+         c->Bt[d + D1D * q] = B[q + Q1D * d];
+         c->Gt[d + D1D * q] = G[q + Q1D * d];
+      }
+   c->Bl.assign(Bl, Bl + Q1D * L1D);
+   c->Blt.resize(Q1D * L1D);
+   for (int q = 0; q < Q1D; q++)
+      for (int l = 0; l < L1D; l++) { c->Blt[l + L1D * q] = Bl[q + Q1D * l]; }
+   c->W.assign(W, W + c->NQ);
+   c->gamma.assign(gamma, gamma + NE);
+   const int *ess[3] = {ess0, ess1, ess2};
+   for (int k = 0; k < dim; k++) { c->ess[k].assign(ess[k], ess[k] + ess_counts[k]); }
+   c->owner.assign(owner, owner + N);
+   c->visc = visc; c->vort = vort; c->cfl = cfl; c->order_v = order_v;
+   c->h0 = 0.0;
+   const size_t nq = (size_t)NE * c->NQ;
+   c->Jac0inv.assign(nq * dim * dim, 0.0);
+   c->stressJinvT.assign(nq * dim * dim, 0.0);
+   c->rho0DetJ0w.assign(nq, 0.0);
+   c->massD.assign(nq, 0.0);
+   c->diagV.assign(N, 0.0);
+   c->dt_est = std::numeric_limits<double>::infinity();
+   c->cur_ess = -1;
+   c->XE.assign(std::max((size_t)c->L2V, (size_t)NE * c->ND * dim), 0.0);
+   c->YE.assign((size_t)NE * c->ND * dim, 0.0);
+   c->e_vec.assign((size_t)NE * c->ND * dim, 0.0);
+   c->q_dx.assign(nq * dim * dim, 0.0);
+   c->q_dv.assign(nq * dim * dim, 0.0);
+   c->q_e.assign(nq, 0.0);
+   c->q_dt.assign(nq, 0.0);
+   c->cg_r.assign(std::max(N, c->L2V), 0.0);
+   c->cg_z.assign(std::max(N, c->L2V), 0.0);
+   c->cg_d.assign(std::max(N, c->L2V), 0.0);
+   c->t_force = c->t_cgH1 = c->t_cgL2 = c->t_qdata = 0.0;
+   c->H1iter = c->L2iter = c->quad_tstep = 0;
+   return c;
+}
+void lgo_destroy(void *h) { delete (Ctx *)h; }
+
+double *lgo_stressJinvT(void *h) { return ((Ctx *)h)->stressJinvT.data(); }
+double *lgo_Jac0inv(void *h) { return ((Ctx *)h)->Jac0inv.data(); }
+double *lgo_rho0DetJ0w(void *h) { return ((Ctx *)h)->rho0DetJ0w.data(); }
+double *lgo_massD(void *h) { return ((Ctx *)h)->massD.data(); }
+double *lgo_diagV(void *h) { return ((Ctx *)h)->diagV.data(); }
+double *lgo_q_dx(void *h) { return ((Ctx *)h)->q_dx.data(); }
+double *lgo_q_dv(void *h) { return ((Ctx *)h)->q_dv.data(); }
+double *lgo_q_e(void *h) { return ((Ctx *)h)->q_e.data(); }
+double lgo_get_h0(void *h) { return ((Ctx *)h)->h0; }
+void lgo_set_h0(void *h, double v) { ((Ctx *)h)->h0 = v; }
+double lgo_get_dt_est(void *h) { return ((Ctx *)h)->dt_est; }
+void lgo_set_dt_est(void *h, double v) { ((Ctx *)h)->dt_est = v; }
+void lgo_get_timers(void *h, double *t4, long *c3)
+{
+   Ctx *c = (Ctx *)h;
+   t4[0] = c->t_cgH1; t4[1] = c->t_cgL2; t4[2] = c->t_force; t4[3] = c->t_qdata;
+   c3[0] = c->H1iter; c3[1] = c->L2iter; c3[2] = c->quad_tstep;
+}
+void lgo_reset_timers(void *h)
+{
+   Ctx *c = (Ctx *)h;
+   c->t_force = c->t_cgH1 = c->t_cgL2 = c->t_qdata = 0.0;
+   c->H1iter = c->L2iter = c->quad_tstep = 0;
+}
+
+// --- E-vector level kernels (for kernel-granularity parity tests) ----------
+void lgo_force_mult_E(void *h, const double *sJit, const double *XE, double *YE) { force_mult_E(*(Ctx *)h, sJit, XE, YE); }
+void lgo_force_mult_t_E(void *h, const double *sJit, const double *YE, double *XE) { force_mult_t_E(*(Ctx *)h, sJit, YE, XE); }
+void lgo_mass_apply_E(void *h, int space, const double *XE, double *YE) { mass_apply_E(*(Ctx *)h, space, XE, YE); }
+void lgo_h1_gather(void *h, int vdim, const double *xL, double *XE) { h1_gather(*(Ctx *)h, vdim, xL, XE); }
+void lgo_h1_scatter_add(void *h, int vdim, const double *YE, double *yL) { h1_scatter_add(*(Ctx *)h, vdim, YE, yL); }
+void lgo_qkernel(void *h, const double *q_dx, const double *q_e, const double *q_dv, double *q_dt, double *sJit)
+{
+   Ctx *c = (Ctx *)h;
+   const double inf = std::numeric_limits<double>::infinity();
+   if (c->dim == 2) { QKernel<2>(c->NE, c->NQ, c->visc, c->vort, c->h0, (double)c->order_v, c->cfl, inf, c->gamma.data(), c->W.data(), q_dx, c->rho0DetJ0w.data(), q_e, q_dv, c->Jac0inv.data(), q_dt, sJit); }
+   else { QKernel<3>(c->NE, c->NQ, c->visc, c->vort, c->h0, (double)c->order_v, c->cfl, inf, c->gamma.data(), c->W.data(), q_dx, c->rho0DetJ0w.data(), q_e, q_dv, c->Jac0inv.data(), q_dt, sJit); }
+}
+// small-matrix probes for tests (vs numpy)
+void lgo_eig3(const double *A, double *lam, double *vec) { sm::CalcEigenvalues<3>(A, lam, vec); }
+void lgo_eig2(const double *A, double *lam, double *vec) { sm::CalcEigenvalues<2>(A, lam, vec); }
+double lgo_sv3(const double *A, int i) { return sm::CalcSingularvalue<3>(A, i); }
+double lgo_sv2(const double *A, int i) { return sm::CalcSingularvalue<2>(A, i); }
+
+// --- operator level (L-vectors), mirroring the reference classes -----------
+
+// ForcePAOperator::Mult (laghos_assembly.cpp:557-565): x L2 L-vector, y H1 L-vector (byNODES)
+void lgo_force_mult(void *h, const double *x, double *y)
+{
+   Ctx *c = (Ctx *)h;
+   // L2R->Mult is the identity copy for lexicographic L2
+   force_mult_E(*c, c->stressJinvT.data(), x, c->YE.data());
+   h1_scatter_add(*c, c->dim, c->YE.data(), y);
+   halo(y, c->dim);
+}
+// ForcePAOperator::MultTranspose (laghos_assembly.cpp:965-973)
+void lgo_force_mult_transpose(void *h, const double *v, double *y)
+{
+   Ctx *c = (Ctx *)h;
+   h1_gather(*c, c->dim, v, c->YE.data());
+   force_mult_t_E(*c, c->stressJinvT.data(), c->YE.data(), y);
+}
+// MassPAOperator::SetEssentialTrueDofs (laghos_assembly.cpp:98-110) with c_tdofs[comp]
+void lgo_mass_set_ess(void *h, int comp) { ((Ctx *)h)->cur_ess = comp; }
+// MassPAOperator::EliminateRHS (laghos_assembly.cpp:112-115)
+void lgo_mass_eliminate_rhs(void *h, double *b)
+{
+   Ctx *c = (Ctx *)h;
+   if (c->cur_ess >= 0)
+      for (int i : c->ess[c->cur_ess]) { b[i] = 0.0; }
+}
+// MassPAOperator::MultFull / Mult (laghos_assembly.cpp:117-121; hpp:127)
+void lgo_mass_mult(void *h, int space, int full, const double *x, double *y)
+{
+   Ctx *c = (Ctx *)h;
+   if (space == 0)
+   {
+      h1_gather(*c, 1, x, c->XE.data());
+      mass_apply_E(*c, 0, c->XE.data(), c->YE.data());
+      h1_scatter_add(*c, 1, c->YE.data(), y);
+      halo(y, 1);
+      if (!full && c->cur_ess >= 0)
+         for (int i : c->ess[c->cur_ess]) { y[i] = 0.0; }
+   }
+   else { mass_apply_E(*c, 1, x, y); }
+}
+// Jacobi diagonal for OperatorJacobiSmoother (laghos_solver.cpp:266-270), empty ess list
+void lgo_mass_assemble_diag(void *h)
+{
+   Ctx *c = (Ctx *)h;
+   if (c->dim == 2) { mass_diag_dispatch<2>(c->D1D, c->Q1D, c->NE, c->B.data(), c->massD.data(), c->YE.data()); }
+   else { mass_diag_dispatch<3>(c->D1D, c->Q1D, c->NE, c->B.data(), c->massD.data(), c->YE.data()); }
+   h1_scatter_add(*c, 1, c->YE.data(), c->diagV.data());
+   halo(c->diagV.data(), 1);
+}
+
+// Rho0DetJ0Vol (laghos_solver.cpp:1170-1261).  x0: H1 L-vector of initial node
+// positions; rho0_l2: rho0 grid function (Bernstein L2 dofs) -> rho0DetJ0w and
+// Jac0inv; rho0_q: the *function* rho0 at the physical quadrature points ->
+// mass PA data (laghos_assembly.cpp:92-95).  Returns local volume.
+double lgo_setup_rho0detj0(void *h, const double *x0, const double *rho0_l2, const double *rho0_q)
+{
+   Ctx *c = (Ctx *)h;
+   const int dim = c->dim, NQ = c->NQ, NE = c->NE;
+   h1_gather(*c, dim, x0, c->e_vec.data());
+   if (dim == 2) { interp_dispatch<2>(c->D1D, c->Q1D, NE, dim, c->B.data(), c->G.data(), c->e_vec.data(), nullptr, c->q_dx.data()); }
+   else { interp_dispatch<3>(c->D1D, c->Q1D, NE, dim, c->B.data(), c->G.data(), c->e_vec.data(), nullptr, c->q_dx.data()); }
+   if (dim == 2) { interp_dispatch<2>(c->L1D, c->Q1D, NE, 1, c->Bl.data(), nullptr, rho0_l2, c->q_e.data(), nullptr); }
+   else { interp_dispatch<3>(c->L1D, c->Q1D, NE, 1, c->Bl.data(), nullptr, rho0_l2, c->q_e.data(), nullptr); }
+   double vol = 0.0;
+   for (int e = 0; e < NE; e++)
+      for (int q = 0; q < NQ; q++)
+      {
+         const size_t eq = (size_t)e * NQ + q;
+         const double *J = c->q_dx.data() + eq * dim * dim; // J(i,j) at i + dim*j
+         double *Ji = c->Jac0inv.data() + eq * dim * dim;
+         double det;
+         if (dim == 2)
+         {
+            const double J11 = J[0], J12 = J[1], J21 = J[2], J22 = J[3]; // names as reference :1209-1212
+            det = sm::Det<2>(J);
+            const double r = 1.0 / det;
+            Ji[0] = J22 * r;
+            Ji[1] = -J12 * r;
+            Ji[2] = -J21 * r;
+            Ji[3] = J11 * r;
+         }
+         else
+         {
+            // reference :1237-1251 with J(q,i,j,e): Jab = J(q,a-1,b-1,e)
+            const double J11 = J[0], J12 = J[3], J13 = J[6];
+            const double J21 = J[1], J22 = J[4], J23 = J[7];
+            const double J31 = J[2], J32 = J[5], J33 = J[8];
+            det = sm::Det<3>(J);
+            const double r = 1.0 / det;
+            Ji[0] = r * ((J22 * J33) - (J23 * J32));
+            Ji[1] = r * ((J32 * J13) - (J33 * J12));
+            Ji[2] = r * ((J12 * J23) - (J13 * J22));
+            Ji[3] = r * ((J23 * J31) - (J21 * J33));
+            Ji[4] = r * ((J33 * J11) - (J31 * J13));
+            Ji[5] = r * ((J13 * J21) - (J11 * J23));
+            Ji[6] = r * ((J21 * J32) - (J22 * J31));
+            Ji[7] = r * ((J31 * J12) - (J32 * J11));
+            Ji[8] = r * ((J11 * J22) - (J12 * J21));
+         }
+         c->rho0DetJ0w[eq] = c->W[q] * c->q_e[eq] * det;
+         c->massD[eq] = c->W[q] * det * rho0_q[eq];
+         vol += c->W[q] * det;
+      }
+   return vol;
+}
+
+// QUpdate::UpdateQuadratureData (laghos_solver.cpp:1354-1411); S = [x | v | e]
+void lgo_qupdate(void *h, const double *S)
+{
+   Ctx *c = (Ctx *)h;
+   const double t0 = now();
+   const int dim = c->dim, NE = c->NE;
+   const double *x = S, *v = S + c->H1V, *e = S + 2 * (size_t)c->H1V;
+   h1_gather(*c, dim, x, c->e_vec.data());
+   if (dim == 2) { interp_dispatch<2>(c->D1D, c->Q1D, NE, dim, c->B.data(), c->G.data(), c->e_vec.data(), nullptr, c->q_dx.data()); }
+   else { interp_dispatch<3>(c->D1D, c->Q1D, NE, dim, c->B.data(), c->G.data(), c->e_vec.data(), nullptr, c->q_dx.data()); }
+   h1_gather(*c, dim, v, c->e_vec.data());
+   if (dim == 2) { interp_dispatch<2>(c->D1D, c->Q1D, NE, dim, c->B.data(), c->G.data(), c->e_vec.data(), nullptr, c->q_dv.data()); }
+   else { interp_dispatch<3>(c->D1D, c->Q1D, NE, dim, c->B.data(), c->G.data(), c->e_vec.data(), nullptr, c->q_dv.data()); }
+   if (dim == 2) { interp_dispatch<2>(c->L1D, c->Q1D, NE, 1, c->Bl.data(), nullptr, e, c->q_e.data(), nullptr); }
+   else { interp_dispatch<3>(c->L1D, c->Q1D, NE, 1, c->Bl.data(), nullptr, e, c->q_e.data(), nullptr); }
+   std::fill(c->q_dt.begin(), c->q_dt.end(), c->dt_est); // :1374
+   lgo_qkernel(h, c->q_dx.data(), c->q_e.data(), c->q_dv.data(), c->q_dt.data(), c->stressJinvT.data());
+   double m = std::numeric_limits<double>::infinity();
+   for (double d : c->q_dt) { m = std::fmin(m, d); }
+   c->dt_est = m; // :1406
+   c->t_qdata += now() - t0;
+   c->quad_tstep += NE;
+}
+
+// CGSolver::Mult (upstream MFEM linalg/solvers.cpp, restated).
+// space 0: scalar H1 mass with the active essential list, Jacobi
+// preconditioner, iterative_mode=true (X holds the initial guess);
+// space 1: L2 mass, no preconditioner, iterative_mode=false.
+// Dot products count shared dofs once (owner mask) and are all-reduced.
+int lgo_cg(void *h, int space, const double *b, double *x, double rel_tol, int max_iter)
+{
+   Ctx *c = (Ctx *)h;
+   const double t0 = now();
+   const int n = space == 0 ? c->N : c->L2V;
+   double *r = c->cg_r.data(), *z = c->cg_z.data(), *d = c->cg_d.data();
+   auto dot = [&](const double *a, const double *bb) {
+      const double s = space == 0 ? dot_owned(*c, a, bb) : dot_plain(n, a, bb);
+      return allreduce(s, 0);
+   };
+   int final_iter = 0;
+   const bool prec = (space == 0);
+   if (space == 0)
+   {
+      lgo_mass_mult(h, 0, 0, x, r);
+      for (int i = 0; i < n; i++) { r[i] = b[i] - r[i]; }
+   }
+   else
+   {
+      for (int i = 0; i < n; i++) { r[i] = b[i]; x[i] = 0.0; }
+   }
+   if (prec)
+   {
+      for (int i = 0; i < n; i++) { z[i] = r[i] / c->diagV[i]; d[i] = z[i]; }
+   }
+   else
+   {
+      for (int i = 0; i < n; i++) { d[i] = r[i]; }
+   }
+   double nom = dot(d, r);
+   if (nom < 0.0) { final_iter = 0; goto done; }
+   {
+      const double r0 = std::max(nom * rel_tol * rel_tol, 0.0);
+      if (nom <= r0) { final_iter = 0; goto done; }
+      lgo_mass_mult(h, space, 0, d, z);
+      double den = dot(z, d);
+      if (den <= 0.0 && den == 0.0) { final_iter = 0; goto done; }
+      final_iter = max_iter;
+      for (int i = 1; true;)
+      {
+         const double alpha = nom / den;
+#pragma omp parallel for schedule(static)
+         for (int k = 0; k < n; k++)
+         {
+            x[k] = x[k] + alpha * d[k];
+            r[k] = r[k] - alpha * z[k];
+         }
+         double betanom;
+         if (prec)
+         {
+#pragma omp parallel for schedule(static)
+            for (int k = 0; k < n; k++) { z[k] = r[k] / c->diagV[k]; }
+            betanom = dot(r, z);
+         }
+         else { betanom = dot(r, r); }
+         if (betanom < 0.0) { final_iter = i; break; }
+         if (betanom <= r0) { final_iter = i; break; }
+         if (++i > max_iter) { break; }
+         const double beta = betanom / nom;
+         if (prec)
+         {
+#pragma omp parallel for schedule(static)
+            for (int k = 0; k < n; k++) { d[k] = z[k] + beta * d[k]; }
+         }
+         else
+         {
+#pragma omp parallel for schedule(static)
+            for (int k = 0; k < n; k++) { d[k] = r[k] + beta * d[k]; }
+         }
+         lgo_mass_mult(h, space, 0, d, z);
+         den = dot(d, z);
+         if (den <= 0.0 && den == 0.0) { final_iter = i; break; }
+         nom = betanom;
+      }
+   }
+done:
+   if (space == 0) { c->t_cgH1 += now() - t0; c->H1iter += final_iter; }
+   else { c->t_cgL2 += now() - t0; c->L2iter += (final_iter == 0) ? 1 : final_iter; } // laghos_solver.cpp:486
+   return final_iter;
+}
+
+// LagrangianHydroOperator::Mult (laghos_solver.cpp:308-327) with
+// SolveVelocity (:329-399) and SolveEnergy (:442-490), PA branch, no sources.
+// S = [x|v|e], dS = [dx|dv|de].  The caller owns the qdata_is_current flag
+// (laghos_solver.cpp:809-812, :326): when set, UpdateQuadratureData is skipped.
+void lgo_hydro_mult(void *h, const double *S, double *dS, double cg_tol, int cg_max_iter,
+                    const double *e_source /* optional L2 L-vector or NULL */,
+                    int qdata_is_current /* :809 early return */)
+{
+   Ctx *c = (Ctx *)h;
+   const int dim = c->dim, N = c->N, H1V = c->H1V, L2V = c->L2V;
+   const double *v = S + H1V;
+   double *dx = dS, *dv = dS + H1V, *de = dS + 2 * (size_t)H1V;
+   std::memcpy(dx, v, sizeof(double) * H1V); // :323
+   // --- SolveVelocity
+   if (!qdata_is_current) { lgo_qupdate(h, S); } // :332, :809
+   std::fill(dv, dv + H1V, 0.0);
+   std::vector<double> one(L2V, 1.0), rhs(H1V), Bv(N), e_rhs(L2V);
+   double t0 = now();
+   lgo_force_mult(h, one.data(), rhs.data()); // :354
+   c->t_force += now() - t0;
+   for (int i = 0; i < H1V; i++) { rhs[i] = -rhs[i]; } // :358
+   for (int cc = 0; cc < dim; cc++)
+   {
+      std::memcpy(Bv.data(), rhs.data() + (size_t)cc * N, sizeof(double) * N); // :368-369
+      double *X = dv + (size_t)cc * N;                                           // :382 (dv = 0)
+      lgo_mass_set_ess(h, cc);                                                   // :383
+      lgo_mass_eliminate_rhs(h, Bv.data());                                      // :384
+      lgo_cg(h, 0, Bv.data(), X, cg_tol, cg_max_iter);                           // :388
+   }
+   // --- SolveEnergy (quadrature data is current)
+   t0 = now();
+   lgo_force_mult_transpose(h, v, e_rhs.data()); // :473
+   c->t_force += now() - t0;
+   if (e_source)
+      for (int i = 0; i < L2V; i++) { e_rhs[i] += e_source[i]; } // :477
+   lgo_cg(h, 1, e_rhs.data(), de, cg_tol, cg_max_iter); // :481
+}
+
+// ComputeVolumeIntegral users (laghos_solver.cpp:640-697): internal and kinetic energy
+double lgo_internal_energy(void *h, const double *e)
+{
+   Ctx *c = (Ctx *)h;
+   if (c->dim == 2) { interp_dispatch<2>(c->L1D, c->Q1D, c->NE, 1, c->Bl.data(), nullptr, e, c->q_e.data(), nullptr); }
+   else { interp_dispatch<3>(c->L1D, c->Q1D, c->NE, 1, c->Bl.data(), nullptr, e, c->q_e.data(), nullptr); }
+   double s = 0.0;
+   for (size_t i = 0; i < (size_t)c->NE * c->NQ; i++) { s += c->q_e[i] * c->rho0DetJ0w[i]; }
+   return allreduce(s, 0);
+}
+double lgo_kinetic_energy(void *h, const double *v)
+{
+   Ctx *c = (Ctx *)h;
+   const int dim = c->dim;
+   std::vector<double> qv((size_t)c->NE * c->NQ * dim);
+   h1_gather(*c, dim, v, c->e_vec.data());
+   if (dim == 2) { interp_dispatch<2>(c->D1D, c->Q1D, c->NE, dim, c->B.data(), c->G.data(), c->e_vec.data(), qv.data(), nullptr); }
+   else { interp_dispatch<3>(c->D1D, c->Q1D, c->NE, dim, c->B.data(), c->G.data(), c->e_vec.data(), qv.data(), nullptr); }
+   double s = 0.0;
+   for (size_t i = 0; i < (size_t)c->NE * c->NQ; i++)
+   {
+      double vm = 0.0;
+      for (int k = 0; k < dim; k++) { vm += qv[k + dim * i] * qv[k + dim * i]; }
+      s += vm * c->rho0DetJ0w[i];
+   }
+   return 0.5 * allreduce(s, 0);
+}
+
+// 2D Taylor-Green energy source (laghos_solver.cpp:454-465, TaylorCoefficient
+// laghos_solver.hpp:208-218): e_src_i = sum_q w_q detJ(q) f(x_q) phi_i(q) on the
+// CURRENT mesh.  Uses q_dx (Jacobians) left by the last lgo_qupdate(S).
+void lgo_tg_source_2d(void *h, const double *S, double *out)
+{
+   Ctx *c = (Ctx *)h;
+   if (c->dim != 2) { std::abort(); }
+   const int NQ = c->NQ, NE = c->NE, L = c->L1D, Q = c->Q1D;
+   std::vector<double> xq((size_t)NE * NQ * 2);
+   h1_gather(*c, 2, S, c->e_vec.data());
+   interp_dispatch<2>(c->D1D, c->Q1D, NE, 2, c->B.data(), c->G.data(), c->e_vec.data(), xq.data(), c->q_dx.data());
+   for (int e = 0; e < NE; e++)
+   {
+      for (int l = 0; l < c->NL; l++) { out[l + (size_t)c->NL * e] = 0.0; }
+      for (int qy = 0; qy < Q; qy++)
+         for (int qx = 0; qx < Q; qx++)
+         {
+            const size_t eq = (size_t)e * NQ + qx + Q * qy;
+            const double x0 = xq[0 + 2 * eq], x1 = xq[1 + 2 * eq];
+            const double f = 3.0 / 8.0 * M_PI * (std::cos(3.0 * M_PI * x0) * std::cos(M_PI * x1) - std::cos(M_PI * x0) * std::cos(3.0 * M_PI * x1));
+            const double wdet = c->W[qx + Q * qy] * sm::Det<2>(c->q_dx.data() + 4 * eq);
+            for (int ly = 0; ly < L; ly++)
+               for (int lx = 0; lx < L; lx++)
+               {
+                  out[lx + L * ly + (size_t)c->NL * e] += wdet * f * c->Bl[qx + Q * lx] * c->Bl[qy + Q * ly];
+               }
+         }
+   }
+}
+
+int lgo_num_threads()
+{
+#ifdef _OPENMP
+   return omp_get_max_threads();
+#else
+   return 1;
+#endif
+}
+void lgo_set_num_threads(int n)
+{
+#ifdef _OPENMP
+   omp_set_num_threads(n);
+#else
+   (void)n;
+#endif
+}
+
+} // extern "C"
