@@ -1,0 +1,181 @@
+/* laghos_hip.h — C ABI of the MI355X-native Laghos partial-assembly hot path.
+ *
+ * This is the drop-in boundary: the reference's C++ operator
+ * classes keep their shape (laghos_amd/host/) and their Mult / MultTranspose /
+ * UpdateQuadratureData bodies become calls into this library of hand-written
+ * HIP kernels for gfx950.  Plain C types only; no torch / MFEM types.
+ *
+ * Conventions
+ *  - Every `const double*` / `double*` vector argument is a DEVICE pointer owned
+ *    by the caller (the reference's mfem::Vector device memory).  Pointers inside
+ *    lgh_config are HOST pointers, copied at creation.
+ *  - L-vectors use the reference layouts: H1 vectors are byNODES (component c at
+ *    [c*N, (c+1)*N)), element-local dofs lexicographic; L2 dofs are e*L1D^dim + l
+ *    (SURVEY A2-A4).  S = [x | v | e] with offsets {0, dim*N, 2*dim*N}
+ *    (/root/reference/laghos_solver.cpp:166-169).
+ *  - All work is enqueued on the context's HIP stream; calls are asynchronous
+ *    unless they return a scalar to the host (documented per function).
+ *  - Return value: 0 = LGH_OK, non-zero = error; lgh_last_error() gives the text.
+ *    The reference aborts on the same conditions (MFEM_ABORT "Unknown kernel",
+ *    laghos_assembly.cpp:549-553); the C++ shells turn non-zero into abort().
+ *  - Not re-entrant per context; one host thread / one process per GPU.
+ */
+#ifndef LAGHOS_HIP_H
+#define LAGHOS_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LGH_OK 0
+#define LGH_ERR_ARG 1         /* bad argument */
+#define LGH_ERR_UNSUPPORTED 2 /* (dim,D1D,Q1D) has no kernel: "Unknown kernel 0x..." */
+#define LGH_ERR_HIP 3         /* HIP runtime error */
+#define LGH_ERR_COMM 4        /* RCCL error */
+
+#define LGH_SPACE_H1 0 /* scalar H1 space "H1c" (laghos_solver.cpp:121) */
+#define LGH_SPACE_L2 1
+
+typedef struct lgh_ctx lgh_ctx;
+
+/* Everything ForcePAOperator / MassPAOperator / QUpdate constructors pull out of
+ * the MFEM spaces (laghos_assembly.cpp:123-143, :80-96; laghos_solver.hpp:72-89). */
+typedef struct lgh_config
+{
+   int dim, NE;            /* mesh dimension (2|3), local elements */
+   int D1D, Q1D, L1D;      /* H1 dofs, quadrature points, L2 dofs per direction */
+   int N;                  /* local scalar H1 nodes (H1c.GetVSize()) */
+   const int *h1_map;      /* NE*D1D^dim: node of element-local lexicographic dof
+                              (ElementRestriction, LEXICOGRAPHIC; assembly.cpp:133) */
+   const double *B_h1;     /* Q1D*D1D, B[q + Q1D*d]  (DofToQuad::TENSOR, assembly.cpp:141-142) */
+   const double *G_h1;     /* Q1D*D1D, derivative table */
+   const double *B_l2;     /* Q1D*L1D */
+   const double *weights;  /* NQ = Q1D^dim integration weights (ir.GetWeights()) */
+   const double *gamma;    /* NE: order-0 L2 gamma grid function (laghos.cpp:628-632) */
+   int ess_count[3];       /* c_tdofs[c].Size()  (laghos_solver.cpp:187-195) */
+   const int *ess[3];      /* c_tdofs[c]: scalar nodes with v_c = 0 */
+   const double *owner;    /* N, 1.0 where this rank owns the node, 0.0 where a lower
+                              rank does (T-vector dot products); NULL = all owned */
+   int use_viscosity, use_vorticity;
+   double cfl;
+   int order_v;            /* H1.GetOrder(0): h1order in QUpdateBody */
+   int device;             /* HIP device ordinal */
+   void *stream;           /* hipStream_t to use, or NULL to create one */
+} lgh_config;
+
+const char *lgh_last_error(void);
+const char *lgh_version(void);
+
+int lgh_create(const lgh_config *cfg, lgh_ctx **out);
+int lgh_destroy(lgh_ctx *ctx);
+int lgh_sync(lgh_ctx *ctx); /* hipStreamSynchronize on the context stream */
+void *lgh_stream(lgh_ctx *ctx);
+
+/* ---- QuadratureData (laghos_assembly.hpp:31-62); device arrays owned by ctx.
+ *   stressJinvT[(e*NQ+q) + NE*NQ*(gd + dim*vd)]     (laghos_solver.cpp:1160-1167)
+ *   Jac0inv[i + dim*(j + dim*(e*NQ+q))]              (laghos_solver.cpp:1195)
+ *   rho0DetJ0w[e*NQ+q];  mass_D = w*detJ0*rho0(x_q)  (laghos_assembly.cpp:92-95)   */
+double *lgh_qdata_stressJinvT(lgh_ctx *ctx);
+double *lgh_qdata_Jac0inv(lgh_ctx *ctx);
+double *lgh_qdata_rho0DetJ0w(lgh_ctx *ctx);
+double *lgh_mass_D(lgh_ctx *ctx);
+double *lgh_mass_diag(lgh_ctx *ctx); /* Jacobi diagonal of the scalar H1 mass (N) */
+int lgh_set_h0(lgh_ctx *ctx, double h0);
+int lgh_get_h0(lgh_ctx *ctx, double *h0);
+/* qdata.dt_est: host-visible scalar; the get synchronises the stream. */
+int lgh_set_dt_est(lgh_ctx *ctx, double dt_est);
+int lgh_get_dt_est(lgh_ctx *ctx, double *dt_est);
+
+/* Rho0DetJ0Vol (laghos_solver.cpp:1170-1261) + mass PA data + Jacobi diagonal
+ * (OperatorJacobiSmoother, laghos_solver.cpp:266-270).  x0: H1 L-vector of the
+ * initial nodes; rho0_l2: rho0 grid function (L2 dofs); rho0_q: the function rho0
+ * at the NE*NQ physical quadrature points.  Synchronous; returns the local volume. */
+int lgh_setup_rho0detj0(lgh_ctx *ctx, const double *x0, const double *rho0_l2,
+                        const double *rho0_q, double *volume);
+
+/* ---- ForcePAOperator (laghos_assembly.hpp:94-112) */
+/* Mult (laghos_assembly.cpp:557-565): x L2 L-vector -> y H1 L-vector (dim*N). */
+int lgh_force_mult(lgh_ctx *ctx, const double *x_l2, double *y_h1);
+/* MultTranspose (laghos_assembly.cpp:965-973): v H1 L-vector -> y L2 L-vector. */
+int lgh_force_mult_transpose(lgh_ctx *ctx, const double *v_h1, double *y_l2);
+
+/* ---- MassPAOperator (laghos_assembly.hpp:115-131) */
+/* SetEssentialTrueDofs(c_tdofs[comp]) (assembly.cpp:98-110); comp = -1 clears. */
+int lgh_mass_set_essential_tdofs(lgh_ctx *ctx, int comp);
+/* EliminateRHS (assembly.cpp:112-115): b[ess] = 0. */
+int lgh_mass_eliminate_rhs(lgh_ctx *ctx, double *b);
+/* Mult (assembly.cpp:117-121): y = M x, then y[ess] = 0.  space = LGH_SPACE_*. */
+int lgh_mass_mult(lgh_ctx *ctx, int space, const double *x, double *y);
+/* MultFull (assembly.hpp:127): no essential-row elimination. */
+int lgh_mass_mult_full(lgh_ctx *ctx, int space, const double *x, double *y);
+
+/* ---- CG solves configured at laghos_solver.cpp:264-284 (upstream CGSolver,
+ * SURVEY §3.2).  space H1: Jacobi-preconditioned, iterative_mode (x = initial
+ * guess), active essential list; space L2: plain CG, x overwritten.  Dot products
+ * are wave-shuffle reductions, owner-masked and all-reduced over RCCL when a
+ * communicator is attached.  Synchronous; *iters = GetNumIterations(). */
+int lgh_cg_solve(lgh_ctx *ctx, int space, const double *b, double *x, double rel_tol,
+                 int max_iter, int *iters);
+
+/* ---- QUpdate::UpdateQuadratureData (laghos_solver.cpp:1354-1411): fused
+ * E-restriction + reference-gradient + QKernel; updates stressJinvT and folds the
+ * point-wise dt estimate into qdata.dt_est (device side, no host sync). */
+int lgh_qupdate(lgh_ctx *ctx, const double *S);
+
+/* ---- LagrangianHydroOperator pieces kept together for launch efficiency
+ * (laghos_solver.cpp:329-399, :442-490).  dS_dt = [dx|dv|de]; one_l2 is the
+ * constant-one L2 vector (laghos_solver.cpp:170-171); rhs_h1 / e_rhs / work are
+ * caller scratch (dim*N, L2 size, N).  e_source may be NULL.
+ * *h1_iters / *l2_iters accumulate CG iteration counts (timer.H1iter, L2iter). */
+int lgh_solve_velocity(lgh_ctx *ctx, const double *S, double *dS_dt, const double *one_l2,
+                       double *rhs_h1, double *work_B, double rel_tol, int max_iter,
+                       int *h1_iters);
+int lgh_solve_energy(lgh_ctx *ctx, const double *S, const double *v_h1, double *dS_dt,
+                     double *e_rhs, const double *e_source, double rel_tol, int max_iter,
+                     int *l2_iters);
+
+/* ---- vector helpers on the context stream (device pointers) */
+int lgh_vec_set(lgh_ctx *ctx, double *y, double a, long n);              /* y = a */
+int lgh_vec_copy(lgh_ctx *ctx, double *y, const double *x, long n);      /* y = x */
+int lgh_vec_axpby(lgh_ctx *ctx, double *z, double a, const double *x, double b,
+                  const double *y, long n);                                /* z = a x + b y */
+int lgh_vec_dot(lgh_ctx *ctx, const double *x, const double *y, long n, double *result); /* sync */
+
+/* ---- energies (laghos_solver.cpp:640-697); synchronous, all-reduced */
+int lgh_internal_energy(lgh_ctx *ctx, const double *e_l2, double *result);
+int lgh_kinetic_energy(lgh_ctx *ctx, const double *v_h1, double *result);
+
+/* ---- timing data (TimingData, laghos_solver.hpp:39-56): seconds measured with
+ * HIP events around the same regions as the reference stopwatches.
+ * t[0..3] = cgH1, cgL2, force, qdata; c[0..2] = H1iter, L2iter, quad_tstep */
+int lgh_get_timers(lgh_ctx *ctx, double t[4], long c[3]);
+int lgh_reset_timers(lgh_ctx *ctx);
+int lgh_enable_timers(lgh_ctx *ctx, int on);
+
+/* ---- multi-GPU: element blocks per rank, shared H1 nodes summed
+ * over RCCL, dot products / dt all-reduced.  unique_id is the 128-byte
+ * ncclUniqueId produced by lgh_comm_unique_id on rank 0 and broadcast by the
+ * caller (e.g. torch.distributed).  Neighbour lists: for each of n_nbr peers,
+ * the local node indices shared with that peer, sorted identically on both
+ * sides (global lexicographic order). */
+int lgh_comm_unique_id(char id_out[128]);
+int lgh_comm_init(lgh_ctx *ctx, int nranks, int rank, const char unique_id[128]);
+int lgh_comm_set_neighbors(lgh_ctx *ctx, int n_nbr, const int *nbr_rank, const int *nbr_count,
+                           const int *const *nbr_nodes);
+/* in-place sum of shared nodes of an H1 L-vector with ncomp components */
+int lgh_halo_sum(lgh_ctx *ctx, double *v_h1, int ncomp);
+/* op 0 = sum, 1 = min; synchronous */
+int lgh_allreduce(lgh_ctx *ctx, double *value, int op);
+
+/* ---- E-vector level entry points (kernel-granularity parity tests only) */
+int lgh_force_mult_E(lgh_ctx *ctx, const double *sJit, const double *x_E, double *y_E);
+int lgh_force_mult_transpose_E(lgh_ctx *ctx, const double *sJit, const double *v_E, double *y_E);
+int lgh_mass_apply_E(lgh_ctx *ctx, int space, const double *x_E, double *y_E);
+/* device small-matrix probes: n matrices (column-major, 9 or 4 doubles each) */
+int lgh_test_eig(lgh_ctx *ctx, int dim, int n, const double *A, double *lambda, double *vec);
+int lgh_test_singular(lgh_ctx *ctx, int dim, int n, const double *A, double *sv_min);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LAGHOS_HIP_H */

@@ -1,0 +1,265 @@
+"""Thin Python handle over the C ABI (include/laghos_hip.h) using torch CUDA
+tensors as device memory.  Plumbing only: every method is one C-ABI call.
+
+Used by the GPU parity tests and by bench.py; the product host layer that
+mirrors the reference's C++ classes lives in laghos_amd/host/.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import LghConfig, check
+
+
+def _np_i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _np_f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _ptr(t):
+    """device pointer of a contiguous float64 CUDA tensor"""
+    assert t.is_cuda and t.dtype == torch.float64 and t.is_contiguous()
+    return ctypes.c_void_p(t.data_ptr())
+
+
+class Context:
+    """lgh_ctx owner.  Arguments follow struct lgh_config: tables are (Q,D)
+    arrays B[q,d]; h1_map is (NE, ND); ess is a list of dim int arrays."""
+
+    def __init__(self, dim, NE, D1D, Q1D, L1D, N, h1_map, B_h1, G_h1, B_l2, weights, gamma, ess,
+                 owner=None, use_viscosity=True, use_vorticity=False, cfl=0.5, order_v=None,
+                 device=0):
+        self.lib = _lib.load()
+        self.dim, self.NE, self.D1D, self.Q1D, self.L1D, self.N = dim, NE, D1D, Q1D, L1D, N
+        self.ND, self.NQ, self.NL = D1D ** dim, Q1D ** dim, L1D ** dim
+        self.H1V, self.L2V = dim * N, NE * self.NL
+        self.device = torch.device("cuda", device)
+        keep = dict(
+            h1=_np_i32(np.asarray(h1_map).reshape(-1)),
+            B=_np_f64(np.asarray(B_h1).T.reshape(-1)),   # -> [q + Q*d]
+            G=_np_f64(np.asarray(G_h1).T.reshape(-1)),
+            Bl=_np_f64(np.asarray(B_l2).T.reshape(-1)),
+            W=_np_f64(weights), gamma=_np_f64(gamma),
+            ess=[_np_i32(e) if len(e) else np.zeros(1, np.int32) for e in ess],
+            owner=None if owner is None else _np_f64(owner),
+        )
+        self._keep = keep
+        cfg = LghConfig()
+        cfg.dim, cfg.NE, cfg.D1D, cfg.Q1D, cfg.L1D, cfg.N = dim, NE, D1D, Q1D, L1D, N
+        ip, dp = ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_double)
+        cfg.h1_map = keep["h1"].ctypes.data_as(ip)
+        cfg.B_h1 = keep["B"].ctypes.data_as(dp)
+        cfg.G_h1 = keep["G"].ctypes.data_as(dp)
+        cfg.B_l2 = keep["Bl"].ctypes.data_as(dp)
+        cfg.weights = keep["W"].ctypes.data_as(dp)
+        cfg.gamma = keep["gamma"].ctypes.data_as(dp)
+        for k in range(3):
+            cfg.ess_count[k] = len(ess[k]) if k < dim else 0
+            cfg.ess[k] = keep["ess"][k].ctypes.data_as(ip) if k < dim else None
+        cfg.owner = keep["owner"].ctypes.data_as(dp) if owner is not None else None
+        cfg.use_viscosity, cfg.use_vorticity = int(use_viscosity), int(use_vorticity)
+        cfg.cfl = cfl
+        cfg.order_v = order_v if order_v is not None else D1D - 1
+        cfg.device = device
+        cfg.stream = None
+        h = ctypes.c_void_p()
+        check(self.lib.lgh_create(ctypes.byref(cfg), ctypes.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.lgh_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- helpers ----------------------------------------------------------------
+    def empty(self, n):
+        return torch.empty(int(n), dtype=torch.float64, device=self.device)
+
+    def zeros(self, n):
+        return torch.zeros(int(n), dtype=torch.float64, device=self.device)
+
+    def to_dev(self, a):
+        return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64)).to(self.device)
+
+    def sync(self):
+        check(self.lib.lgh_sync(self.h))
+
+    def _view(self, ptr, n):
+        """read a ctx-owned device array into a numpy array"""
+        out = self.empty(n)
+        self.sync()
+        check(self.lib.lgh_vec_copy(self.h, _ptr(out), ctypes.c_void_p(ptr), int(n)))
+        self.sync()
+        return out.cpu().numpy()
+
+    def _write(self, ptr, arr):
+        t = self.to_dev(arr)
+        torch.cuda.synchronize()
+        check(self.lib.lgh_vec_copy(self.h, ctypes.c_void_p(ptr), _ptr(t), t.numel()))
+        self.sync()
+
+    @property
+    def stressJinvT(self):
+        return self._view(self.lib.lgh_qdata_stressJinvT(self.h), self.NE * self.NQ * self.dim ** 2)
+
+    def set_stressJinvT(self, arr):
+        self._write(self.lib.lgh_qdata_stressJinvT(self.h), arr)
+
+    @property
+    def Jac0inv(self):
+        return self._view(self.lib.lgh_qdata_Jac0inv(self.h), self.NE * self.NQ * self.dim ** 2)
+
+    @property
+    def rho0DetJ0w(self):
+        return self._view(self.lib.lgh_qdata_rho0DetJ0w(self.h), self.NE * self.NQ)
+
+    @property
+    def massD(self):
+        return self._view(self.lib.lgh_mass_D(self.h), self.NE * self.NQ)
+
+    @property
+    def mass_diag(self):
+        return self._view(self.lib.lgh_mass_diag(self.h), self.N)
+
+    # ---- one method per C-ABI entry ------------------------------------------------
+    def set_h0(self, h0):
+        check(self.lib.lgh_set_h0(self.h, h0))
+
+    def set_dt_est(self, v):
+        check(self.lib.lgh_set_dt_est(self.h, v))
+
+    def get_dt_est(self):
+        v = ctypes.c_double()
+        check(self.lib.lgh_get_dt_est(self.h, ctypes.byref(v)))
+        return v.value
+
+    def setup_rho0detj0(self, x0, rho0_l2, rho0_q):
+        vol = ctypes.c_double()
+        torch.cuda.synchronize()
+        check(self.lib.lgh_setup_rho0detj0(self.h, _ptr(x0), _ptr(rho0_l2), _ptr(rho0_q), ctypes.byref(vol)))
+        return vol.value
+
+    def force_mult(self, x_l2, y_h1):
+        check(self.lib.lgh_force_mult(self.h, _ptr(x_l2), _ptr(y_h1)))
+
+    def force_mult_transpose(self, v_h1, y_l2):
+        check(self.lib.lgh_force_mult_transpose(self.h, _ptr(v_h1), _ptr(y_l2)))
+
+    def mass_set_ess(self, comp):
+        check(self.lib.lgh_mass_set_essential_tdofs(self.h, comp))
+
+    def mass_eliminate_rhs(self, b):
+        check(self.lib.lgh_mass_eliminate_rhs(self.h, _ptr(b)))
+
+    def mass_mult(self, space, x, y, full=False):
+        fn = self.lib.lgh_mass_mult_full if full else self.lib.lgh_mass_mult
+        check(fn(self.h, space, _ptr(x), _ptr(y)))
+
+    def cg_solve(self, space, b, x, rel_tol, max_iter):
+        it = ctypes.c_int(0)
+        check(self.lib.lgh_cg_solve(self.h, space, _ptr(b), _ptr(x), rel_tol, max_iter, ctypes.byref(it)))
+        return it.value
+
+    def qupdate(self, S):
+        check(self.lib.lgh_qupdate(self.h, _ptr(S)))
+
+    def solve_velocity(self, S, dS, one, rhs, work, rel_tol, max_iter):
+        it = ctypes.c_int(0)
+        check(self.lib.lgh_solve_velocity(self.h, _ptr(S), _ptr(dS), _ptr(one), _ptr(rhs), _ptr(work),
+                                          rel_tol, max_iter, ctypes.byref(it)))
+        return it.value
+
+    def solve_energy(self, S, v, dS, e_rhs, rel_tol, max_iter, e_source=None):
+        it = ctypes.c_int(0)
+        check(self.lib.lgh_solve_energy(self.h, _ptr(S), _ptr(v), _ptr(dS), _ptr(e_rhs),
+                                        _ptr(e_source) if e_source is not None else None,
+                                        rel_tol, max_iter, ctypes.byref(it)))
+        return it.value
+
+    def vec_axpby(self, z, a, x, b, y):
+        check(self.lib.lgh_vec_axpby(self.h, _ptr(z), a, _ptr(x), b, _ptr(y), z.numel()))
+
+    def vec_copy(self, y, x):
+        check(self.lib.lgh_vec_copy(self.h, _ptr(y), _ptr(x), y.numel()))
+
+    def vec_dot(self, x, y):
+        v = ctypes.c_double()
+        check(self.lib.lgh_vec_dot(self.h, _ptr(x), _ptr(y), x.numel(), ctypes.byref(v)))
+        return v.value
+
+    def internal_energy(self, e):
+        v = ctypes.c_double()
+        check(self.lib.lgh_internal_energy(self.h, _ptr(e), ctypes.byref(v)))
+        return v.value
+
+    def kinetic_energy(self, vel):
+        v = ctypes.c_double()
+        check(self.lib.lgh_kinetic_energy(self.h, _ptr(vel), ctypes.byref(v)))
+        return v.value
+
+    def timers(self):
+        t = (ctypes.c_double * 4)()
+        c = (ctypes.c_long * 3)()
+        check(self.lib.lgh_get_timers(self.h, t, c))
+        return dict(cgH1=t[0], cgL2=t[1], force=t[2], qdata=t[3], H1iter=c[0], L2iter=c[1],
+                    quad_tstep=c[2])
+
+    def reset_timers(self):
+        check(self.lib.lgh_reset_timers(self.h))
+
+    def enable_timers(self, on):
+        check(self.lib.lgh_enable_timers(self.h, int(on)))
+
+    # E-level (tests)
+    def force_mult_E(self, sJit, xE, yE):
+        check(self.lib.lgh_force_mult_E(self.h, _ptr(sJit), _ptr(xE), _ptr(yE)))
+
+    def force_mult_transpose_E(self, sJit, vE, yE):
+        check(self.lib.lgh_force_mult_transpose_E(self.h, _ptr(sJit), _ptr(vE), _ptr(yE)))
+
+    def mass_apply_E(self, space, xE, yE):
+        check(self.lib.lgh_mass_apply_E(self.h, space, _ptr(xE), _ptr(yE)))
+
+    def test_eig(self, dim, A, lam, vec):
+        check(self.lib.lgh_test_eig(self.h, dim, lam.numel(), _ptr(A), _ptr(lam), _ptr(vec)))
+
+    def test_singular(self, dim, A, sv):
+        check(self.lib.lgh_test_singular(self.h, dim, sv.numel(), _ptr(A), _ptr(sv)))
+
+    # multi-GPU
+    def comm_init(self, nranks, rank, unique_id):
+        check(self.lib.lgh_comm_init(self.h, nranks, rank, unique_id))
+
+    def comm_set_neighbors(self, nbr_rank, nbr_nodes):
+        n = len(nbr_rank)
+        ranks = _np_i32(nbr_rank) if n else np.zeros(1, np.int32)
+        counts = _np_i32([len(x) for x in nbr_nodes]) if n else np.zeros(1, np.int32)
+        lists = [_np_i32(x) for x in nbr_nodes]
+        ip = ctypes.POINTER(ctypes.c_int)
+        arr = (ip * max(n, 1))(*[l.ctypes.data_as(ip) for l in lists])
+        check(self.lib.lgh_comm_set_neighbors(self.h, n, ranks.ctypes.data_as(ip), counts.ctypes.data_as(ip), arr))
+
+    def halo_sum(self, v, ncomp):
+        check(self.lib.lgh_halo_sum(self.h, _ptr(v), ncomp))
+
+    def allreduce(self, value, op=0):
+        v = ctypes.c_double(value)
+        check(self.lib.lgh_allreduce(self.h, ctypes.byref(v), op))
+        return v.value
+
+
+def unique_id():
+    buf = ctypes.create_string_buffer(128)
+    check(_lib.load().lgh_comm_unique_id(buf))
+    return buf.raw

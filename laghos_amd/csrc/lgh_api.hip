@@ -1,0 +1,536 @@
+// lgh_api.hip — C ABI of liblaghos_hip.so: context life cycle, vector helpers,
+// timers, and the operator-level entry points declared in include/laghos_hip.h.
+#include <cstdarg>
+#include <algorithm>
+#include <limits>
+
+#include "lgh_common.hpp"
+
+namespace lgh
+{
+
+static thread_local char g_err[512] = "";
+void set_error(const char *fmt, ...)
+{
+   va_list ap;
+   va_start(ap, fmt);
+   vsnprintf(g_err, sizeof(g_err), fmt, ap);
+   va_end(ap);
+}
+
+// ---- small vector kernels ------------------------------------------------------
+__global__ void __launch_bounds__(256) vec_set_k(double *y, double a, long n)
+{
+   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) { y[i] = a; }
+}
+__global__ void __launch_bounds__(256)
+vec_axpby_k(double *z, double a, const double *x, double b, const double *y, long n)
+{
+   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+   {
+      z[i] = a * x[i] + b * y[i];
+   }
+}
+__global__ void __launch_bounds__(256) vec_neg_k(double *y, long n)
+{
+   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) { y[i] = -y[i]; }
+}
+__global__ void __launch_bounds__(256) vec_zero_list_k(double *y, const int *list, int n)
+{
+   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+   if (i < n) { y[list[i]] = 0.0; }
+}
+__global__ void __launch_bounds__(256)
+vec_dot_k(const double *x, const double *y, const double *w, long n, double *partials,
+          unsigned int *ticket, double *out)
+{
+   __shared__ double red[16];
+   double s = 0.0;
+   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+   {
+      s += (w ? w[i] : 1.0) * x[i] * y[i];
+   }
+   const double bsum = block_sum(s, red);
+   double total;
+   if (grid_sum_last_block(bsum, partials, ticket, red, total))
+   {
+      if (threadIdx.x == 0) { *out = total; }
+   }
+}
+__global__ void set_double_k(double *p, double v) { *p = v; }
+
+static int grid_for(long n) { return (int)std::min<long>(std::max<long>((n + 255) / 256, 1), 2048); }
+
+int vec_set(lgh_ctx *c, double *y, double a, long n)
+{
+   if (n <= 0) { return LGH_OK; }
+   hipLaunchKernelGGL(vec_set_k, dim3(grid_for(n)), dim3(256), 0, c->stream, y, a, n);
+   LGH_HIP_CHECK(hipGetLastError());
+   return LGH_OK;
+}
+int vec_axpby(lgh_ctx *c, double *z, double a, const double *x, double b, const double *y, long n)
+{
+   if (n <= 0) { return LGH_OK; }
+   hipLaunchKernelGGL(vec_axpby_k, dim3(grid_for(n)), dim3(256), 0, c->stream, z, a, x, b, y, n);
+   LGH_HIP_CHECK(hipGetLastError());
+   return LGH_OK;
+}
+int vec_neg_inplace(lgh_ctx *c, double *y, long n)
+{
+   if (n <= 0) { return LGH_OK; }
+   hipLaunchKernelGGL(vec_neg_k, dim3(grid_for(n)), dim3(256), 0, c->stream, y, n);
+   LGH_HIP_CHECK(hipGetLastError());
+   return LGH_OK;
+}
+int vec_zero_list(lgh_ctx *c, double *y, const int *list, int n)
+{
+   if (n <= 0) { return LGH_OK; }
+   hipLaunchKernelGGL(vec_zero_list_k, dim3(ceil_div(n, 256)), dim3(256), 0, c->stream, y, list, n);
+   LGH_HIP_CHECK(hipGetLastError());
+   return LGH_OK;
+}
+int vec_dot(lgh_ctx *c, const double *x, const double *y, const double *w, long n, double *dev_out)
+{
+   hipLaunchKernelGGL(vec_dot_k, dim3(grid_for(n)), dim3(256), 0, c->stream, x, y, w, n,
+                      c->partials + 3 * (size_t)c->part_stride, c->tickets + 3, dev_out);
+   LGH_HIP_CHECK(hipGetLastError());
+   return LGH_OK;
+}
+
+// ---- timers: HIP events around the reference's stopwatch regions -----------------
+void timer_start(lgh_ctx *c)
+{
+   if (!c->timers.enabled) { return; }
+   (void)hipEventRecord(c->timers.ev[0], c->stream);
+}
+void timer_stop(lgh_ctx *c, int which)
+{
+   if (!c->timers.enabled) { return; }
+   (void)hipEventRecord(c->timers.ev[1], c->stream);
+   (void)hipEventSynchronize(c->timers.ev[1]);
+   float ms = 0.f;
+   (void)hipEventElapsedTime(&ms, c->timers.ev[0], c->timers.ev[1]);
+   c->timers.t[which] += 1e-3 * ms;
+}
+
+template <typename T> static int dev_alloc_copy(T **dst, const T *src, size_t n)
+{
+   LGH_HIP_CHECK(hipMalloc((void **)dst, std::max<size_t>(n, 1) * sizeof(T)));
+   if (src && n) { LGH_HIP_CHECK(hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice)); }
+   return LGH_OK;
+}
+template <typename T> static int dev_alloc_zero(T **dst, size_t n)
+{
+   LGH_HIP_CHECK(hipMalloc((void **)dst, std::max<size_t>(n, 1) * sizeof(T)));
+   LGH_HIP_CHECK(hipMemset(*dst, 0, std::max<size_t>(n, 1) * sizeof(T)));
+   return LGH_OK;
+}
+
+static bool kernel_id_supported(int id)
+{
+   switch (id)
+   {
+      case 0x222: case 0x234: case 0x246: case 0x258: case 0x26A:
+      case 0x322: case 0x334: case 0x346: case 0x358: case 0x36A:
+         return true;
+   }
+   return false;
+}
+
+} // namespace lgh
+
+using namespace lgh;
+
+extern "C"
+{
+
+const char *lgh_last_error(void) { return g_err; }
+const char *lgh_version(void) { return "laghos_hip 0.1 (gfx950)"; }
+
+int lgh_create(const lgh_config *cfg, lgh_ctx **out)
+{
+   LGH_CHECK_ARG(cfg && out);
+   LGH_CHECK_ARG(cfg->dim == 2 || cfg->dim == 3);
+   LGH_CHECK_ARG(cfg->NE > 0 && cfg->N > 0);
+   LGH_CHECK_ARG(cfg->h1_map && cfg->B_h1 && cfg->G_h1 && cfg->B_l2 && cfg->weights && cfg->gamma);
+   // MFEM_VERIFY(L1D==D1D-1) (laghos_assembly.cpp:533, :943)
+   if (cfg->L1D != cfg->D1D - 1)
+   {
+      set_error("L1D!=D1D-1");
+      return LGH_ERR_UNSUPPORTED;
+   }
+   const int kid = (cfg->dim << 8) | (cfg->D1D << 4) | cfg->Q1D;
+   if (!kernel_id_supported(kid))
+   {
+      set_error("Unknown kernel 0x%x", kid);
+      return LGH_ERR_UNSUPPORTED;
+   }
+   int ndev = 0;
+   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+   {
+      set_error("no HIP device available: the laghos_hip path requires an MI355X (gfx950) GPU");
+      return LGH_ERR_HIP;
+   }
+   LGH_HIP_CHECK(hipSetDevice(cfg->device));
+
+   lgh_ctx *c = new lgh_ctx();
+   memset((void *)c, 0, sizeof(lgh_ctx));
+   new (&c->timers) Timers();
+   c->dim = cfg->dim; c->NE = cfg->NE; c->D1D = cfg->D1D; c->Q1D = cfg->Q1D; c->L1D = cfg->L1D;
+   const int dim = c->dim;
+   c->ND = dim == 2 ? c->D1D * c->D1D : c->D1D * c->D1D * c->D1D;
+   c->NQ = dim == 2 ? c->Q1D * c->Q1D : c->Q1D * c->Q1D * c->Q1D;
+   c->NL = dim == 2 ? c->L1D * c->L1D : c->L1D * c->L1D * c->L1D;
+   c->N = cfg->N;
+   c->H1V = dim * c->N;
+   c->L2V = c->NE * c->NL;
+   c->kid = kid;
+   c->visc = cfg->use_viscosity != 0;
+   c->vort = cfg->use_vorticity != 0;
+   c->cfl = cfg->cfl;
+   c->h1order = (double)cfg->order_v;
+   c->h0 = 0.0;
+   c->device = cfg->device;
+   c->cur_ess = -1;
+   c->nranks = 1;
+   c->rank = 0;
+   if (cfg->stream) { c->stream = (hipStream_t)cfg->stream; c->own_stream = false; }
+   else { LGH_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+
+   int rc;
+#define LGH_TRY(x) do { rc = (x); if (rc) { return rc; } } while (0)
+   LGH_TRY(dev_alloc_copy(&c->B, cfg->B_h1, (size_t)c->Q1D * c->D1D));
+   LGH_TRY(dev_alloc_copy(&c->G, cfg->G_h1, (size_t)c->Q1D * c->D1D));
+   LGH_TRY(dev_alloc_copy(&c->Bl, cfg->B_l2, (size_t)c->Q1D * c->L1D));
+   LGH_TRY(dev_alloc_copy(&c->W, cfg->weights, (size_t)c->NQ));
+   LGH_TRY(dev_alloc_copy(&c->gamma, cfg->gamma, (size_t)c->NE));
+   const size_t nmap = (size_t)c->NE * c->ND;
+   LGH_TRY(dev_alloc_copy(&c->h1map, cfg->h1_map, nmap));
+   // transpose of the restriction in CSR form (ascending element order per node)
+   {
+      std::vector<int> off((size_t)c->N + 1, 0), idx(nmap);
+      for (size_t i = 0; i < nmap; i++)
+      {
+         const int n = cfg->h1_map[i];
+         if (n < 0 || n >= c->N) { set_error("h1_map entry out of range"); return LGH_ERR_ARG; }
+         off[(size_t)n + 1]++;
+      }
+      for (int n = 0; n < c->N; n++) { off[(size_t)n + 1] += off[n]; }
+      std::vector<int> pos(off.begin(), off.end() - 1);
+      for (size_t i = 0; i < nmap; i++) { idx[pos[cfg->h1_map[i]]++] = (int)i; }
+      LGH_TRY(dev_alloc_copy(&c->t_off, off.data(), off.size()));
+      LGH_TRY(dev_alloc_copy(&c->t_idx, idx.data(), idx.size()));
+   }
+   for (int k = 0; k < 3; k++)
+   {
+      c->ess_count[k] = (k < dim) ? cfg->ess_count[k] : 0;
+      std::vector<uint8_t> mask((size_t)c->N, 0);
+      for (int i = 0; i < c->ess_count[k]; i++)
+      {
+         const int n = cfg->ess[k][i];
+         if (n < 0 || n >= c->N) { set_error("essential dof out of range"); return LGH_ERR_ARG; }
+         mask[n] = 1;
+      }
+      LGH_TRY(dev_alloc_copy(&c->essmask[k], mask.data(), mask.size()));
+      LGH_TRY(dev_alloc_copy(&c->ess[k], c->ess_count[k] ? cfg->ess[k] : nullptr, (size_t)c->ess_count[k]));
+   }
+   if (cfg->owner) { LGH_TRY(dev_alloc_copy(&c->owner, cfg->owner, (size_t)c->N)); }
+
+   const size_t nq = (size_t)c->NE * c->NQ;
+   LGH_TRY(dev_alloc_zero(&c->stressJinvT, nq * dim * dim));
+   LGH_TRY(dev_alloc_zero(&c->Jac0inv, nq * dim * dim));
+   LGH_TRY(dev_alloc_zero(&c->rho0DetJ0w, nq));
+   LGH_TRY(dev_alloc_zero(&c->massD, nq));
+   LGH_TRY(dev_alloc_zero(&c->diagV, (size_t)c->N));
+   LGH_TRY(dev_alloc_zero(&c->dinvV, (size_t)c->N));
+   LGH_TRY(dev_alloc_zero(&c->dt_est_dev, 1));
+   const size_t ne_nd = nmap * dim;
+   LGH_TRY(dev_alloc_zero(&c->XE, std::max<size_t>(ne_nd, (size_t)c->L2V)));
+   LGH_TRY(dev_alloc_zero(&c->YE, ne_nd));
+   const size_t nv = std::max<size_t>((size_t)c->N, (size_t)c->L2V);
+   LGH_TRY(dev_alloc_zero(&c->cg_r, nv));
+   LGH_TRY(dev_alloc_zero(&c->cg_z, nv));
+   LGH_TRY(dev_alloc_zero(&c->cg_d0, nv));
+   LGH_TRY(dev_alloc_zero(&c->cg_d1, nv));
+   LGH_TRY(dev_alloc_zero(&c->cg_y, nv));
+   c->part_stride = (int)std::max<size_t>(std::max<size_t>((size_t)c->NE, (nv + 255) / 256), 2048);
+   LGH_TRY(dev_alloc_zero(&c->partials, 4 * (size_t)c->part_stride));
+   LGH_TRY(dev_alloc_zero(&c->tickets, 8));
+   LGH_TRY(dev_alloc_zero(&c->cgs, 1));
+   LGH_TRY(dev_alloc_zero(&c->scal, 16));
+   LGH_HIP_CHECK(hipHostMalloc((void **)&c->host_pinned, 32 * sizeof(double), hipHostMallocDefault));
+   LGH_HIP_CHECK(hipEventCreate(&c->timers.ev[0]));
+   LGH_HIP_CHECK(hipEventCreate(&c->timers.ev[1]));
+   const double inf = std::numeric_limits<double>::infinity();
+   LGH_HIP_CHECK(hipMemcpy(c->dt_est_dev, &inf, sizeof(double), hipMemcpyHostToDevice));
+#undef LGH_TRY
+   *out = c;
+   return LGH_OK;
+}
+
+int lgh_destroy(lgh_ctx *c)
+{
+   if (!c) { return LGH_OK; }
+   (void)hipSetDevice(c->device);
+   (void)hipStreamSynchronize(c->stream);
+   void *ptrs[] = {c->B, c->G, c->Bl, c->W, c->gamma, c->h1map, c->t_off, c->t_idx, c->essmask[0],
+                   c->essmask[1], c->essmask[2], c->ess[0], c->ess[1], c->ess[2], c->owner,
+                   c->stressJinvT, c->Jac0inv, c->rho0DetJ0w, c->massD, c->diagV, c->dinvV,
+                   c->dt_est_dev, c->XE, c->YE, c->cg_r, c->cg_z, c->cg_d0, c->cg_d1, c->cg_y,
+                   c->partials, c->tickets, c->cgs, c->scal};
+   for (void *p : ptrs) { if (p) { (void)hipFree(p); } }
+   if (c->host_pinned) { (void)hipHostFree(c->host_pinned); }
+   if (c->timers.ev[0]) { (void)hipEventDestroy(c->timers.ev[0]); }
+   if (c->timers.ev[1]) { (void)hipEventDestroy(c->timers.ev[1]); }
+   extern void lgh_comm_free(lgh_ctx *);
+   lgh_comm_free(c);
+   if (c->own_stream) { (void)hipStreamDestroy(c->stream); }
+   delete c;
+   return LGH_OK;
+}
+
+int lgh_sync(lgh_ctx *c)
+{
+   LGH_CHECK_ARG(c);
+   LGH_HIP_CHECK(hipStreamSynchronize(c->stream));
+   return LGH_OK;
+}
+void *lgh_stream(lgh_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+double *lgh_qdata_stressJinvT(lgh_ctx *c) { return c->stressJinvT; }
+double *lgh_qdata_Jac0inv(lgh_ctx *c) { return c->Jac0inv; }
+double *lgh_qdata_rho0DetJ0w(lgh_ctx *c) { return c->rho0DetJ0w; }
+double *lgh_mass_D(lgh_ctx *c) { return c->massD; }
+double *lgh_mass_diag(lgh_ctx *c) { return c->diagV; }
+int lgh_set_h0(lgh_ctx *c, double h0) { LGH_CHECK_ARG(c); c->h0 = h0; return LGH_OK; }
+int lgh_get_h0(lgh_ctx *c, double *h0) { LGH_CHECK_ARG(c && h0); *h0 = c->h0; return LGH_OK; }
+
+int lgh_set_dt_est(lgh_ctx *c, double v)
+{
+   LGH_CHECK_ARG(c);
+   hipLaunchKernelGGL(set_double_k, dim3(1), dim3(1), 0, c->stream, c->dt_est_dev, v);
+   LGH_HIP_CHECK(hipGetLastError());
+   return LGH_OK;
+}
+int lgh_get_dt_est(lgh_ctx *c, double *v)
+{
+   LGH_CHECK_ARG(c && v);
+   LGH_HIP_CHECK(hipMemcpyAsync(c->host_pinned + 8, c->dt_est_dev, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+   LGH_HIP_CHECK(hipStreamSynchronize(c->stream));
+   *v = c->host_pinned[8];
+   return LGH_OK;
+}
+
+int lgh_setup_rho0detj0(lgh_ctx *c, const double *x0, const double *rho0_l2, const double *rho0_q,
+                        double *volume)
+{
+   LGH_CHECK_ARG(c && x0 && rho0_l2 && rho0_q && volume);
+   int rc = setup_rho0detj0(c, x0, rho0_l2, rho0_q, volume);
+   if (rc) { return rc; }
+   return mass_assemble_diag(c);
+}
+
+int lgh_force_mult(lgh_ctx *c, const double *x_l2, double *y_h1)
+{
+   LGH_CHECK_ARG(c && x_l2 && y_h1);
+   // L2R->Mult is the identity for the lexicographic L2 space (assembly.cpp:559-560)
+   int rc = force_mult_E(c, c->stressJinvT, x_l2, c->YE);
+   if (rc) { return rc; }
+   rc = h1_transpose_gather(c, c->dim, c->YE, y_h1); // H1R->MultTranspose (:564)
+   if (rc) { return rc; }
+   if (c->nranks > 1) { rc = halo_sum(c, y_h1, c->dim); }
+   return rc;
+}
+int lgh_force_mult_transpose(lgh_ctx *c, const double *v_h1, double *y_l2)
+{
+   LGH_CHECK_ARG(c && v_h1 && y_l2);
+   return force_mult_t_L(c, c->stressJinvT, v_h1, y_l2);
+}
+
+int lgh_mass_set_essential_tdofs(lgh_ctx *c, int comp)
+{
+   LGH_CHECK_ARG(c && comp >= -1 && comp < c->dim);
+   c->cur_ess = comp;
+   return LGH_OK;
+}
+int lgh_mass_eliminate_rhs(lgh_ctx *c, double *b)
+{
+   LGH_CHECK_ARG(c && b);
+   if (c->cur_ess < 0) { return LGH_OK; }
+   return vec_zero_list(c, b, c->ess[c->cur_ess], c->ess_count[c->cur_ess]);
+}
+int lgh_mass_mult(lgh_ctx *c, int space, const double *x, double *y)
+{
+   LGH_CHECK_ARG(c && x && y && (space == LGH_SPACE_H1 || space == LGH_SPACE_L2));
+   return space == LGH_SPACE_H1 ? mass_apply_h1(c, x, y, true) : mass_apply_l2(c, x, y);
+}
+int lgh_mass_mult_full(lgh_ctx *c, int space, const double *x, double *y)
+{
+   LGH_CHECK_ARG(c && x && y && (space == LGH_SPACE_H1 || space == LGH_SPACE_L2));
+   return space == LGH_SPACE_H1 ? mass_apply_h1(c, x, y, false) : mass_apply_l2(c, x, y);
+}
+
+int lgh_cg_solve(lgh_ctx *c, int space, const double *b, double *x, double rel_tol, int max_iter,
+                 int *iters)
+{
+   LGH_CHECK_ARG(c && b && x && (space == LGH_SPACE_H1 || space == LGH_SPACE_L2));
+   return cg_solve(c, space, b, x, rel_tol, max_iter, iters, false);
+}
+
+int lgh_qupdate(lgh_ctx *c, const double *S)
+{
+   LGH_CHECK_ARG(c && S);
+   timer_start(c);
+   int rc = qupdate(c, S);
+   timer_stop(c, 3);
+   c->timers.c[2] += c->NE;
+   return rc;
+}
+
+// SolveVelocity, PA branch without acceleration source (laghos_solver.cpp:329-399).
+// The caller has already run UpdateQuadratureData(S) if the data was stale (:332).
+int lgh_solve_velocity(lgh_ctx *c, const double *S, double *dS_dt, const double *one_l2,
+                       double *rhs_h1, double *work_B, double rel_tol, int max_iter, int *h1_iters)
+{
+   LGH_CHECK_ARG(c && S && dS_dt && one_l2 && rhs_h1 && work_B);
+   (void)S;
+   const int dim = c->dim, N = c->N;
+   double *dv = dS_dt + c->H1V;
+   int rc = vec_set(c, dv, 0.0, c->H1V); // dv = 0.0 (:338)
+   if (rc) { return rc; }
+   timer_start(c);
+   rc = lgh_force_mult(c, one_l2, rhs_h1); // :354
+   timer_stop(c, 2);
+   if (rc) { return rc; }
+   rc = vec_neg_inplace(c, rhs_h1, c->H1V); // :358
+   if (rc) { return rc; }
+   for (int cc = 0; cc < dim; cc++)
+   {
+      // B = rhs_c (Pconf is the identity on a conforming mesh; shared-node sums
+      // were already applied by lgh_force_mult) (:368-369)
+      LGH_HIP_CHECK(hipMemcpyAsync(work_B, rhs_h1 + (size_t)cc * N, sizeof(double) * N,
+                                   hipMemcpyDeviceToDevice, c->stream));
+      rc = lgh_mass_set_essential_tdofs(c, cc); // :383
+      if (rc) { return rc; }
+      rc = lgh_mass_eliminate_rhs(c, work_B); // :384
+      if (rc) { return rc; }
+      int it = 0;
+      timer_start(c);
+      rc = cg_solve(c, LGH_SPACE_H1, work_B, dv + (size_t)cc * N, rel_tol, max_iter, &it, true); // :388
+      timer_stop(c, 0);
+      if (rc) { return rc; }
+      c->timers.c[0] += it; // :392
+      if (h1_iters) { *h1_iters += it; }
+   }
+   return LGH_OK;
+}
+
+// SolveEnergy, PA branch (laghos_solver.cpp:442-490)
+int lgh_solve_energy(lgh_ctx *c, const double *S, const double *v_h1, double *dS_dt, double *e_rhs,
+                     const double *e_source, double rel_tol, int max_iter, int *l2_iters)
+{
+   LGH_CHECK_ARG(c && S && v_h1 && dS_dt && e_rhs);
+   (void)S;
+   double *de = dS_dt + 2 * (size_t)c->H1V;
+   timer_start(c);
+   int rc = lgh_force_mult_transpose(c, v_h1, e_rhs); // :473
+   timer_stop(c, 2);
+   if (rc) { return rc; }
+   if (e_source)
+   {
+      rc = vec_axpby(c, e_rhs, 1.0, e_rhs, 1.0, e_source, c->L2V); // :477
+      if (rc) { return rc; }
+   }
+   int it = 0;
+   timer_start(c);
+   rc = cg_solve(c, LGH_SPACE_L2, e_rhs, de, rel_tol, max_iter, &it, true); // :481
+   timer_stop(c, 1);
+   if (rc) { return rc; }
+   const int counted = (it == 0) ? 1 : it; // :486
+   c->timers.c[1] += counted;
+   if (l2_iters) { *l2_iters += counted; }
+   return LGH_OK;
+}
+
+int lgh_vec_set(lgh_ctx *c, double *y, double a, long n) { LGH_CHECK_ARG(c && y); return vec_set(c, y, a, n); }
+int lgh_vec_copy(lgh_ctx *c, double *y, const double *x, long n)
+{
+   LGH_CHECK_ARG(c && y && x);
+   LGH_HIP_CHECK(hipMemcpyAsync(y, x, sizeof(double) * n, hipMemcpyDeviceToDevice, c->stream));
+   return LGH_OK;
+}
+int lgh_vec_axpby(lgh_ctx *c, double *z, double a, const double *x, double b, const double *y, long n)
+{
+   LGH_CHECK_ARG(c && z && x && y);
+   return vec_axpby(c, z, a, x, b, y, n);
+}
+int lgh_vec_dot(lgh_ctx *c, const double *x, const double *y, long n, double *result)
+{
+   LGH_CHECK_ARG(c && x && y && result);
+   int rc = vec_dot(c, x, y, nullptr, n, c->scal + 1);
+   if (rc) { return rc; }
+   LGH_HIP_CHECK(hipMemcpyAsync(c->host_pinned + 1, c->scal + 1, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+   LGH_HIP_CHECK(hipStreamSynchronize(c->stream));
+   *result = c->host_pinned[1];
+   return LGH_OK;
+}
+
+int lgh_internal_energy(lgh_ctx *c, const double *e_l2, double *result)
+{
+   LGH_CHECK_ARG(c && e_l2 && result);
+   return interp_energy(c, 0, e_l2, result);
+}
+int lgh_kinetic_energy(lgh_ctx *c, const double *v_h1, double *result)
+{
+   LGH_CHECK_ARG(c && v_h1 && result);
+   return interp_energy(c, 1, v_h1, result);
+}
+
+int lgh_get_timers(lgh_ctx *c, double t[4], long n[3])
+{
+   LGH_CHECK_ARG(c && t && n);
+   for (int i = 0; i < 4; i++) { t[i] = c->timers.t[i]; }
+   for (int i = 0; i < 3; i++) { n[i] = c->timers.c[i]; }
+   return LGH_OK;
+}
+int lgh_reset_timers(lgh_ctx *c)
+{
+   LGH_CHECK_ARG(c);
+   for (int i = 0; i < 4; i++) { c->timers.t[i] = 0; }
+   for (int i = 0; i < 3; i++) { c->timers.c[i] = 0; }
+   return LGH_OK;
+}
+int lgh_enable_timers(lgh_ctx *c, int on)
+{
+   LGH_CHECK_ARG(c);
+   c->timers.enabled = on != 0;
+   return LGH_OK;
+}
+
+int lgh_force_mult_E(lgh_ctx *c, const double *sJit, const double *x_E, double *y_E)
+{
+   LGH_CHECK_ARG(c && sJit && x_E && y_E);
+   return force_mult_E(c, sJit, x_E, y_E);
+}
+int lgh_force_mult_transpose_E(lgh_ctx *c, const double *sJit, const double *v_E, double *y_E)
+{
+   LGH_CHECK_ARG(c && sJit && v_E && y_E);
+   return force_mult_t_E(c, sJit, v_E, y_E);
+}
+int lgh_mass_apply_E(lgh_ctx *c, int space, const double *x_E, double *y_E)
+{
+   LGH_CHECK_ARG(c && x_E && y_E);
+   return mass_apply_E(c, space, x_E, y_E);
+}
+int lgh_test_eig(lgh_ctx *c, int dim, int n, const double *A, double *lambda, double *vec)
+{
+   LGH_CHECK_ARG(c && A && lambda && vec && (dim == 2 || dim == 3));
+   return test_eig(c, dim, n, A, lambda, vec);
+}
+int lgh_test_singular(lgh_ctx *c, int dim, int n, const double *A, double *sv)
+{
+   LGH_CHECK_ARG(c && A && sv && (dim == 2 || dim == 3));
+   return test_singular(c, dim, n, A, sv);
+}
+
+} // extern "C"

@@ -1,0 +1,299 @@
+// lgh_comm.hip — multi-GPU support: element blocks per rank, shared H1 nodes
+// summed across ranks and scalar all-reduces, over RCCL on the context stream.
+//
+// Replaces what the reference gets from MFEM's ParFiniteElementSpace /
+// GroupCommunicator over MPI (call-site inventory in SURVEY §2): the conforming
+// prolongation P^T (sum of shared dofs, inside mass->Mult laghos_assembly.cpp:119
+// and Pconf->MultTranspose laghos_solver.cpp:368), CGSolver::Dot's MPI_Allreduce
+// and the MIN reduction of the time-step estimate (laghos_solver.cpp:533).
+//
+// MI355X design: xGMI is point-to-point, and a 2x2x2 block partition gives every
+// GPU 7 neighbours = its 7 links, so the halo is one grouped ncclSend/ncclRecv
+// per neighbour (<= 75 KB each at 32^3 Q3 elements) rather than a ring
+// collective; pack and unpack-add are single kernels over all neighbours.
+// RCCL is resolved with dlopen at lgh_comm_init time so that the same library
+// loads on a host without RCCL (and reuses torch's copy when already loaded).
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <utility>
+
+#include "lgh_common.hpp"
+
+namespace lgh
+{
+
+// minimal NCCL ABI (rccl.h): opaque handles + the enums used here
+typedef struct ncclComm *ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+enum { ncclSuccess = 0 };
+enum { ncclFloat64 = 8 };
+enum { ncclSum = 0, ncclMin = 3 };
+
+struct NcclApi
+{
+   void *lib = nullptr;
+   int (*GetUniqueId)(ncclUniqueId *) = nullptr;
+   int (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+   int (*CommDestroy)(ncclComm_t) = nullptr;
+   int (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+   int (*Send)(const void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+   int (*Recv)(void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+   int (*GroupStart)() = nullptr;
+   int (*GroupEnd)() = nullptr;
+   const char *(*GetErrorString)(int) = nullptr;
+};
+static NcclApi g_nccl;
+
+static int load_nccl()
+{
+   if (g_nccl.lib) { return LGH_OK; }
+   const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+   void *h = nullptr;
+   for (const char *n : names) { h = dlopen(n, RTLD_NOW | RTLD_NOLOAD); if (h) { break; } }
+   if (!h) { for (const char *n : names) { h = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (h) { break; } } }
+   if (!h)
+   {
+      set_error("cannot load RCCL: %s", dlerror());
+      return LGH_ERR_COMM;
+   }
+   g_nccl.lib = h;
+#define LGH_SYM(field, name)                                                        \
+   *(void **)(&g_nccl.field) = dlsym(h, name);                                     \
+   if (!g_nccl.field) { set_error("RCCL symbol %s missing", name); g_nccl.lib = nullptr; return LGH_ERR_COMM; }
+   LGH_SYM(GetUniqueId, "ncclGetUniqueId");
+   LGH_SYM(CommInitRank, "ncclCommInitRank");
+   LGH_SYM(CommDestroy, "ncclCommDestroy");
+   LGH_SYM(AllReduce, "ncclAllReduce");
+   LGH_SYM(Send, "ncclSend");
+   LGH_SYM(Recv, "ncclRecv");
+   LGH_SYM(GroupStart, "ncclGroupStart");
+   LGH_SYM(GroupEnd, "ncclGroupEnd");
+   LGH_SYM(GetErrorString, "ncclGetErrorString");
+#undef LGH_SYM
+   return LGH_OK;
+}
+
+#define LGH_NCCL_CHECK(expr)                                                             \
+   do                                                                                    \
+   {                                                                                     \
+      int r_ = (expr);                                                                   \
+      if (r_ != ncclSuccess)                                                             \
+      {                                                                                  \
+         set_error("RCCL error %s at %s:%d", g_nccl.GetErrorString(r_), __FILE__, __LINE__); \
+         return LGH_ERR_COMM;                                                            \
+      }                                                                                  \
+   } while (0)
+
+struct Comm
+{
+   ncclComm_t comm = nullptr;
+   int n_nbr = 0;
+   std::vector<int> nbr_rank, nbr_count, nbr_off; // offsets into the packed buffers
+   int total = 0;        // sum of nbr_count
+   int *nodes = nullptr; // device: concatenated neighbour node lists
+   double *sendbuf = nullptr, *recvbuf = nullptr; // device: total * 3 doubles
+   int n_shared = 0;                               // unique shared nodes
+   int *sh_node = nullptr, *sh_off = nullptr, *sh_src = nullptr; // device CSR (see halo_combine_k)
+};
+
+__global__ void __launch_bounds__(256)
+halo_pack_k(const int total, const int ncomp, const int N, const int *__restrict__ nodes,
+            const double *__restrict__ v, double *__restrict__ buf)
+{
+   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+   if (i >= total * ncomp) { return; }
+   const int c = i / total, k = i - c * total;
+   buf[i] = v[(size_t)c * N + nodes[k]];
+}
+// Canonical sum of a shared node: contributions are added in ascending rank
+// order (own value at its rank's position), so every rank holding the node
+// computes bit-identical results, as MFEM's GroupCommunicator does.  CSR over the
+// unique shared nodes; src >= 0: index into the receive buffer, -1: own value.
+__global__ void __launch_bounds__(256)
+halo_combine_k(const int n_shared, const int total, const int ncomp, const int N,
+               const int *__restrict__ sh_node, const int *__restrict__ sh_off,
+               const int *__restrict__ sh_src, const double *__restrict__ buf, double *__restrict__ v)
+{
+   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+   if (i >= n_shared * ncomp) { return; }
+   const int c = i / n_shared, u = i - c * n_shared;
+   const int node = sh_node[u];
+   double s = 0.0;
+   for (int k = sh_off[u]; k < sh_off[u + 1]; k++)
+   {
+      const int src = sh_src[k];
+      const double val = (src < 0) ? v[(size_t)c * N + node] : buf[(size_t)c * total + src];
+      s = (k == sh_off[u]) ? val : s + val;
+   }
+   v[(size_t)c * N + node] = s;
+}
+
+int halo_sum(lgh_ctx *c, double *v, int ncomp)
+{
+   Comm *cm = c->comm;
+   if (!cm || c->nranks <= 1 || cm->n_nbr == 0) { return LGH_OK; }
+   if (ncomp > 3) { set_error("halo_sum: ncomp > 3"); return LGH_ERR_ARG; }
+   const int tot = cm->total;
+   hipLaunchKernelGGL(halo_pack_k, dim3(ceil_div((long)tot * ncomp, 256)), dim3(256), 0, c->stream, tot,
+                      ncomp, c->N, cm->nodes, v, cm->sendbuf);
+   LGH_HIP_CHECK(hipGetLastError());
+   LGH_NCCL_CHECK(g_nccl.GroupStart());
+   for (int comp = 0; comp < ncomp; comp++)
+   {
+      for (int k = 0; k < cm->n_nbr; k++)
+      {
+         const size_t o = (size_t)comp * tot + cm->nbr_off[k];
+         LGH_NCCL_CHECK(g_nccl.Send(cm->sendbuf + o, cm->nbr_count[k], ncclFloat64, cm->nbr_rank[k], cm->comm, c->stream));
+         LGH_NCCL_CHECK(g_nccl.Recv(cm->recvbuf + o, cm->nbr_count[k], ncclFloat64, cm->nbr_rank[k], cm->comm, c->stream));
+      }
+   }
+   LGH_NCCL_CHECK(g_nccl.GroupEnd());
+   hipLaunchKernelGGL(halo_combine_k, dim3(ceil_div((long)cm->n_shared * ncomp, 256)), dim3(256), 0,
+                      c->stream, cm->n_shared, tot, ncomp, c->N, cm->sh_node, cm->sh_off, cm->sh_src,
+                      cm->recvbuf, v);
+   LGH_HIP_CHECK(hipGetLastError());
+   return LGH_OK;
+}
+
+int allreduce_dev(lgh_ctx *c, double *dev, int count, int op)
+{
+   Comm *cm = c->comm;
+   if (!cm || c->nranks <= 1) { return LGH_OK; }
+   LGH_NCCL_CHECK(g_nccl.AllReduce(dev, dev, (size_t)count, ncclFloat64, op == 0 ? ncclSum : ncclMin, cm->comm, c->stream));
+   return LGH_OK;
+}
+
+} // namespace lgh
+
+using namespace lgh;
+
+extern "C"
+{
+
+void lgh_comm_free(lgh_ctx *c)
+{
+   if (!c || !c->comm) { return; }
+   Comm *cm = c->comm;
+   if (cm->comm && g_nccl.CommDestroy) { g_nccl.CommDestroy(cm->comm); }
+   void *ptrs[] = {cm->nodes, cm->sendbuf, cm->recvbuf, cm->sh_node, cm->sh_off, cm->sh_src};
+   for (void *p : ptrs) { if (p) { (void)hipFree(p); } }
+   delete cm;
+   c->comm = nullptr;
+}
+
+int lgh_comm_unique_id(char id_out[128])
+{
+   LGH_CHECK_ARG(id_out);
+   int rc = load_nccl();
+   if (rc) { return rc; }
+   ncclUniqueId id;
+   LGH_NCCL_CHECK(g_nccl.GetUniqueId(&id));
+   memcpy(id_out, id.internal, 128);
+   return LGH_OK;
+}
+
+int lgh_comm_init(lgh_ctx *c, int nranks, int rank, const char unique_id[128])
+{
+   LGH_CHECK_ARG(c && nranks >= 1 && rank >= 0 && rank < nranks && unique_id);
+   int rc = load_nccl();
+   if (rc) { return rc; }
+   LGH_HIP_CHECK(hipSetDevice(c->device));
+   if (!c->comm) { c->comm = new Comm(); }
+   ncclUniqueId id;
+   memcpy(id.internal, unique_id, 128);
+   LGH_NCCL_CHECK(g_nccl.CommInitRank(&c->comm->comm, nranks, id, rank));
+   c->nranks = nranks;
+   c->rank = rank;
+   return LGH_OK;
+}
+
+int lgh_comm_set_neighbors(lgh_ctx *c, int n_nbr, const int *nbr_rank, const int *nbr_count,
+                           const int *const *nbr_nodes)
+{
+   LGH_CHECK_ARG(c && n_nbr >= 0);
+   if (!c->comm) { c->comm = new Comm(); }
+   Comm *cm = c->comm;
+   cm->n_nbr = n_nbr;
+   cm->nbr_rank.assign(nbr_rank, nbr_rank + n_nbr);
+   cm->nbr_count.assign(nbr_count, nbr_count + n_nbr);
+   cm->nbr_off.resize(n_nbr);
+   std::vector<int> all;
+   int tot = 0;
+   for (int k = 0; k < n_nbr; k++)
+   {
+      cm->nbr_off[k] = tot;
+      for (int i = 0; i < nbr_count[k]; i++)
+      {
+         const int n = nbr_nodes[k][i];
+         if (n < 0 || n >= c->N) { set_error("neighbour node out of range"); return LGH_ERR_ARG; }
+         all.push_back(n);
+      }
+      tot += nbr_count[k];
+   }
+   cm->total = tot;
+   // canonical-order combine lists (requires the rank: call lgh_comm_init first)
+   {
+      std::vector<std::vector<std::pair<int, int>>> per_node; // (rank, recv index)
+      std::vector<int> uniq;
+      std::vector<int> slot((size_t)c->N, -1);
+      for (int k = 0; k < n_nbr; k++)
+      {
+         for (int i = 0; i < nbr_count[k]; i++)
+         {
+            const int n = nbr_nodes[k][i];
+            if (slot[n] < 0)
+            {
+               slot[n] = (int)uniq.size();
+               uniq.push_back(n);
+               per_node.emplace_back();
+               per_node.back().push_back({c->rank, -1});
+            }
+            per_node[slot[n]].push_back({nbr_rank[k], cm->nbr_off[k] + i});
+         }
+      }
+      std::vector<int> off(uniq.size() + 1, 0), src;
+      for (size_t u = 0; u < uniq.size(); u++)
+      {
+         std::sort(per_node[u].begin(), per_node[u].end());
+         for (auto &pr : per_node[u]) { src.push_back(pr.second); }
+         off[u + 1] = (int)src.size();
+      }
+      void *old[] = {cm->sh_node, cm->sh_off, cm->sh_src};
+      for (void *p : old) { if (p) { (void)hipFree(p); } }
+      cm->n_shared = (int)uniq.size();
+      LGH_HIP_CHECK(hipMalloc((void **)&cm->sh_node, std::max<size_t>(uniq.size(), 1) * sizeof(int)));
+      LGH_HIP_CHECK(hipMalloc((void **)&cm->sh_off, off.size() * sizeof(int)));
+      LGH_HIP_CHECK(hipMalloc((void **)&cm->sh_src, std::max<size_t>(src.size(), 1) * sizeof(int)));
+      if (!uniq.empty()) { LGH_HIP_CHECK(hipMemcpy(cm->sh_node, uniq.data(), uniq.size() * sizeof(int), hipMemcpyHostToDevice)); }
+      LGH_HIP_CHECK(hipMemcpy(cm->sh_off, off.data(), off.size() * sizeof(int), hipMemcpyHostToDevice));
+      if (!src.empty()) { LGH_HIP_CHECK(hipMemcpy(cm->sh_src, src.data(), src.size() * sizeof(int), hipMemcpyHostToDevice)); }
+   }
+   if (cm->nodes) { (void)hipFree(cm->nodes); (void)hipFree(cm->sendbuf); (void)hipFree(cm->recvbuf); }
+   LGH_HIP_CHECK(hipMalloc((void **)&cm->nodes, std::max<size_t>(tot, 1) * sizeof(int)));
+   if (tot) { LGH_HIP_CHECK(hipMemcpy(cm->nodes, all.data(), (size_t)tot * sizeof(int), hipMemcpyHostToDevice)); }
+   LGH_HIP_CHECK(hipMalloc((void **)&cm->sendbuf, std::max<size_t>(tot, 1) * 3 * sizeof(double)));
+   LGH_HIP_CHECK(hipMalloc((void **)&cm->recvbuf, std::max<size_t>(tot, 1) * 3 * sizeof(double)));
+   return LGH_OK;
+}
+
+int lgh_halo_sum(lgh_ctx *c, double *v_h1, int ncomp)
+{
+   LGH_CHECK_ARG(c && v_h1 && ncomp >= 1 && ncomp <= 3);
+   return halo_sum(c, v_h1, ncomp);
+}
+
+int lgh_allreduce(lgh_ctx *c, double *value, int op)
+{
+   LGH_CHECK_ARG(c && value);
+   if (c->nranks <= 1 || !c->comm) { return LGH_OK; }
+   LGH_HIP_CHECK(hipMemcpyAsync(c->scal + 2, value, sizeof(double), hipMemcpyHostToDevice, c->stream));
+   int rc = allreduce_dev(c, c->scal + 2, 1, op);
+   if (rc) { return rc; }
+   LGH_HIP_CHECK(hipMemcpyAsync(c->host_pinned + 2, c->scal + 2, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+   LGH_HIP_CHECK(hipStreamSynchronize(c->stream));
+   *value = c->host_pinned[2];
+   return LGH_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,240 @@
+// lgh_common.hpp — context, error handling and device reduction helpers shared by
+// the HIP translation units of liblaghos_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/laghos_hip.h"
+
+namespace lgh
+{
+
+void set_error(const char *fmt, ...);
+
+#define LGH_HIP_CHECK(expr)                                                              \
+   do                                                                                    \
+   {                                                                                     \
+      hipError_t e_ = (expr);                                                            \
+      if (e_ != hipSuccess)                                                              \
+      {                                                                                  \
+         lgh::set_error("HIP error %s at %s:%d: %s", hipGetErrorName(e_), __FILE__,      \
+                        __LINE__, #expr);                                                \
+         return LGH_ERR_HIP;                                                             \
+      }                                                                                  \
+   } while (0)
+
+#define LGH_CHECK_ARG(cond)                                                              \
+   do                                                                                    \
+   {                                                                                     \
+      if (!(cond))                                                                       \
+      {                                                                                  \
+         lgh::set_error("bad argument: %s (%s:%d)", #cond, __FILE__, __LINE__);          \
+         return LGH_ERR_ARG;                                                             \
+      }                                                                                  \
+   } while (0)
+
+constexpr int kWave = 64;          // gfx950 wavefront
+
+// Device-resident scalars of one CG solve (SURVEY §3.2 names).
+struct CgScalars
+{
+   double rz;       // (r, z) current: nom, later betanom
+   double rz_prev;  // previous (r, z): denominator of beta
+   double den;      // (d, A d)
+   double r0;       // max(nom*rel_tol^2, abs_tol^2)
+   double nom0;     // initial nom
+   double rel_tol2; // rel_tol^2 (set by host before the init kernel)
+   int done;        // 1: converged / breakdown, later kernels become no-ops
+   int iters;       // final_iter
+   int first;       // 1 until the first direction has been formed (beta = 0)
+   int pad;
+};
+
+struct Timers
+{
+   bool enabled = true;
+   hipEvent_t ev[2] = {nullptr, nullptr};
+   double t[4] = {0, 0, 0, 0}; // cgH1, cgL2, force, qdata (seconds)
+   long c[3] = {0, 0, 0};      // H1iter, L2iter, quad_tstep
+};
+
+struct Comm; // RCCL state (lgh_comm.hip)
+
+} // namespace lgh
+
+struct lgh_ctx
+{
+   int dim, NE, D1D, Q1D, L1D, ND, NQ, NL, N, H1V, L2V;
+   int kid; // (dim<<8)|(D1D<<4)|Q1D, the reference's kernel id
+   bool visc, vort;
+   double cfl, h0, h1order;
+   int device;
+   hipStream_t stream;
+   bool own_stream;
+
+   // tables (device): B_h1/G_h1 [q + Q*d], B_l2 [q + Q*l], weights [NQ]
+   double *B, *G, *Bl, *W, *gamma;
+   // element restriction: gather map, and its transpose in CSR form
+   int *h1map;   // NE*ND
+   int *t_off;   // N+1
+   int *t_idx;   // NE*ND: E-vector positions (e*ND + d) contributing to node
+   uint8_t *essmask[3]; // N each (0/1)
+   int *ess[3];
+   int ess_count[3];
+   double *owner; // N or nullptr
+   int cur_ess;
+
+   // QuadratureData + mass PA data
+   double *stressJinvT, *Jac0inv, *rho0DetJ0w, *massD, *diagV, *dinvV;
+   double *dt_est_dev;   // 1 double: running min of the point-wise estimate
+   // scratch
+   double *XE;           // max(L2V, NE*ND*dim)
+   double *YE;           // NE*ND*dim
+   double *cg_r, *cg_z, *cg_d0, *cg_d1, *cg_y; // max(N, L2V)
+   double *partials;     // 4 reduction slots of part_stride block partials each
+   int part_stride;      // >= max #blocks of any reducing launch
+   unsigned int *tickets;// 8 counters
+   lgh::CgScalars *cgs;  // device
+   double *scal;         // small device scalar pool (16 doubles)
+   double *host_pinned;  // pinned host staging (16 doubles)
+
+   lgh::Timers timers;
+   lgh::Comm *comm;
+   int nranks, rank;
+};
+
+namespace lgh
+{
+
+// ---- wave / block reductions (wave64 shuffles) ------------------------------
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+   for (int off = 32; off > 0; off >>= 1) { v += __shfl_down(v, off, 64); }
+   return v;
+}
+__device__ __forceinline__ double wave_min(double v)
+{
+#pragma unroll
+   for (int off = 32; off > 0; off >>= 1) { v = fmin(v, __shfl_down(v, off, 64)); }
+   return v;
+}
+
+// Sum over the block; result valid in thread 0.  `red` = LDS scratch of >= 16 doubles.
+__device__ __forceinline__ double block_sum(double v, double *red)
+{
+   const int tid = threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z);
+   const int nthr = blockDim.x * blockDim.y * blockDim.z;
+   const int lane = tid & 63, wid = tid >> 6, nw = (nthr + 63) >> 6;
+   v = wave_sum(v);
+   __syncthreads();
+   if (lane == 0) { red[wid] = v; }
+   __syncthreads();
+   double s = 0.0;
+   if (tid == 0)
+   {
+      for (int w = 0; w < nw; w++) { s += red[w]; }
+   }
+   return s;
+}
+__device__ __forceinline__ double block_min(double v, double *red)
+{
+   const int tid = threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z);
+   const int nthr = blockDim.x * blockDim.y * blockDim.z;
+   const int lane = tid & 63, wid = tid >> 6, nw = (nthr + 63) >> 6;
+   v = wave_min(v);
+   __syncthreads();
+   if (lane == 0) { red[wid] = v; }
+   __syncthreads();
+   double s = v;
+   if (tid == 0)
+   {
+      s = red[0];
+      for (int w = 1; w < nw; w++) { s = fmin(s, red[w]); }
+   }
+   return s;
+}
+
+// Deterministic grid-wide sum without a second launch: every block publishes its
+// partial with an agent-scope (write-through) atomic store, drains, takes a
+// ticket; the last block re-reads all partials with agent-scope loads in block
+// order.  Both sides use 8-byte agent atomics (MI355X guide, Guideline 16), so no
+// L2 write-back fence is needed.  Returns true in ALL threads of the last block;
+// `total` is then valid in thread 0 of that block.  The ticket counter is reset
+// by the last block, so the slot is reusable by the next launch on the stream.
+__device__ __forceinline__ bool grid_sum_last_block(double block_partial /* thread 0 */,
+                                                    double *partials, unsigned int *ticket,
+                                                    double *red, double &total)
+{
+   const int tid = threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z);
+   const int nthr = blockDim.x * blockDim.y * blockDim.z;
+   const unsigned int nblk = gridDim.x * gridDim.y * gridDim.z;
+   const unsigned int bid = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+   __shared__ unsigned int s_last;
+   if (tid == 0)
+   {
+      __hip_atomic_store(&partials[bid], block_partial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_last = (t == nblk - 1) ? 1u : 0u;
+   }
+   __syncthreads();
+   if (!s_last) { return false; }
+   // fixed-order tree: thread t sums partials t, t+nthr, ...; then block_sum
+   double s = 0.0;
+   for (unsigned int i = tid; i < nblk; i += nthr)
+   {
+      s += __hip_atomic_load(&partials[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+   }
+   total = block_sum(s, red);
+   if (tid == 0) { __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+   return true;
+}
+
+// block index -> work chunk so that blocks resident on one XCD (observed:
+// block b runs on XCD b % 8) sweep a contiguous range: neighbouring elements
+// share H1 nodes, so their gathers hit the same XCD-private L2.
+__device__ __forceinline__ int xcd_swizzle(const int b, const int nblocks)
+{
+   const int per = nblocks >> 3; // blocks per XCD (floor)
+   const int main = per << 3;
+   if (b >= main) { return b; } // tail stays in place
+   return (b & 7) * per + (b >> 3);
+}
+
+inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---- cross-TU launch helpers (implemented in the .hip files) ------------------
+int force_mult_E(lgh_ctx *c, const double *sJit, const double *xE, double *yE);
+int force_mult_t_L(lgh_ctx *c, const double *sJit, const double *v_h1, double *y_l2);
+int force_mult_t_E(lgh_ctx *c, const double *sJit, const double *vE, double *y_l2);
+int h1_transpose_gather(lgh_ctx *c, int ncomp, const double *YE, double *yL);
+int mass_apply_h1(lgh_ctx *c, const double *x, double *y, bool eliminate);
+int mass_apply_l2(lgh_ctx *c, const double *x, double *y);
+int mass_apply_E(lgh_ctx *c, int space, const double *xE, double *yE);
+int mass_assemble_diag(lgh_ctx *c);
+int cg_solve(lgh_ctx *c, int space, const double *b, double *x, double rel_tol, int max_iter,
+             int *iters, bool x_is_zero);
+int qupdate(lgh_ctx *c, const double *S);
+int setup_rho0detj0(lgh_ctx *c, const double *x0, const double *rho0_l2, const double *rho0_q,
+                    double *volume);
+int interp_energy(lgh_ctx *c, int which, const double *vec, double *result);
+int test_eig(lgh_ctx *c, int dim, int n, const double *A, double *lambda, double *vec);
+int test_singular(lgh_ctx *c, int dim, int n, const double *A, double *sv);
+int vec_set(lgh_ctx *c, double *y, double a, long n);
+int vec_axpby(lgh_ctx *c, double *z, double a, const double *x, double b, const double *y, long n);
+int vec_neg_inplace(lgh_ctx *c, double *y, long n);
+int vec_zero_list(lgh_ctx *c, double *y, const int *list, int n);
+int vec_dot(lgh_ctx *c, const double *x, const double *y, const double *w, long n, double *dev_out);
+int halo_sum(lgh_ctx *c, double *v, int ncomp);
+int allreduce_dev(lgh_ctx *c, double *dev, int count, int op);
+
+void timer_start(lgh_ctx *c);
+void timer_stop(lgh_ctx *c, int which);
+
+} // namespace lgh

@@ -1,0 +1,772 @@
+// lgh_mass.hip — MassPAOperator action, Jacobi diagonal and the device-resident
+// CG solves for gfx950.
+//
+// Replaces MassPAOperator::{Mult,MultFull,EliminateRHS}
+// (/root/reference/laghos_assembly.cpp:80-121; the contraction itself is upstream
+// MFEM MassIntegrator::AddMultPA, same math as amr/laghos_assembly.cpp:878-963),
+// OperatorJacobiSmoother (laghos_solver.cpp:266-270) and the two CGSolver
+// instances configured at laghos_solver.cpp:264-284 (algorithm: SURVEY §3.2).
+//
+// MI355X design: one CG iteration is two kernels and no host round trip.
+//   K1 (element batches): beta = rz/rz_prev; d = z + beta*d fused into the
+//       gather (ping-pong direction buffers, so elements sharing a node never
+//       see a half-updated value); y_e = B^T D B d_e with the z contraction in
+//       registers and tables in SGPRs; den = sum_e d_e.y_e (the E-vector form of
+//       (d, A d), so no extra pass over the L-vector is needed).
+//   K2 (nodes): z = sum of element contributions (deterministic CSR gather, no
+//       atomics), essential rows zeroed, alpha = rz/den, x += alpha d,
+//       r -= alpha z, z = r/diag, betanom = (r,z) with a wave64 shuffle
+//       reduction; the last block to finish folds the block partials in fixed
+//       order, updates the device scalars and the convergence flag.
+// The host only enqueues iterations in chunks and looks at the flag between
+// chunks; once `done` is set the remaining kernels of a chunk exit immediately.
+#include "lgh_common.hpp"
+
+namespace lgh
+{
+
+// ---------------------------------------------------------------------------
+// element kernel: y_e = B^T diag(D_e) B x_e
+//   MODE 0: x is an E-vector (or L2 vector), plain apply
+//   MODE 1: x gathered from an L-vector through `map`
+//   MODE 2: CG K1 (H1): d_new = z[map] + beta * d_old[map]; write d_new; den
+//   MODE 3: CG K1 (L2, no map): d_new = r + beta*d_old (element-local vectors)
+// ---------------------------------------------------------------------------
+struct MassArgs
+{
+   int NE;
+   const double *B;   // [q + Q*d]
+   const double *Dq;  // [q + NQ*e]
+   const double *x;   // MODE 0/1 input; MODE 2/3: z (H1) or r (L2)
+   const int *map;    // NE*ND or null
+   double *y;         // E-vector (H1) or L2 vector output
+   // CG
+   const double *d_old;
+   double *d_new;
+   CgScalars *cgs;
+   double *partials;
+   unsigned int *ticket;
+   int multi; // multi-GPU: den is all-reduced before any decision is taken on it
+};
+
+template <int D, int Q, int NEB, int MODE>
+__global__ void __launch_bounds__(Q *Q *NEB)
+mass_apply_3d(const MassArgs a)
+{
+   constexpr int NQ = Q * Q * Q, ND = D * D * D;
+   constexpr int SX = (ND > D * Q * Q) ? ND : D * Q * Q; // X then C[dz][qy][qx]
+   constexpr int SA = D * D * Q;                         // A[dz][dy][qx] then E[dz][qy][dx]
+   constexpr int SAE = (SA > D * Q * D) ? SA : D * Q * D;
+   constexpr int PER = SX + SAE + 1;
+   __shared__ double smem[NEB * PER];
+   __shared__ double red[16];
+
+   const int tid = threadIdx.x;
+   const int tx = tid % Q, ty = (tid / Q) % Q, eb = tid / (Q * Q);
+   const int nblocks = gridDim.x;
+   const int blk = (MODE == 2 || MODE == 1) ? xcd_swizzle(blockIdx.x, nblocks) : blockIdx.x;
+   const int e0 = blk * NEB;
+   const int e = e0 + eb;
+   const bool active = (e < a.NE);
+   double *sX = smem + eb * PER;
+   double *sA = sX + SX;
+
+   double beta = 0.0;
+   if (MODE >= 2)
+   {
+      if (a.cgs->done) { return; }
+      beta = a.cgs->first ? 0.0 : a.cgs->rz / a.cgs->rz_prev;
+   }
+
+   // ---- cooperative load of the block's element dofs
+   {
+      const int nthr = Q * Q * NEB;
+      const int nel = min(NEB, a.NE - e0);
+      for (int i = tid; i < nel * ND; i += nthr)
+      {
+         const int el = i / ND, d = i - el * ND;
+         const size_t p = (size_t)(e0 + el) * ND + d;
+         double val;
+         if (MODE == 0) { val = a.x[p]; }
+         else if (MODE == 1) { val = a.x[a.map[p]]; }
+         else if (MODE == 2)
+         {
+            const int n = a.map[p];
+            val = a.x[n] + beta * a.d_old[n];
+            a.d_new[n] = val; // every element sharing n writes the same value
+         }
+         else
+         {
+            val = a.x[p] + beta * a.d_old[p];
+            a.d_new[p] = val;
+         }
+         smem[el * PER + d] = val;
+      }
+   }
+   double bx[D], by[D];
+#pragma unroll
+   for (int d = 0; d < D; d++)
+   {
+      bx[d] = a.B[tx + Q * d];
+      by[d] = a.B[ty + Q * d];
+   }
+   // quadrature data of this column, issued early
+   double dq[Q];
+   if (active)
+   {
+      const double *p = a.Dq + (size_t)e * NQ + tx + Q * ty;
+#pragma unroll
+      for (int qz = 0; qz < Q; qz++) { dq[qz] = p[Q * Q * qz]; }
+   }
+   else
+   {
+#pragma unroll
+      for (int qz = 0; qz < Q; qz++) { dq[qz] = 0.0; }
+   }
+   __syncthreads();
+
+   // E-level dot needs x_e for the (dx,dy) threads: keep the column in registers
+   double xcol[D];
+   if (MODE >= 2)
+   {
+#pragma unroll
+      for (int dz = 0; dz < D; dz++) { xcol[dz] = (tx < D && ty < D) ? sX[tx + D * (ty + D * dz)] : 0.0; }
+   }
+
+   // forward x: thread (qx = tx, dy = ty < D)
+   if (ty < D)
+   {
+#pragma unroll
+      for (int dz = 0; dz < D; dz++)
+      {
+         double u = 0.0;
+#pragma unroll
+         for (int dx = 0; dx < D; dx++) { u += bx[dx] * sX[dx + D * (ty + D * dz)]; }
+         sA[tx + Q * (ty + D * dz)] = u;
+      }
+   }
+   __syncthreads();
+   // forward y (registers per dz), forward z, scale, backward z
+   double r[D];
+   {
+      double bb[D];
+#pragma unroll
+      for (int dz = 0; dz < D; dz++)
+      {
+         double u = 0.0;
+#pragma unroll
+         for (int dy = 0; dy < D; dy++) { u += by[dy] * sA[tx + Q * (dy + D * dz)]; }
+         bb[dz] = u;
+      }
+      double qv[Q];
+#pragma unroll
+      for (int qz = 0; qz < Q; qz++)
+      {
+         double u = 0.0;
+#pragma unroll
+         for (int dz = 0; dz < D; dz++) { u += a.B[qz + Q * dz] * bb[dz]; }
+         qv[qz] = u * dq[qz];
+      }
+#pragma unroll
+      for (int dz = 0; dz < D; dz++)
+      {
+         double u = 0.0;
+#pragma unroll
+         for (int qz = 0; qz < Q; qz++) { u += a.B[qz + Q * dz] * qv[qz]; }
+         r[dz] = u;
+      }
+   }
+   // sX is dead (read before the previous barrier): reuse as C[dz][qy][qx]
+#pragma unroll
+   for (int dz = 0; dz < D; dz++) { sX[tx + Q * (ty + Q * dz)] = r[dz]; }
+   __syncthreads();
+   // backward x: thread (dx = tx < D, qy = ty)
+   if (tx < D)
+   {
+      double brow[Q];
+#pragma unroll
+      for (int q = 0; q < Q; q++) { brow[q] = a.B[q + Q * tx]; }
+#pragma unroll
+      for (int dz = 0; dz < D; dz++)
+      {
+         double u = 0.0;
+#pragma unroll
+         for (int qx = 0; qx < Q; qx++) { u += brow[qx] * sX[qx + Q * (ty + Q * dz)]; }
+         sA[tx + D * (ty + Q * dz)] = u;
+      }
+   }
+   __syncthreads();
+   // backward y: thread (dx = tx < D, dy = ty < D)
+   double dot = 0.0;
+   if (tx < D && ty < D && active)
+   {
+      double brow[Q];
+#pragma unroll
+      for (int q = 0; q < Q; q++) { brow[q] = a.B[q + Q * ty]; }
+#pragma unroll
+      for (int dz = 0; dz < D; dz++)
+      {
+         double u = 0.0;
+#pragma unroll
+         for (int qy = 0; qy < Q; qy++) { u += brow[qy] * sA[tx + D * (qy + Q * dz)]; }
+         a.y[tx + D * (ty + D * dz) + (size_t)ND * e] = u;
+         if (MODE >= 2) { dot += xcol[dz] * u; }
+      }
+   }
+   if (MODE >= 2)
+   {
+      const double bsum = block_sum(dot, red);
+      double total;
+      if (grid_sum_last_block(bsum, a.partials, a.ticket, red, total))
+      {
+         if (tid == 0)
+         {
+            a.cgs->den = total;
+            if (a.cgs->first) { a.cgs->first = 0; }
+            if (total == 0.0 && !a.multi) { a.cgs->done = 1; } // breakdown (den == 0): stop, as upstream
+         }
+      }
+   }
+}
+
+// 2D: one thread per quadrature point; same MODE semantics.
+template <int D, int Q, int NEB, int MODE>
+__global__ void __launch_bounds__(Q *Q *NEB)
+mass_apply_2d(const MassArgs a)
+{
+   constexpr int NQ = Q * Q, ND = D * D;
+   constexpr int PER = ND + D * Q + NQ + 1;
+   __shared__ double smem[NEB * PER];
+   __shared__ double red[16];
+   const int tid = threadIdx.x;
+   const int tx = tid % Q, ty = (tid / Q) % Q, eb = tid / (Q * Q);
+   const int e0 = blockIdx.x * NEB;
+   const int e = e0 + eb;
+   const bool active = (e < a.NE);
+   double *sX = smem + eb * PER; // [dy][dx]
+   double *sA = sX + ND;         // [dy][qx] / [qy][dx]
+   double *sQ = sA + D * Q;      // [qy][qx]
+   double beta = 0.0;
+   if (MODE >= 2)
+   {
+      if (a.cgs->done) { return; }
+      beta = a.cgs->first ? 0.0 : a.cgs->rz / a.cgs->rz_prev;
+   }
+   {
+      const int nthr = Q * Q * NEB;
+      const int nel = min(NEB, a.NE - e0);
+      for (int i = tid; i < nel * ND; i += nthr)
+      {
+         const int el = i / ND, d = i - el * ND;
+         const size_t p = (size_t)(e0 + el) * ND + d;
+         double val;
+         if (MODE == 0) { val = a.x[p]; }
+         else if (MODE == 1) { val = a.x[a.map[p]]; }
+         else if (MODE == 2)
+         {
+            const int n = a.map[p];
+            val = a.x[n] + beta * a.d_old[n];
+            a.d_new[n] = val;
+         }
+         else
+         {
+            val = a.x[p] + beta * a.d_old[p];
+            a.d_new[p] = val;
+         }
+         smem[el * PER + d] = val;
+      }
+   }
+   __syncthreads();
+   if (ty < D)
+   {
+      double u = 0.0;
+      for (int dx = 0; dx < D; dx++) { u += a.B[tx + Q * dx] * sX[dx + D * ty]; }
+      sA[tx + Q * ty] = u;
+   }
+   __syncthreads();
+   {
+      double u = 0.0;
+      for (int dy = 0; dy < D; dy++) { u += a.B[ty + Q * dy] * sA[tx + Q * dy]; }
+      sQ[tx + Q * ty] = active ? u * a.Dq[(size_t)e * NQ + tx + Q * ty] : 0.0;
+   }
+   __syncthreads();
+   if (tx < D)
+   {
+      double u = 0.0;
+      for (int qx = 0; qx < Q; qx++) { u += a.B[qx + Q * tx] * sQ[qx + Q * ty]; }
+      sA[tx + D * ty] = u;
+   }
+   __syncthreads();
+   double dot = 0.0;
+   if (tx < D && ty < D && active)
+   {
+      double u = 0.0;
+      for (int qy = 0; qy < Q; qy++) { u += a.B[qy + Q * ty] * sA[tx + D * qy]; }
+      a.y[tx + D * ty + (size_t)ND * e] = u;
+      if (MODE >= 2) { dot = sX[tx + D * ty] * u; }
+   }
+   if (MODE >= 2)
+   {
+      const double bsum = block_sum(dot, red);
+      double total;
+      if (grid_sum_last_block(bsum, a.partials, a.ticket, red, total))
+      {
+         if (tid == 0)
+         {
+            a.cgs->den = total;
+            if (a.cgs->first) { a.cgs->first = 0; }
+            if (total == 0.0 && !a.multi) { a.cgs->done = 1; }
+         }
+      }
+   }
+}
+
+static int unknown_kernel(int id)
+{
+   set_error("Unknown kernel 0x%x", id);
+   return LGH_ERR_UNSUPPORTED;
+}
+
+template <int Q> constexpr int neb_for() { return (256 / (Q * Q)) > 0 ? (256 / (Q * Q)) : 1; }
+
+template <int MODE> static int launch_mass(lgh_ctx *c, int space, const MassArgs &a)
+{
+   const int n1d = (space == LGH_SPACE_H1) ? c->D1D : c->L1D;
+   const int id = (c->dim << 8) | (n1d << 4) | c->Q1D;
+#define LGH_MASS_CASE(DIMK, D_, Q_)                                                           \
+   {                                                                                          \
+      constexpr int NEB_ = neb_for<Q_>();                                                     \
+      hipLaunchKernelGGL((DIMK<D_, Q_, NEB_, MODE>), dim3(ceil_div(c->NE, NEB_)),             \
+                         dim3(Q_ * Q_ * NEB_), 0, c->stream, a);                              \
+   }                                                                                          \
+   break
+   switch (id)
+   {
+      case 0x212: LGH_MASS_CASE(mass_apply_2d, 1, 2);
+      case 0x222: LGH_MASS_CASE(mass_apply_2d, 2, 2);
+      case 0x224: LGH_MASS_CASE(mass_apply_2d, 2, 4);
+      case 0x234: LGH_MASS_CASE(mass_apply_2d, 3, 4);
+      case 0x236: LGH_MASS_CASE(mass_apply_2d, 3, 6);
+      case 0x246: LGH_MASS_CASE(mass_apply_2d, 4, 6);
+      case 0x248: LGH_MASS_CASE(mass_apply_2d, 4, 8);
+      case 0x258: LGH_MASS_CASE(mass_apply_2d, 5, 8);
+      case 0x25A: LGH_MASS_CASE(mass_apply_2d, 5, 10);
+      case 0x26A: LGH_MASS_CASE(mass_apply_2d, 6, 10);
+      case 0x312: LGH_MASS_CASE(mass_apply_3d, 1, 2);
+      case 0x322: LGH_MASS_CASE(mass_apply_3d, 2, 2);
+      case 0x324: LGH_MASS_CASE(mass_apply_3d, 2, 4);
+      case 0x334: LGH_MASS_CASE(mass_apply_3d, 3, 4);
+      case 0x336: LGH_MASS_CASE(mass_apply_3d, 3, 6);
+      case 0x346: LGH_MASS_CASE(mass_apply_3d, 4, 6);
+      case 0x348: LGH_MASS_CASE(mass_apply_3d, 4, 8);
+      case 0x358: LGH_MASS_CASE(mass_apply_3d, 5, 8);
+      case 0x35A: LGH_MASS_CASE(mass_apply_3d, 5, 10);
+      case 0x36A: LGH_MASS_CASE(mass_apply_3d, 6, 10);
+      default: return unknown_kernel(id);
+   }
+#undef LGH_MASS_CASE
+   LGH_HIP_CHECK(hipGetLastError());
+   return LGH_OK;
+}
+
+static MassArgs base_args(lgh_ctx *c, int space)
+{
+   MassArgs a;
+   memset(&a, 0, sizeof(a));
+   a.NE = c->NE;
+   a.B = (space == LGH_SPACE_H1) ? c->B : c->Bl;
+   a.Dq = c->massD;
+   return a;
+}
+
+int mass_apply_E(lgh_ctx *c, int space, const double *xE, double *yE)
+{
+   MassArgs a = base_args(c, space);
+   a.x = xE;
+   a.y = yE;
+   return launch_mass<0>(c, space, a);
+}
+
+// ---- node kernels -----------------------------------------------------------
+// y[n] = sum of element contributions; optional essential-row elimination.
+__global__ void __launch_bounds__(256)
+mass_gather_k(const int N, const int ND, const int *__restrict__ off, const int *__restrict__ idx,
+              const double *__restrict__ YE, const uint8_t *__restrict__ ess, double *__restrict__ y)
+{
+   const int n = blockIdx.x * blockDim.x + threadIdx.x;
+   if (n >= N) { return; }
+   double s = 0.0;
+   for (int k = off[n]; k < off[n + 1]; k++) { s += YE[idx[k]]; }
+   if (ess && ess[n]) { s = 0.0; }
+   y[n] = s;
+}
+
+int mass_apply_h1(lgh_ctx *c, const double *x, double *y, bool eliminate)
+{
+   MassArgs a = base_args(c, LGH_SPACE_H1);
+   a.x = x;
+   a.map = c->h1map;
+   a.y = c->YE;
+   int rc = launch_mass<1>(c, LGH_SPACE_H1, a);
+   if (rc) { return rc; }
+   const bool multi = (c->nranks > 1);
+   const uint8_t *ess = (eliminate && c->cur_ess >= 0 && !multi) ? c->essmask[c->cur_ess] : nullptr;
+   hipLaunchKernelGGL(mass_gather_k, dim3(ceil_div(c->N, 256)), dim3(256), 0, c->stream, c->N,
+                      c->ND, c->t_off, c->t_idx, c->YE, ess, y);
+   LGH_HIP_CHECK(hipGetLastError());
+   if (multi)
+   {
+      rc = halo_sum(c, y, 1);
+      if (rc) { return rc; }
+      if (eliminate && c->cur_ess >= 0 && c->ess_count[c->cur_ess] > 0)
+      {
+         rc = vec_zero_list(c, y, c->ess[c->cur_ess], c->ess_count[c->cur_ess]);
+      }
+   }
+   return rc;
+}
+
+int mass_apply_l2(lgh_ctx *c, const double *x, double *y)
+{
+   MassArgs a = base_args(c, LGH_SPACE_L2);
+   a.x = x;
+   a.y = y;
+   return launch_mass<0>(c, LGH_SPACE_L2, a);
+}
+
+// ---- Jacobi diagonal: diag_e[d] = sum_q prod_a B(q_a,d_a)^2 D_e[q] ---------------
+template <int DIM>
+__global__ void __launch_bounds__(256)
+mass_diag_k(const int NE, const int D, const int Q, const double *__restrict__ B,
+            const double *__restrict__ Dq, double *__restrict__ yE)
+{
+   const int ND = (DIM == 2) ? D * D : D * D * D;
+   const int NQ = (DIM == 2) ? Q * Q : Q * Q * Q;
+   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+   if (i >= (size_t)NE * ND) { return; }
+   const int e = (int)(i / ND), d = (int)(i - (size_t)e * ND);
+   const int dx = d % D, dy = (d / D) % D, dz = d / (D * D);
+   const double *De = Dq + (size_t)e * NQ;
+   double s = 0.0;
+   if (DIM == 2)
+   {
+      for (int qy = 0; qy < Q; qy++)
+         for (int qx = 0; qx < Q; qx++)
+         {
+            const double bxv = B[qx + Q * dx], byv = B[qy + Q * dy];
+            s += bxv * bxv * byv * byv * De[qx + Q * qy];
+         }
+   }
+   else
+   {
+      for (int qz = 0; qz < Q; qz++)
+         for (int qy = 0; qy < Q; qy++)
+            for (int qx = 0; qx < Q; qx++)
+            {
+               const double bxv = B[qx + Q * dx], byv = B[qy + Q * dy], bzv = B[qz + Q * dz];
+               s += bxv * bxv * byv * byv * bzv * bzv * De[qx + Q * (qy + Q * qz)];
+            }
+   }
+   yE[i] = s;
+}
+
+__global__ void __launch_bounds__(256)
+reciprocal_k(const int n, const double *__restrict__ x, double *__restrict__ y)
+{
+   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+   if (i < n) { y[i] = 1.0 / x[i]; }
+}
+
+int mass_assemble_diag(lgh_ctx *c)
+{
+   const size_t tot = (size_t)c->NE * c->ND;
+   if (c->dim == 2)
+   {
+      hipLaunchKernelGGL(mass_diag_k<2>, dim3(ceil_div(tot, 256)), dim3(256), 0, c->stream, c->NE,
+                         c->D1D, c->Q1D, c->B, c->massD, c->YE);
+   }
+   else
+   {
+      hipLaunchKernelGGL(mass_diag_k<3>, dim3(ceil_div(tot, 256)), dim3(256), 0, c->stream, c->NE,
+                         c->D1D, c->Q1D, c->B, c->massD, c->YE);
+   }
+   LGH_HIP_CHECK(hipGetLastError());
+   hipLaunchKernelGGL(mass_gather_k, dim3(ceil_div(c->N, 256)), dim3(256), 0, c->stream, c->N,
+                      c->ND, c->t_off, c->t_idx, c->YE, (const uint8_t *)nullptr, c->diagV);
+   LGH_HIP_CHECK(hipGetLastError());
+   if (c->nranks > 1)
+   {
+      int rc = halo_sum(c, c->diagV, 1);
+      if (rc) { return rc; }
+   }
+   hipLaunchKernelGGL(reciprocal_k, dim3(ceil_div(c->N, 256)), dim3(256), 0, c->stream, c->N,
+                      c->diagV, c->dinvV);
+   LGH_HIP_CHECK(hipGetLastError());
+   return LGH_OK;
+}
+
+// ---------------------------------------------------------------------------
+// CG node / vector kernels
+// ---------------------------------------------------------------------------
+struct CgVecArgs
+{
+   int n;              // N (H1) or L2V
+   const int *off;     // H1 fused gather (null: y already an L-vector)
+   const int *idx;
+   const double *YE;   // E-vector from K1 (H1) ...
+   const double *yL;   // ... or the operator result as an L-vector (L2, multi-GPU H1)
+   const uint8_t *ess; // essential mask or null
+   const double *dinv; // Jacobi (null: no preconditioner)
+   const double *owner;// ownership weights or null
+   const double *b;
+   const double *d;
+   double *x, *r, *z;
+   CgScalars *cgs;
+   double *partials;
+   unsigned int *ticket;
+   int iter;
+   int allreduce_pending; // multi-GPU: the scalar fold is finished by a later kernel
+};
+
+// init: r = b - A x (A x supplied in yL/YE, or absent when x == 0), z = M^-1 r,
+// nom = (z, r); sets r0, done, rz.
+template <bool HAVE_AX>
+__global__ void __launch_bounds__(256)
+cg_init_k(const CgVecArgs a)
+{
+   __shared__ double red[16];
+   const int n = blockIdx.x * blockDim.x + threadIdx.x;
+   double part = 0.0;
+   if (n < a.n)
+   {
+      double rv = a.b[n];
+      if (HAVE_AX) { rv -= a.yL[n]; }
+      a.r[n] = rv;
+      double zv = rv;
+      if (a.dinv)
+      {
+         zv = rv * a.dinv[n];
+         a.z[n] = zv;
+      }
+      part = (a.owner ? a.owner[n] : 1.0) * zv * rv;
+   }
+   const double bsum = block_sum(part, red);
+   double total;
+   if (grid_sum_last_block(bsum, a.partials, a.ticket, red, total))
+   {
+      if (threadIdx.x == 0)
+      {
+         CgScalars *s = a.cgs;
+         s->rz = total;
+         s->rz_prev = total;
+         s->nom0 = total;
+         s->iters = 0;
+         s->first = 1;
+         if (!a.allreduce_pending)
+         {
+            s->r0 = fmax(total * s->rel_tol2, 0.0);
+            s->done = (total < 0.0 || total <= s->r0) ? 1 : 0;
+         }
+      }
+   }
+}
+
+// multi-GPU: after the all-reduce of rz (init) finish the scalar bookkeeping
+__global__ void cg_init_finish_k(CgScalars *s)
+{
+   s->rz_prev = s->rz;
+   s->nom0 = s->rz;
+   s->r0 = fmax(s->rz * s->rel_tol2, 0.0);
+   s->done = (s->rz < 0.0 || s->rz <= s->r0) ? 1 : 0;
+}
+
+// K2: see file header.
+template <bool FUSED_GATHER>
+__global__ void __launch_bounds__(256)
+cg_update_k(const CgVecArgs a)
+{
+   __shared__ double red[16];
+   if (a.cgs->done) { return; }
+   const double alpha = a.cgs->rz / a.cgs->den;
+   const int n = blockIdx.x * blockDim.x + threadIdx.x;
+   double part = 0.0;
+   if (n < a.n)
+   {
+      double zv;
+      if (FUSED_GATHER)
+      {
+         zv = 0.0;
+         for (int k = a.off[n]; k < a.off[n + 1]; k++) { zv += a.YE[a.idx[k]]; }
+      }
+      else { zv = a.yL[n]; }
+      if (a.ess && a.ess[n]) { zv = 0.0; }
+      const double xv = a.x[n] + alpha * a.d[n];
+      const double rv = a.r[n] - alpha * zv;
+      a.x[n] = xv;
+      a.r[n] = rv;
+      double pz = rv;
+      if (a.dinv)
+      {
+         pz = rv * a.dinv[n];
+         a.z[n] = pz;
+      }
+      part = (a.owner ? a.owner[n] : 1.0) * rv * pz;
+   }
+   const double bsum = block_sum(part, red);
+   double total;
+   if (grid_sum_last_block(bsum, a.partials, a.ticket, red, total))
+   {
+      if (threadIdx.x == 0)
+      {
+         CgScalars *s = a.cgs;
+         s->rz_prev = s->rz;
+         s->rz = total; // betanom
+         if (!a.allreduce_pending)
+         {
+            s->iters = a.iter;
+            if (total < 0.0 || total <= s->r0) { s->done = 1; }
+         }
+      }
+   }
+}
+__global__ void cg_update_finish_k(CgScalars *s, int iter)
+{
+   if (s->done) { return; }
+   s->iters = iter;
+   if (s->rz < 0.0 || s->rz <= s->r0) { s->done = 1; }
+}
+
+// In multi-GPU runs a rank-local `done` can only be set from all-reduced values,
+// so every rank takes identical decisions.
+__global__ void cg_den_finish_k(CgScalars *s)
+{
+   if (s->done) { return; }
+   if (s->den == 0.0) { s->done = 1; }
+}
+
+__global__ void cg_set_tol_k(CgScalars *s, double rel_tol2)
+{
+   s->rel_tol2 = rel_tol2;
+   s->done = 0;
+   s->first = 1;
+   s->iters = 0;
+}
+
+int cg_solve(lgh_ctx *c, int space, const double *b, double *x, double rel_tol, int max_iter,
+             int *iters, bool x_is_zero)
+{
+   const bool h1 = (space == LGH_SPACE_H1);
+   const int n = h1 ? c->N : c->L2V;
+   const bool multi = (c->nranks > 1);
+   int rc;
+   hipLaunchKernelGGL(cg_set_tol_k, dim3(1), dim3(1), 0, c->stream, c->cgs, rel_tol * rel_tol);
+
+   CgVecArgs v;
+   memset(&v, 0, sizeof(v));
+   v.n = n;
+   v.b = b;
+   v.x = x;
+   v.r = c->cg_r;
+   v.z = h1 ? c->cg_z : c->cg_r; // no preconditioner: z aliases r
+   v.dinv = h1 ? c->dinvV : nullptr;
+   v.owner = (h1 && multi) ? c->owner : nullptr;
+   v.cgs = c->cgs;
+   v.partials = c->partials;
+   v.ticket = c->tickets;
+   v.allreduce_pending = multi ? 1 : 0;
+   const uint8_t *ess = (h1 && c->cur_ess >= 0) ? c->essmask[c->cur_ess] : nullptr;
+   const int nb = ceil_div(n, 256);
+
+   // --- r = b - A x  (iterative_mode for H1; L2 starts from x = 0: solvers.cpp)
+   if (!h1) { rc = vec_set(c, x, 0.0, n); if (rc) { return rc; } x_is_zero = true; }
+   if (!x_is_zero)
+   {
+      rc = mass_apply_h1(c, x, c->cg_y, true);
+      if (rc) { return rc; }
+      v.yL = c->cg_y;
+      hipLaunchKernelGGL(cg_init_k<true>, dim3(nb), dim3(256), 0, c->stream, v);
+   }
+   else { hipLaunchKernelGGL(cg_init_k<false>, dim3(nb), dim3(256), 0, c->stream, v); }
+   LGH_HIP_CHECK(hipGetLastError());
+   if (multi)
+   {
+      rc = allreduce_dev(c, &c->cgs->rz, 1, 0);
+      if (rc) { return rc; }
+      hipLaunchKernelGGL(cg_init_finish_k, dim3(1), dim3(1), 0, c->stream, c->cgs);
+   }
+
+   MassArgs m = base_args(c, space);
+   m.x = h1 ? c->cg_z : c->cg_r;
+   m.map = h1 ? c->h1map : nullptr;
+   m.y = h1 ? c->YE : c->cg_y;
+   m.cgs = c->cgs;
+   m.partials = c->partials + c->part_stride;
+   m.ticket = c->tickets + 1;
+   m.multi = multi ? 1 : 0;
+
+   double *dbuf[2] = {c->cg_d0, c->cg_d1};
+   int it = 0;
+   CgScalars *hs = (CgScalars *)c->host_pinned;
+   // chunk = iterations enqueued between two looks at the convergence flag
+   int chunk = 8;
+   bool done = false;
+   while (!done)
+   {
+      LGH_HIP_CHECK(hipMemcpyAsync(hs, c->cgs, sizeof(CgScalars), hipMemcpyDeviceToHost, c->stream));
+      LGH_HIP_CHECK(hipStreamSynchronize(c->stream));
+      if (hs->done || it >= max_iter) { break; }
+      const int upto = std::min(max_iter, it + chunk);
+      for (; it < upto;)
+      {
+         ++it;
+         m.d_old = dbuf[(it - 1) & 1];
+         m.d_new = dbuf[it & 1];
+         rc = h1 ? launch_mass<2>(c, space, m) : launch_mass<3>(c, space, m);
+         if (rc) { return rc; }
+         v.d = m.d_new;
+         v.iter = it;
+         v.ess = ess;
+         if (h1 && !multi)
+         {
+            v.off = c->t_off;
+            v.idx = c->t_idx;
+            v.YE = c->YE;
+            hipLaunchKernelGGL(cg_update_k<true>, dim3(nb), dim3(256), 0, c->stream, v);
+         }
+         else
+         {
+            if (h1)
+            {
+               // multi-GPU: assemble the L-vector, sum shared nodes, reduce den
+               hipLaunchKernelGGL(mass_gather_k, dim3(nb), dim3(256), 0, c->stream, c->N, c->ND,
+                                  c->t_off, c->t_idx, c->YE, (const uint8_t *)nullptr, c->cg_y);
+               rc = halo_sum(c, c->cg_y, 1);
+               if (rc) { return rc; }
+            }
+            if (multi)
+            {
+               rc = allreduce_dev(c, &c->cgs->den, 1, 0);
+               if (rc) { return rc; }
+               hipLaunchKernelGGL(cg_den_finish_k, dim3(1), dim3(1), 0, c->stream, c->cgs);
+            }
+            v.yL = c->cg_y;
+            hipLaunchKernelGGL(cg_update_k<false>, dim3(nb), dim3(256), 0, c->stream, v);
+            if (multi)
+            {
+               rc = allreduce_dev(c, &c->cgs->rz, 1, 0);
+               if (rc) { return rc; }
+               hipLaunchKernelGGL(cg_update_finish_k, dim3(1), dim3(1), 0, c->stream, c->cgs, it);
+            }
+         }
+         LGH_HIP_CHECK(hipGetLastError());
+      }
+      chunk = std::min(chunk * 2, 32);
+   }
+   // upstream: final_iter = max_iter when the loop runs out without converging
+   int fin = hs->iters;
+   if (!hs->done && it >= max_iter) { fin = max_iter; }
+   if (iters) { *iters = fin; }
+   return LGH_OK;
+}
+
+} // namespace lgh

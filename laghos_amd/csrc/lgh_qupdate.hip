@@ -1,0 +1,619 @@
+// lgh_qupdate.hip — quadrature-data update, initial geometric data and energy
+// integrals for gfx950.
+//
+// Replaces QUpdate::UpdateQuadratureData + QKernel/QUpdateBody
+// (/root/reference/laghos_solver.cpp:1354-1411, :1263-1352, :1042-1168),
+// Rho0DetJ0Vol (:1170-1261) and InternalEnergy/KineticEnergy (:640-697).
+//
+// MI355X design: the reference makes five global-memory round trips before the
+// physics kernel starts (E-vector of x, 9*NQ Jacobians, E-vector of v, 9*NQ
+// velocity gradients, NQ energies: laghos_solver.cpp:1365-1373).  Here one
+// workgroup per element gathers x, v, e straight from the state L-vector into
+// LDS, evaluates the reference gradients by sum factorisation in LDS, runs the
+// point-wise EOS / viscosity / time-step body in registers (one thread per
+// quadrature point) and streams the nine stressJinvT planes out coalesced.  The
+// running dt estimate is folded on the device (block min -> last-block fold).
+// Algorithmic traffic 36 KB/element instead of >= 100 KB.
+#include "lgh_common.hpp"
+#include "lgh_smallmat.hpp"
+
+namespace lgh
+{
+
+enum { QMODE_UPDATE = 0, QMODE_SETUP = 1, QMODE_IE = 2, QMODE_KE = 3 };
+
+struct QArgs
+{
+   int NE, N;
+   const double *B, *G, *Bl, *W;
+   const int *map;
+   const double *x, *v, *e; // L-vectors (byNODES for x, v)
+   const double *gamma;
+   const double *rho0DetJ0w_in;
+   const double *Jac0inv_in;
+   double *stressJinvT;
+   // setup outputs
+   double *Jac0inv_out, *rho0DetJ0w_out, *massD_out;
+   const double *rho0_q;
+   // reductions
+   double *partials;
+   unsigned int *ticket;
+   double *result; // dt_est (min-folded) or sum
+   double h0, h1order, cfl;
+   int visc, vort;
+};
+
+// Smooth transition between 0 and 1 for x in [-eps, eps] (laghos_solver.cpp:799-805)
+__device__ __forceinline__ double smooth_step_01(double x, double eps)
+{
+   const double y = (x + eps) / (2.0 * eps);
+   if (y < 0.0) { return 0.0; }
+   if (y > 1.0) { return 1.0; }
+   return (3.0 - 2.0 * y) * y * y;
+}
+
+__device__ __forceinline__ bool grid_min_last_block(double block_partial, double *partials,
+                                                    unsigned int *ticket, double *red, double &total)
+{
+   const int tid = threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z);
+   const int nthr = blockDim.x * blockDim.y * blockDim.z;
+   const unsigned int nblk = gridDim.x;
+   __shared__ unsigned int s_last;
+   if (tid == 0)
+   {
+      __hip_atomic_store(&partials[blockIdx.x], block_partial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_last = (t == nblk - 1) ? 1u : 0u;
+   }
+   __syncthreads();
+   if (!s_last) { return false; }
+   double s = INFINITY;
+   for (unsigned int i = tid; i < nblk; i += nthr)
+   {
+      s = fmin(s, __hip_atomic_load(&partials[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+   }
+   total = block_min(s, red);
+   if (tid == 0) { __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+   return true;
+}
+
+// The point-wise body: QUpdateBody (laghos_solver.cpp:1042-1168).  J and dV are
+// column-major [c + DIM*d] = d u_c / d xi_d.  Returns this point's dt candidate.
+template <int DIM>
+__device__ __forceinline__ double qpoint_body(const QArgs &a, const int e, const size_t eq,
+                                              const double weight, const double *J, const double *dV,
+                                              const double e_val, const size_t plane)
+{
+   constexpr int DIM2 = DIM * DIM;
+   double Jinv[DIM2], stress[DIM2], sgrad_v[DIM2], stressJiT[DIM2];
+   const double gamma = a.gamma[e];
+   const double inv_weight = 1. / weight;
+   const double detJ = sm::det<DIM>(J);
+   sm::inverse<DIM>(J, detJ, Jinv);
+   const double R = inv_weight * a.rho0DetJ0w_in[eq] / detJ;
+   const double E = fmax(0.0, e_val);
+   const double P = (gamma - 1.0) * R * E;
+   const double S = sqrt(gamma * (gamma - 1.0) * E);
+#pragma unroll
+   for (int k = 0; k < DIM2; k++) { stress[k] = 0.0; }
+#pragma unroll
+   for (int d = 0; d < DIM; d++) { stress[d * DIM + d] = -P; }
+   double visc_coeff = 0.0;
+   if (a.visc)
+   {
+      sm::matmul<DIM>(dV, Jinv, sgrad_v);
+      double vorticity_coeff = 1.0;
+      if (a.vort)
+      {
+         const double grad_norm = sm::fnorm<DIM>(sgrad_v);
+         const double div_v = fabs(sm::trace<DIM>(sgrad_v));
+         vorticity_coeff = (grad_norm > 0.0) ? div_v / grad_norm : 1.0;
+      }
+      sm::symmetrize<DIM>(sgrad_v);
+      double mu, compr_dir[DIM], Jpi[DIM2], ph_dir[DIM], J0i[DIM2];
+      sm::min_eigenpair<DIM>(sgrad_v, mu, compr_dir);
+#pragma unroll
+      for (int k = 0; k < DIM2; k++) { J0i[k] = a.Jac0inv_in[eq * DIM2 + k]; }
+      sm::matmul<DIM>(J, J0i, Jpi);
+      sm::matvec<DIM>(Jpi, compr_dir, ph_dir);
+      const double ph_dir_nl2 = sm::norml2<DIM>(ph_dir);
+      const double compr_dir_nl2 = sm::norml2<DIM>(compr_dir);
+      const double H = a.h0 * ph_dir_nl2 / compr_dir_nl2;
+      visc_coeff = 2.0 * R * H * H * fabs(mu);
+      const double eps = 1e-12;
+      visc_coeff += 0.5 * R * H * S * vorticity_coeff * (1.0 - smooth_step_01(mu - 2.0 * eps, eps));
+#pragma unroll
+      for (int k = 0; k < DIM2; k++) { stress[k] += visc_coeff * sgrad_v[k]; }
+   }
+   const double sv = sm::min_singular<DIM>(J);
+   const double h_min = sv / a.h1order;
+   const double ih_min = 1. / h_min;
+   const double irho_ih_min_sq = ih_min * ih_min / R;
+   const double idt = S * ih_min + 2.5 * visc_coeff * irho_ih_min_sq;
+   double dt_cand = INFINITY;
+   if (detJ < 0.0) { dt_cand = 0.0; }
+   else if (idt > 0.0) { dt_cand = a.cfl / idt; }
+   sm::matmul_abt<DIM>(stress, Jinv, stressJiT);
+   const double wd = weight * detJ;
+#pragma unroll
+   for (int vd = 0; vd < DIM; vd++)
+#pragma unroll
+      for (int gd = 0; gd < DIM; gd++)
+      {
+         a.stressJinvT[eq + plane * (gd + vd * DIM)] = stressJiT[vd + gd * DIM] * wd;
+      }
+   return dt_cand;
+}
+
+// One workgroup = NEB elements, one thread per quadrature point.
+//   3D: blockDim = Q^3 (NEB = 1); 2D: blockDim = Q^2 * NEB.
+// NF = H1 fields interpolated per LDS pass (3 unless LDS is short).
+template <int DIM, int D, int Q, int L, int NEB, int NF, int MODE>
+__global__ void __launch_bounds__((DIM == 3 ? Q * Q * Q : Q * Q) * NEB)
+qpoint_kernel(const QArgs a)
+{
+   constexpr int ND = (DIM == 3) ? D * D * D : D * D;
+   constexpr int NQ = (DIM == 3) ? Q * Q * Q : Q * Q;
+   constexpr int NL = (DIM == 3) ? L * L * L : L * L;
+   constexpr int NTE = NQ; // threads per element
+   // LDS per element
+   constexpr int SU = NF * ND;
+   constexpr int SXs = (DIM == 3) ? 2 * NF * D * D * Q : 2 * NF * D * Q; // B,G applied in x
+   constexpr int SYs = (DIM == 3) ? 3 * NF * D * Q * Q : 0;              // BB,GB,BG (3D only)
+   constexpr int SEs = NL + ((DIM == 3) ? (L * L * Q + L * Q * Q) : (L * Q));
+   constexpr int PER = SU + SXs + SYs + SEs + 1;
+   __shared__ double smem[NEB * PER];
+   __shared__ double sB[Q * D], sG[Q * D], sBl[Q * L];
+   __shared__ double red[16];
+
+   const int tid = threadIdx.x;
+   const int lt = tid % NTE, eb = tid / NTE;
+   const int tx = lt % Q, ty = (lt / Q) % Q, tz = lt / (Q * Q);
+   const int e = blockIdx.x * NEB + eb;
+   const bool active = (e < a.NE);
+   const int ec = active ? e : a.NE - 1; // clamp: inactive threads compute on a valid element
+   double *sU = smem + eb * PER;
+   double *sX = sU + SU;
+   double *sY = sX + SXs;
+   double *sE = sY + SYs;
+
+   for (int i = tid; i < Q * D; i += NTE * NEB) { sB[i] = a.B[i]; sG[i] = a.G[i]; }
+   for (int i = tid; i < Q * L; i += NTE * NEB) { sBl[i] = a.Bl[i]; }
+
+   constexpr bool NEED_X = (MODE == QMODE_UPDATE || MODE == QMODE_SETUP);
+   constexpr bool NEED_V = (MODE == QMODE_UPDATE || MODE == QMODE_KE);
+   constexpr bool NEED_E = (MODE != QMODE_KE);
+   constexpr int NFIELD = (NEED_X ? DIM : 0) + (NEED_V ? DIM : 0);
+
+   double grad[NFIELD > 0 ? NFIELD * DIM : 1]; // [field][d]
+   double val[NFIELD > 0 ? NFIELD : 1];
+   (void)grad;
+   (void)val;
+
+   for (int f0 = 0; f0 < NFIELD; f0 += NF)
+   {
+      __syncthreads(); // previous pass done with sU/sX/sY; tables visible
+      // gather NF fields of this element: field f -> (x or v, component)
+      for (int i = lt; i < NF * ND; i += NTE)
+      {
+         const int fl = i / ND, d = i - fl * ND;
+         const int f = f0 + fl;
+         double u = 0.0;
+         if (f < NFIELD)
+         {
+            const bool isx = NEED_X && (f < DIM);
+            const int comp = isx ? f : (f - (NEED_X ? DIM : 0));
+            const double *src = isx ? a.x : a.v;
+            u = src[(size_t)comp * a.N + a.map[(size_t)ec * ND + d]];
+         }
+         sU[i] = u;
+      }
+      __syncthreads();
+      if (DIM == 3)
+      {
+         // x stage: [k][fl][dz][dy][qx]
+         for (int i = lt; i < NF * D * D * Q; i += NTE)
+         {
+            const int qx = i % Q, dy = (i / Q) % D, dz = (i / (Q * D)) % D, fl = i / (Q * D * D);
+            double u = 0.0, w = 0.0;
+#pragma unroll
+            for (int dx = 0; dx < D; dx++)
+            {
+               const double s = sU[dx + D * (dy + D * dz) + ND * fl];
+               u += sB[qx + Q * dx] * s;
+               w += sG[qx + Q * dx] * s;
+            }
+            sX[i] = u;
+            sX[i + NF * D * D * Q] = w;
+         }
+         __syncthreads();
+         // y stage: BB, GB, BG [k][fl][dz][qy][qx]
+         for (int i = lt; i < NF * D * Q * Q; i += NTE)
+         {
+            const int qx = i % Q, qy = (i / Q) % Q, dz = (i / (Q * Q)) % D, fl = i / (Q * Q * D);
+            double bb = 0.0, gb = 0.0, bg = 0.0;
+#pragma unroll
+            for (int dy = 0; dy < D; dy++)
+            {
+               const int j = qx + Q * (dy + D * (dz + D * fl));
+               const double vb = sX[j], vg = sX[j + NF * D * D * Q];
+               bb += sB[qy + Q * dy] * vb;
+               gb += sB[qy + Q * dy] * vg;
+               bg += sG[qy + Q * dy] * vb;
+            }
+            sY[i] = bb;
+            sY[i + NF * D * Q * Q] = gb;
+            sY[i + 2 * NF * D * Q * Q] = bg;
+         }
+         __syncthreads();
+         // z stage: this thread's point
+#pragma unroll
+         for (int fl = 0; fl < NF; fl++)
+         {
+            if (f0 + fl < NFIELD)
+            {
+               double vv = 0.0, d0 = 0.0, d1 = 0.0, d2 = 0.0;
+#pragma unroll
+               for (int dz = 0; dz < D; dz++)
+               {
+                  const int j = tx + Q * (ty + Q * (dz + D * fl));
+                  const double b = sB[tz + Q * dz], g = sG[tz + Q * dz];
+                  const double bb = sY[j];
+                  vv += b * bb;
+                  d0 += b * sY[j + NF * D * Q * Q];
+                  d1 += b * sY[j + 2 * NF * D * Q * Q];
+                  d2 += g * bb;
+               }
+               val[f0 + fl] = vv;
+               grad[(f0 + fl) * DIM + 0] = d0;
+               grad[(f0 + fl) * DIM + 1] = d1;
+               grad[(f0 + fl) * DIM + (DIM - 1)] = d2;
+            }
+         }
+      }
+      else
+      {
+         for (int i = lt; i < NF * D * Q; i += NTE)
+         {
+            const int qx = i % Q, dy = (i / Q) % D, fl = i / (Q * D);
+            double u = 0.0, w = 0.0;
+#pragma unroll
+            for (int dx = 0; dx < D; dx++)
+            {
+               const double s = sU[dx + D * dy + ND * fl];
+               u += sB[qx + Q * dx] * s;
+               w += sG[qx + Q * dx] * s;
+            }
+            sX[i] = u;
+            sX[i + NF * D * Q] = w;
+         }
+         __syncthreads();
+#pragma unroll
+         for (int fl = 0; fl < NF; fl++)
+         {
+            if (f0 + fl < NFIELD)
+            {
+               double vv = 0.0, d0 = 0.0, d1 = 0.0;
+#pragma unroll
+               for (int dy = 0; dy < D; dy++)
+               {
+                  const int j = tx + Q * (dy + D * fl);
+                  const double vb = sX[j], vg = sX[j + NF * D * Q];
+                  vv += sB[ty + Q * dy] * vb;
+                  d0 += sB[ty + Q * dy] * vg;
+                  d1 += sG[ty + Q * dy] * vb;
+               }
+               val[f0 + fl] = vv;
+               grad[(f0 + fl) * DIM + 0] = d0;
+               grad[(f0 + fl) * DIM + 1] = d1;
+            }
+         }
+      }
+   }
+
+   // ---- L2 field (e, or rho0 for SETUP) at this point
+   double e_val = 0.0;
+   if (NEED_E)
+   {
+      __syncthreads();
+      for (int i = lt; i < NL; i += NTE) { sE[i] = a.e[(size_t)ec * NL + i]; }
+      __syncthreads();
+      if (DIM == 3)
+      {
+         double *s1 = sE + NL;         // [lz][ly][qx]
+         double *s2 = s1 + L * L * Q;  // [lz][qy][qx]
+         for (int i = lt; i < L * L * Q; i += NTE)
+         {
+            const int qx = i % Q, ly = (i / Q) % L, lz = i / (Q * L);
+            double u = 0.0;
+#pragma unroll
+            for (int lx = 0; lx < L; lx++) { u += sBl[qx + Q * lx] * sE[lx + L * (ly + L * lz)]; }
+            s1[i] = u;
+         }
+         __syncthreads();
+         for (int i = lt; i < L * Q * Q; i += NTE)
+         {
+            const int qx = i % Q, qy = (i / Q) % Q, lz = i / (Q * Q);
+            double u = 0.0;
+#pragma unroll
+            for (int ly = 0; ly < L; ly++) { u += sBl[qy + Q * ly] * s1[qx + Q * (ly + L * lz)]; }
+            s2[i] = u;
+         }
+         __syncthreads();
+#pragma unroll
+         for (int lz = 0; lz < L; lz++) { e_val += sBl[tz + Q * lz] * s2[tx + Q * (ty + Q * lz)]; }
+      }
+      else
+      {
+         double *s1 = sE + NL; // [ly][qx]
+         for (int i = lt; i < L * Q; i += NTE)
+         {
+            const int qx = i % Q, ly = i / Q;
+            double u = 0.0;
+#pragma unroll
+            for (int lx = 0; lx < L; lx++) { u += sBl[qx + Q * lx] * sE[lx + L * ly]; }
+            s1[i] = u;
+         }
+         __syncthreads();
+#pragma unroll
+         for (int ly = 0; ly < L; ly++) { e_val += sBl[ty + Q * ly] * s1[tx + Q * ly]; }
+      }
+   }
+
+   const size_t eq = (size_t)ec * NQ + lt;
+   const size_t plane = (size_t)a.NE * NQ;
+   const double weight = a.W[lt];
+
+   if (MODE == QMODE_UPDATE)
+   {
+      // grad[(c)*DIM + d] for x then v  ->  column-major J[c + DIM*d]
+      double J[DIM * DIM], dV[DIM * DIM];
+#pragma unroll
+      for (int c = 0; c < DIM; c++)
+#pragma unroll
+         for (int d = 0; d < DIM; d++)
+         {
+            J[c + DIM * d] = grad[c * DIM + d];
+            dV[c + DIM * d] = grad[(DIM + c) * DIM + d];
+         }
+      double cand = INFINITY;
+      if (active) { cand = qpoint_body<DIM>(a, e, eq, weight, J, dV, e_val, plane); }
+      const double bmin = block_min(cand, red);
+      double total;
+      if (grid_min_last_block(bmin, a.partials, a.ticket, red, total))
+      {
+         if (tid == 0) { *a.result = fmin(*a.result, total); } // q_dt_est = qdata.dt_est; Min() (:1374, :1406)
+      }
+   }
+   else if (MODE == QMODE_SETUP)
+   {
+      // Rho0DetJ0Vol: Jac0inv with the reference's index convention (:1209-1251)
+      double J[DIM * DIM];
+#pragma unroll
+      for (int c = 0; c < DIM; c++)
+#pragma unroll
+         for (int d = 0; d < DIM; d++) { J[c + DIM * d] = grad[c * DIM + d]; }
+      const double det = sm::det<DIM>(J);
+      double part = 0.0;
+      if (active)
+      {
+         double *Ji = a.Jac0inv_out + eq * DIM * DIM;
+         const double r = 1.0 / det;
+         if (DIM == 2)
+         {
+            Ji[0] = J[3] * r;
+            Ji[1] = -J[1] * r;
+            Ji[2] = -J[2] * r;
+            Ji[3] = J[0] * r;
+         }
+         else
+         {
+            // J11..J33 named as in the reference: Jab = J(q,a-1,b-1,e)
+            const double J11 = J[0], J12 = J[3], J13 = J[6];
+            const double J21 = J[1], J22 = J[4], J23 = J[7];
+            const double J31 = J[2], J32 = J[5], J33 = J[8];
+            Ji[0] = r * ((J22 * J33) - (J23 * J32));
+            Ji[1] = r * ((J32 * J13) - (J33 * J12));
+            Ji[2] = r * ((J12 * J23) - (J13 * J22));
+            Ji[3] = r * ((J23 * J31) - (J21 * J33));
+            Ji[4] = r * ((J33 * J11) - (J31 * J13));
+            Ji[5] = r * ((J13 * J21) - (J11 * J23));
+            Ji[6] = r * ((J21 * J32) - (J22 * J31));
+            Ji[7] = r * ((J31 * J12) - (J32 * J11));
+            Ji[8] = r * ((J11 * J22) - (J12 * J21));
+         }
+         a.rho0DetJ0w_out[eq] = weight * e_val * det; // e_val = rho0 grid function here
+         a.massD_out[eq] = weight * det * a.rho0_q[eq];
+         part = weight * det;
+      }
+      const double bsum = block_sum(part, red);
+      double total;
+      if (grid_sum_last_block(bsum, a.partials, a.ticket, red, total))
+      {
+         if (tid == 0) { *a.result = total; }
+      }
+   }
+   else
+   {
+      // ComputeVolumeIntegral (laghos_solver.cpp:565-639): sum_q f(q) * rho0DetJ0w
+      double part = 0.0;
+      if (active)
+      {
+         double f;
+         if (MODE == QMODE_IE) { f = e_val; }
+         else
+         {
+            f = 0.0;
+#pragma unroll
+            for (int c = 0; c < DIM; c++) { f += val[c] * val[c]; }
+         }
+         part = f * a.rho0DetJ0w_in[eq];
+      }
+      const double bsum = block_sum(part, red);
+      double total;
+      if (grid_sum_last_block(bsum, a.partials, a.ticket, red, total))
+      {
+         if (tid == 0) { *a.result = total; }
+      }
+   }
+}
+
+static int unknown_kernel(int id)
+{
+   set_error("Unknown kernel 0x%x", id);
+   return LGH_ERR_UNSUPPORTED;
+}
+
+template <int MODE> static int launch_q(lgh_ctx *c, const QArgs &a)
+{
+#define LGH_Q3(D_, Q_, L_, NF_)                                                                      \
+   hipLaunchKernelGGL((qpoint_kernel<3, D_, Q_, L_, 1, NF_, MODE>), dim3(c->NE), dim3(Q_ * Q_ * Q_), \
+                      0, c->stream, a);                                                              \
+   break
+#define LGH_Q2(D_, Q_, L_)                                                                           \
+   {                                                                                                 \
+      constexpr int NEB_ = (256 / (Q_ * Q_)) > 0 ? (256 / (Q_ * Q_)) : 1;                            \
+      hipLaunchKernelGGL((qpoint_kernel<2, D_, Q_, L_, NEB_, 2, MODE>), dim3(ceil_div(c->NE, NEB_)), \
+                         dim3(Q_ * Q_ * NEB_), 0, c->stream, a);                                     \
+   }                                                                                                 \
+   break
+   switch (c->kid)
+   {
+      // ids follow the reference table (laghos_solver.cpp:1387-1396) joined with D1D
+      case 0x222: LGH_Q2(2, 2, 1);
+      case 0x234: LGH_Q2(3, 4, 2);
+      case 0x246: LGH_Q2(4, 6, 3);
+      case 0x258: LGH_Q2(5, 8, 4);
+      case 0x26A: LGH_Q2(6, 10, 5);
+      case 0x322: LGH_Q3(2, 2, 1, 3);
+      case 0x334: LGH_Q3(3, 4, 2, 3);
+      case 0x346: LGH_Q3(4, 6, 3, 3);
+      case 0x358: LGH_Q3(5, 8, 4, 3);
+      case 0x36A: LGH_Q3(6, 10, 5, 1); // extension: not in the reference table
+      default: return unknown_kernel(c->kid);
+   }
+#undef LGH_Q3
+#undef LGH_Q2
+   LGH_HIP_CHECK(hipGetLastError());
+   return LGH_OK;
+}
+
+static QArgs q_base(lgh_ctx *c)
+{
+   QArgs a;
+   memset(&a, 0, sizeof(a));
+   a.NE = c->NE;
+   a.N = c->N;
+   a.B = c->B;
+   a.G = c->G;
+   a.Bl = c->Bl;
+   a.W = c->W;
+   a.map = c->h1map;
+   a.gamma = c->gamma;
+   a.rho0DetJ0w_in = c->rho0DetJ0w;
+   a.Jac0inv_in = c->Jac0inv;
+   a.stressJinvT = c->stressJinvT;
+   a.partials = c->partials + 2 * (size_t)c->part_stride;
+   a.ticket = c->tickets + 2;
+   a.h0 = c->h0;
+   a.h1order = c->h1order;
+   a.cfl = c->cfl;
+   a.visc = c->visc;
+   a.vort = c->vort;
+   return a;
+}
+
+int qupdate(lgh_ctx *c, const double *S)
+{
+   QArgs a = q_base(c);
+   a.x = S;
+   a.v = S + c->H1V;
+   a.e = S + 2 * (size_t)c->H1V;
+   a.result = c->dt_est_dev;
+   return launch_q<QMODE_UPDATE>(c, a);
+}
+
+int setup_rho0detj0(lgh_ctx *c, const double *x0, const double *rho0_l2, const double *rho0_q,
+                    double *volume)
+{
+   QArgs a = q_base(c);
+   a.x = x0;
+   a.e = rho0_l2;
+   a.rho0_q = rho0_q;
+   a.Jac0inv_out = c->Jac0inv;
+   a.rho0DetJ0w_out = c->rho0DetJ0w;
+   a.massD_out = c->massD;
+   a.result = c->scal;
+   int rc = launch_q<QMODE_SETUP>(c, a);
+   if (rc) { return rc; }
+   LGH_HIP_CHECK(hipMemcpyAsync(c->host_pinned, c->scal, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+   LGH_HIP_CHECK(hipStreamSynchronize(c->stream));
+   *volume = c->host_pinned[0];
+   return LGH_OK;
+}
+
+int interp_energy(lgh_ctx *c, int which, const double *vec, double *result)
+{
+   QArgs a = q_base(c);
+   a.result = c->scal;
+   int rc;
+   if (which == 0)
+   {
+      a.e = vec;
+      rc = launch_q<QMODE_IE>(c, a);
+   }
+   else
+   {
+      a.v = vec;
+      rc = launch_q<QMODE_KE>(c, a);
+   }
+   if (rc) { return rc; }
+   if (c->nranks > 1)
+   {
+      rc = allreduce_dev(c, c->scal, 1, 0);
+      if (rc) { return rc; }
+   }
+   LGH_HIP_CHECK(hipMemcpyAsync(c->host_pinned, c->scal, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+   LGH_HIP_CHECK(hipStreamSynchronize(c->stream));
+   *result = (which == 0) ? c->host_pinned[0] : 0.5 * c->host_pinned[0];
+   return LGH_OK;
+}
+
+// ---- device probes for the small-matrix kernels (tests) ----------------------
+template <int DIM>
+__global__ void test_eig_k(int n, const double *A, double *lambda, double *vec)
+{
+   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+   if (i >= n) { return; }
+   double a[DIM * DIM], v[DIM], l;
+   for (int k = 0; k < DIM * DIM; k++) { a[k] = A[(size_t)i * DIM * DIM + k]; }
+   sm::min_eigenpair<DIM>(a, l, v);
+   lambda[i] = l;
+   for (int k = 0; k < DIM; k++) { vec[(size_t)i * DIM + k] = v[k]; }
+}
+template <int DIM>
+__global__ void test_sv_k(int n, const double *A, double *sv)
+{
+   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+   if (i >= n) { return; }
+   double a[DIM * DIM];
+   for (int k = 0; k < DIM * DIM; k++) { a[k] = A[(size_t)i * DIM * DIM + k]; }
+   sv[i] = sm::min_singular<DIM>(a);
+}
+int test_eig(lgh_ctx *c, int dim, int n, const double *A, double *lambda, double *vec)
+{
+   if (dim == 2) { hipLaunchKernelGGL(test_eig_k<2>, dim3(ceil_div(n, 128)), dim3(128), 0, c->stream, n, A, lambda, vec); }
+   else { hipLaunchKernelGGL(test_eig_k<3>, dim3(ceil_div(n, 128)), dim3(128), 0, c->stream, n, A, lambda, vec); }
+   LGH_HIP_CHECK(hipGetLastError());
+   return LGH_OK;
+}
+int test_singular(lgh_ctx *c, int dim, int n, const double *A, double *sv)
+{
+   if (dim == 2) { hipLaunchKernelGGL(test_sv_k<2>, dim3(ceil_div(n, 128)), dim3(128), 0, c->stream, n, A, sv); }
+   else { hipLaunchKernelGGL(test_sv_k<3>, dim3(ceil_div(n, 128)), dim3(128), 0, c->stream, n, A, sv); }
+   LGH_HIP_CHECK(hipGetLastError());
+   return LGH_OK;
+}
+
+} // namespace lgh

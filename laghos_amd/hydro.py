@@ -1,0 +1,172 @@
+"""Python mirror of LagrangianHydroOperator + RK4 + the adaptive time loop over
+the C ABI (reference: /root/reference/laghos_solver.cpp:104-540, laghos.cpp:706-778).
+
+All numerics run in liblaghos_hip.so on the GPU; this file only sequences C-ABI
+calls (the same sequencing the C++ host layer in laghos_amd/host/ performs).
+The problem description `prob` is duck-typed: it must provide dim, NE, D1D, Q1D,
+L1D, N, H1V, L2V, h1map, B, G, Bl, W, ess, owner, order_v, use_viscosity(),
+initial_state() -> (S, rho0_l2, gamma, rho0_q).
+"""
+import numpy as np
+import torch
+
+from .context import Context
+
+H1, L2 = 0, 1
+
+
+class HydroOperator:
+    def __init__(self, prob, cfl=0.5, cg_tol=1e-8, cg_max_iter=300, device=0, comm=None):
+        self.p = prob
+        self.cg_tol, self.cg_max_iter = cg_tol, cg_max_iter
+        S, rho_l2, gamma, rho0_q = prob.initial_state()
+        multi = comm is not None and comm["nranks"] > 1
+        self.ctx = ctx = Context(prob.dim, prob.NE, prob.D1D, prob.Q1D, prob.L1D, prob.N, prob.h1map,
+                                 prob.B, prob.G, prob.Bl, prob.W, gamma, prob.ess,
+                                 owner=prob.owner if multi else None,
+                                 use_viscosity=prob.use_viscosity(), cfl=cfl, order_v=prob.order_v,
+                                 device=device)
+        self.multi = multi
+        if multi:
+            ctx.comm_init(comm["nranks"], comm["rank"], comm["unique_id"])
+            ctx.comm_set_neighbors(comm["nbr_rank"], comm["nbr_nodes"])
+        self.S0 = ctx.to_dev(S)
+        x0 = self.S0[:prob.H1V].clone()
+        vol = ctx.setup_rho0detj0(x0, ctx.to_dev(rho_l2), ctx.to_dev(rho0_q))
+        ne = float(prob.NE)
+        if multi:
+            vol = ctx.allreduce(vol, 0)
+            ne = ctx.allreduce(ne, 0)
+        self.volume = vol
+        self.h0 = (vol / ne) ** (1.0 / prob.dim) / prob.order_v   # laghos_solver.cpp:251-262
+        ctx.set_h0(self.h0)
+        # scratch (laghos_solver.cpp:158-164): one, rhs, e_rhs, B
+        self.one = torch.ones(prob.L2V, dtype=torch.float64, device=ctx.device)
+        self.rhs = ctx.zeros(prob.H1V)
+        self.e_rhs = ctx.zeros(prob.L2V)
+        self.work = ctx.zeros(prob.N)
+        self.qdata_is_current = False
+        torch.cuda.synchronize()
+
+    def close(self):
+        self.ctx.close()
+
+    def reset_time_step_estimate(self):
+        self.ctx.set_dt_est(float("inf"))
+
+    def reset_quadrature_data(self):
+        self.qdata_is_current = False
+
+    def update_quadrature_data(self, S):
+        if self.qdata_is_current:
+            return
+        self.qdata_is_current = True
+        self.ctx.qupdate(S)
+
+    def get_time_step_estimate(self, S):
+        self.update_quadrature_data(S)
+        dt = self.ctx.get_dt_est()
+        if self.multi:
+            dt = self.ctx.allreduce(dt, 1)
+        return dt
+
+    def mult(self, S, dS):
+        p, ctx = self.p, self.ctx
+        ctx.vec_copy(dS[:p.H1V], S[p.H1V:2 * p.H1V])             # dx_dt = v
+        self.update_quadrature_data(S)
+        ctx.solve_velocity(S, dS, self.one, self.rhs, self.work, self.cg_tol, self.cg_max_iter)
+        ctx.solve_energy(S, S[p.H1V:2 * p.H1V], dS, self.e_rhs, self.cg_tol, self.cg_max_iter)
+        self.qdata_is_current = False
+
+    def e_norm(self, S):
+        e = S[2 * self.p.H1V:]
+        n2 = self.ctx.vec_dot(e, e)
+        if self.multi:
+            n2 = self.ctx.allreduce(n2, 0)
+        return float(np.sqrt(n2))
+
+
+def rk4_step(hydro, S, t, dt, work):
+    """Classical RK4, the update sequence of upstream RK4Solver::Step."""
+    ctx = hydro.ctx
+    k, y, z = work
+    hydro.mult(S, k)
+    ctx.vec_axpby(y, 1.0, S, dt / 2, k)
+    ctx.vec_axpby(z, 1.0, S, dt / 6, k)
+    hydro.mult(y, k)
+    ctx.vec_axpby(y, 1.0, S, dt / 2, k)
+    ctx.vec_axpby(z, 1.0, z, dt / 3, k)
+    hydro.mult(y, k)
+    ctx.vec_axpby(y, 1.0, S, dt, k)
+    ctx.vec_axpby(z, 1.0, z, dt / 3, k)
+    hydro.mult(y, k)
+    ctx.vec_axpby(S, 1.0, z, dt / 6, k)
+    return t + dt
+
+
+class TimeLoop:
+    """laghos.cpp:706-778 as a resumable object (bench.py steps it K times)."""
+
+    def __init__(self, hydro, t_final=0.6, max_steps=-1):
+        self.h = hydro
+        self.t_final, self.max_steps = t_final, max_steps
+        self.S = hydro.S0.clone()
+        self.S_old = self.S.clone()
+        self.work = tuple(torch.empty_like(self.S) for _ in range(3))
+        torch.cuda.synchronize()  # torch-stream clones visible to the context stream
+        hydro.reset_time_step_estimate()
+        self.t = 0.0
+        self.dt = hydro.get_time_step_estimate(self.S)
+        self.ti = 1
+        self.steps = 0
+        self.repeats = 0
+        self.last_step = False
+
+    def step(self):
+        """Advance one accepted time step (repeating with smaller dt as needed).
+        Returns False when the run is finished."""
+        h = self.h
+        while True:
+            if self.last_step:
+                return False
+            if self.t + self.dt >= self.t_final:
+                self.dt = self.t_final - self.t
+                self.last_step = True
+            if self.steps == self.max_steps:
+                self.last_step = True
+            h.ctx.vec_copy(self.S_old, self.S)
+            t_old = self.t
+            h.reset_time_step_estimate()
+            self.t = rk4_step(h, self.S, self.t, self.dt, self.work)
+            self.steps += 1
+            dt_est = h.get_time_step_estimate(self.S)
+            if dt_est < self.dt:
+                self.dt *= 0.85
+                if self.dt < np.finfo(float).eps:
+                    raise RuntimeError("The time step crashed!")
+                self.t = t_old
+                h.ctx.vec_copy(self.S, self.S_old)
+                h.reset_quadrature_data()
+                self.repeats += 1
+                if self.steps < self.max_steps:
+                    self.last_step = False
+                continue
+            elif dt_est > 1.25 * self.dt:
+                self.dt *= 1.02
+            self.ti += 1
+            return True
+
+
+def run(prob, t_final=0.6, cfl=0.5, cg_tol=1e-8, cg_max_iter=300, max_steps=-1, probe_steps=(),
+        device=0, comm=None):
+    hydro = HydroOperator(prob, cfl=cfl, cg_tol=cg_tol, cg_max_iter=cg_max_iter, device=device, comm=comm)
+    loop = TimeLoop(hydro, t_final=t_final, max_steps=max_steps)
+    probes = {}
+    while loop.step():
+        done_ti = loop.ti - 1
+        if done_ti in probe_steps:
+            probes[done_ti] = hydro.e_norm(loop.S)
+    out = dict(probes=probes, steps=loop.steps, repeats=loop.repeats, ti=loop.ti - 1, t=loop.t,
+               dt=loop.dt, e_norm=hydro.e_norm(loop.S), S=loop.S.cpu().numpy(), timers=hydro.ctx.timers())
+    hydro.close()
+    return out

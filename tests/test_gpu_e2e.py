@@ -1,0 +1,123 @@
+"""GPU parity tests, end to end: the HIP path (through the C ABI) must reproduce
+the reference's golden |e| values and agree with the oracle; at BASELINE.json's
+full sizes the size-independent properties of the operators are checked."""
+import numpy as np
+import pytest
+
+from helpers import make_gpu, rel_err, seeded
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", ["chk-3D-Sedov", "chk-2D-Sedov", "chk-3D-TG", "chk-3D-p3"])
+def test_checks_table_on_gpu(golden, name):
+    """`--checks` golden values (laghos.cpp:1441-1463) through the HIP path.
+    -cgt 1e-14: the CG runs to round-off, so the GPU/CPU difference is the
+    accumulated round-off of <= 188 RK4 steps; bar 1e-10 (north_star: 1e-6)."""
+    from laghos_amd.hydro import run
+    from oracle.fem import Problem
+    g = next(c for c in golden["checks"] if c["name"] == name)
+    probes = {int(k): v for k, v in g["probes"].items()}
+    r = run(Problem(mesh=g["mesh"], rs=0, order_v=2, order_e=1, problem=g["problem"]),
+            t_final=0.6, cfl=0.5, cg_tol=1e-14, probe_steps=tuple(probes))
+    for step, ref in probes.items():
+        got = r["probes"][step]
+        assert abs(got - ref) / ref < 1e-10, (name, step, got, ref)
+
+
+def test_readme_run4_prefix_vs_oracle():
+    """3D Sedov Q2Q1 rs2 (README run 4 configuration), first 30 steps, default
+    -cgt 1e-8: HIP path vs oracle, |e| and the accepted dt sequence."""
+    from laghos_amd.hydro import run
+    from oracle.driver import run as orun
+    from oracle.fem import Problem
+    kw = dict(mesh="cube01_hex", rs=2, problem=1, blast_energy=2.0)
+    probes = (5, 10, 20, 30)
+    r = run(Problem(**kw), t_final=0.6, max_steps=30, probe_steps=probes)
+    o = orun(Problem(**kw), t_final=0.6, max_steps=30, probe_steps=probes)
+    for s in probes:
+        assert abs(r["probes"][s] - o["probes"][s]) / o["probes"][s] < 1e-7, (s, r["probes"][s], o["probes"][s])
+
+
+def test_q3q2_sedov_vs_oracle():
+    """BASELINE config shape (3D Sedov, Q3Q2) at a size the oracle finishes in
+    seconds (rs1 = 64 elements): 10 steps, state vector parity."""
+    from laghos_amd.hydro import run
+    from oracle.driver import run as orun
+    from oracle.fem import Problem
+    kw = dict(mesh="cube01_hex", rs=1, order_v=3, order_e=2, problem=1)
+    r = run(Problem(**kw), t_final=0.6, max_steps=10, cg_tol=1e-12, probe_steps=(10,))
+    o = orun(Problem(**kw), t_final=0.6, max_steps=10, cg_tol=1e-12, probe_steps=(10,))
+    assert abs(r["probes"][10] - o["probes"][10]) / o["probes"][10] < 1e-9
+    assert rel_err(r["S"], o["S"]) < 1e-8
+    assert r["steps"] == o["steps"]
+
+
+@pytest.fixture(scope="module")
+def full_size():
+    """BASELINE configs[1]: 3D Sedov cube01_hex -rs 4 -ok 3 -ot 2 (32768 elements)"""
+    from oracle.fem import Problem
+    prob = Problem(mesh="cube01_hex", rs=4, order_v=3, order_e=2, problem=1)
+    g = make_gpu(prob)
+    yield prob, g
+    g.close()
+
+
+def test_full_size_properties(full_size):
+    """Size-independent properties at the full benchmark size:
+    adjoint identity of F, symmetry and positivity of M, CG residual, mass of 1."""
+    import torch
+    prob, g = full_size
+    ctx = g.ctx
+    sJ = seeded(prob.NE * prob.NQ * 9, 31)
+    ctx.set_stressJinvT(sJ)
+    e, w = ctx.to_dev(seeded(prob.L2V, 32)), ctx.to_dev(seeded(prob.H1V, 33))
+    Fe, Ftw = ctx.empty(prob.H1V), ctx.empty(prob.L2V)
+    torch.cuda.synchronize()
+    ctx.force_mult(e, Fe)
+    ctx.force_mult_transpose(w, Ftw)
+    lhs, rhs = ctx.vec_dot(w, Fe), ctx.vec_dot(Ftw, e)
+    assert abs(lhs - rhs) <= 1e-11 * max(abs(lhs), abs(rhs))
+    # mass: symmetry x.(M y) = y.(M x); (1, M 1) = total mass = volume * rho0 = 1
+    x, y = ctx.to_dev(seeded(prob.N, 34)), ctx.to_dev(seeded(prob.N, 35))
+    Mx, My = ctx.empty(prob.N), ctx.empty(prob.N)
+    torch.cuda.synchronize()
+    ctx.mass_set_ess(-1)
+    ctx.mass_mult(0, x, Mx)
+    ctx.mass_mult(0, y, My)
+    a, b = ctx.vec_dot(y, Mx), ctx.vec_dot(x, My)
+    assert abs(a - b) <= 1e-11 * max(abs(a), abs(b))
+    one = torch.ones(prob.N, dtype=torch.float64, device=ctx.device)
+    M1 = ctx.empty(prob.N)
+    torch.cuda.synchronize()
+    ctx.mass_mult(0, one, M1)
+    assert abs(ctx.vec_dot(one, M1) - 1.0) < 1e-12
+    # CG: residual of the returned solution
+    bvec = ctx.to_dev(seeded(prob.N, 36))
+    sol = ctx.zeros(prob.N)
+    torch.cuda.synchronize()
+    it = ctx.cg_solve(0, bvec, sol, 1e-10, 300)
+    assert 0 < it < 300
+    r = ctx.empty(prob.N)
+    ctx.mass_mult(0, sol, r)
+    ctx.sync()
+    res = (r - bvec)
+    assert float(res.norm() / bvec.norm()) < 1e-8
+
+
+def test_full_size_sedov_steps(full_size):
+    """A few real Sedov steps at full size: energy conservation (the reference
+    prints 'Energy diff', laghos.cpp:956-962) and positivity of dt."""
+    import torch
+    from laghos_amd.hydro import TimeLoop
+    prob, g = full_size
+    g.reset_quadrature_data()
+    loop = TimeLoop(g, t_final=0.6, max_steps=3)
+    H1V = prob.H1V
+    e0 = g.ctx.internal_energy(loop.S[2 * H1V:]) + g.ctx.kinetic_energy(loop.S[H1V:2 * H1V])
+    while loop.step():
+        pass
+    e1 = g.ctx.internal_energy(loop.S[2 * H1V:]) + g.ctx.kinetic_energy(loop.S[H1V:2 * H1V])
+    assert loop.dt > 0 and np.isfinite(loop.dt)
+    assert abs(e1 - e0) / e0 < 1e-6
+    assert abs(e0 - 0.125) < 1e-12  # E0/2^dim (laghos.cpp:603-604)

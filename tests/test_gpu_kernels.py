@@ -1,0 +1,249 @@
+"""GPU parity tests, kernel granularity: every HIP kernel is called through the
+C ABI (liblaghos_hip.so) and compared with the CPU oracle on the same seeded
+inputs.  Tolerances: the oracle follows the reference's summation order
+(x, y, z); the HIP kernels contract z first and use the same fp64 operations
+(-ffp-contract=off), so agreement is at round-off: <= 1e-13 relative to the
+largest entry (SURVEY §8c "Tolerances to state")."""
+import numpy as np
+import pytest
+
+from helpers import deformed_state, make_gpu, make_oracle, rel_err, seeded
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-13
+
+CONFIGS = [
+    # (mesh, rs, order_v, order_e) -> kernel ids 0x234, 0x246, 0x334, 0x346, 0x358, 0x322
+    ("square01_quad", 2, 2, 1),
+    ("square01_quad", 1, 3, 2),
+    ("cube01_hex", 1, 2, 1),
+    ("cube01_hex", 1, 3, 2),
+    ("cube01_hex", 0, 4, 3),
+    ("cube01_hex", 1, 1, 0),
+    ("box01_hex", 0, 3, 2),
+]
+
+
+@pytest.fixture(scope="module", params=CONFIGS, ids=lambda c: f"{c[0]}-rs{c[1]}-Q{c[2]}Q{c[3]}")
+def pair(request):
+    from oracle.fem import Problem
+    mesh, rs, ok, ot = request.param
+    prob = Problem(mesh=mesh, rs=rs, order_v=ok, order_e=ot, problem=1)
+    g, o = make_gpu(prob), make_oracle(prob)
+    yield prob, g, o
+    g.close()
+    o.close()
+
+
+def test_setup_data(pair):
+    """Rho0DetJ0Vol + mass PA data + Jacobi diagonal (laghos_solver.cpp:1170-1261)"""
+    prob, g, o = pair
+    assert rel_err(g.ctx.rho0DetJ0w, o.rho0DetJ0w) < TOL
+    assert rel_err(g.ctx.Jac0inv, o.Jac0inv) < TOL
+    assert rel_err(g.ctx.massD, o.massD) < TOL
+    assert rel_err(g.ctx.mass_diag, o.diagV) < TOL
+    assert abs(g.volume - o.volume) / o.volume < TOL
+    assert abs(g.h0 - o.h0) / o.h0 < TOL
+
+
+def test_force_mult_E(pair):
+    import ctypes
+    prob, g, o = pair
+    nq = prob.NE * prob.NQ * prob.dim ** 2
+    sJ = seeded(nq, 1)
+    xE = seeded(prob.L2V, 2)
+    yE_o = np.empty(prob.NE * prob.ND * prob.dim)
+    from oracle.driver import _dp
+    o.L.lgo_force_mult_E(o.h, _dp(sJ), _dp(xE), _dp(yE_o))
+    yE = g.ctx.empty(yE_o.size)
+    g.ctx.force_mult_E(g.ctx.to_dev(sJ), g.ctx.to_dev(xE), yE)
+    g.ctx.sync()
+    assert rel_err(yE.cpu().numpy(), yE_o) < TOL
+
+
+def test_force_mult_transpose_E(pair):
+    prob, g, o = pair
+    from oracle.driver import _dp
+    nq = prob.NE * prob.NQ * prob.dim ** 2
+    sJ = seeded(nq, 4)
+    vE = seeded(prob.NE * prob.ND * prob.dim, 5)
+    y_o = np.empty(prob.L2V)
+    o.L.lgo_force_mult_t_E(o.h, _dp(sJ), _dp(vE), _dp(y_o))
+    y = g.ctx.empty(prob.L2V)
+    g.ctx.force_mult_transpose_E(g.ctx.to_dev(sJ), g.ctx.to_dev(vE), y)
+    g.ctx.sync()
+    assert rel_err(y.cpu().numpy(), y_o) < TOL
+
+
+def test_force_operators_L(pair):
+    """ForcePAOperator::Mult / MultTranspose at the L-vector boundary, incl. the
+    restriction transposes, and the adjoint identity w.(F e) = (F^T w).e"""
+    prob, g, o = pair
+    sJ = seeded(prob.NE * prob.NQ * prob.dim ** 2, 6)
+    o.stressJinvT[:] = sJ
+    g.ctx.set_stressJinvT(sJ)
+    e = seeded(prob.L2V, 7)
+    w = seeded(prob.H1V, 8)
+    Fe_o = o.force_mult(e)
+    Ftw_o = o.force_mult_transpose(w)
+    Fe, Ftw = g.ctx.empty(prob.H1V), g.ctx.empty(prob.L2V)
+    g.ctx.force_mult(g.ctx.to_dev(e), Fe)
+    g.ctx.force_mult_transpose(g.ctx.to_dev(w), Ftw)
+    g.ctx.sync()
+    Fe, Ftw = Fe.cpu().numpy(), Ftw.cpu().numpy()
+    assert rel_err(Fe, Fe_o) < TOL
+    assert rel_err(Ftw, Ftw_o) < TOL
+    lhs, rhs = float(w @ Fe), float(Ftw @ e)
+    assert abs(lhs - rhs) <= 1e-12 * max(abs(lhs), abs(rhs), 1.0)
+
+
+@pytest.mark.parametrize("space", [0, 1])
+def test_mass_apply_E(pair, space):
+    prob, g, o = pair
+    from oracle.driver import _dp
+    n = prob.NE * (prob.ND if space == 0 else prob.NL)
+    x = seeded(n, 9 + space)
+    y_o = np.empty(n)
+    o.L.lgo_mass_apply_E(o.h, space, _dp(x), _dp(y_o))
+    y = g.ctx.empty(n)
+    g.ctx.mass_apply_E(space, g.ctx.to_dev(x), y)
+    g.ctx.sync()
+    assert rel_err(y.cpu().numpy(), y_o) < TOL
+
+
+@pytest.mark.parametrize("comp", [-1, 0, 1])
+def test_mass_mult_L(pair, comp):
+    """MassPAOperator::Mult with essential rows (laghos_assembly.cpp:117-121)"""
+    prob, g, o = pair
+    x = seeded(prob.N, 11)
+    y_o = o.mass_mult(0, x, comp=comp)
+    y = g.ctx.empty(prob.N)
+    g.ctx.mass_set_ess(comp)
+    g.ctx.mass_mult(0, g.ctx.to_dev(x), y)
+    g.ctx.sync()
+    y = y.cpu().numpy()
+    assert rel_err(y, y_o) < TOL
+    if comp >= 0 and len(prob.ess[comp]):
+        assert np.all(y[prob.ess[comp]] == 0.0)
+
+
+def test_qupdate(pair):
+    """fused QUpdate vs the oracle's 5-pass version, on a distorted state"""
+    prob, g, o = pair
+    S = deformed_state(prob)
+    o.reset_time_step_estimate()
+    o.qdata_is_current = False
+    o.update_quadrature_data(S)
+    g.reset_time_step_estimate()
+    g.reset_quadrature_data()
+    Sd = g.ctx.to_dev(S)
+    import torch
+    torch.cuda.synchronize()
+    g.update_quadrature_data(Sd)
+    dt_g = g.ctx.get_dt_est()
+    dt_o = o.L.lgo_get_dt_est(o.h)
+    assert rel_err(g.ctx.stressJinvT, o.stressJinvT) < 1e-12
+    assert abs(dt_g - dt_o) / dt_o < 1e-12
+
+
+def test_cg_h1(pair):
+    """Jacobi-PCG on the scalar H1 mass with essential dofs vs the oracle's CG"""
+    prob, g, o = pair
+    b = seeded(prob.N, 12)
+    comp = 1
+    if len(prob.ess[comp]):
+        b[prob.ess[comp]] = 0.0
+    x_o, it_o = o.cg(0, b, comp=comp, rel_tol=1e-10, max_iter=300)
+    x = g.ctx.zeros(prob.N)
+    g.ctx.mass_set_ess(comp)
+    import torch
+    torch.cuda.synchronize()
+    it = g.ctx.cg_solve(0, g.ctx.to_dev(b), x, 1e-10, 300)
+    g.ctx.sync()
+    assert abs(it - it_o) <= 1
+    assert rel_err(x.cpu().numpy(), x_o) < 1e-8
+
+
+def test_cg_l2(pair):
+    prob, g, o = pair
+    b = seeded(prob.L2V, 13)
+    x_o, it_o = o.cg(1, b, rel_tol=1e-10, max_iter=300)
+    x = g.ctx.zeros(prob.L2V)
+    import torch
+    torch.cuda.synchronize()
+    it = g.ctx.cg_solve(1, g.ctx.to_dev(b), x, 1e-10, 300)
+    g.ctx.sync()
+    assert abs(it - it_o) <= 1
+    assert rel_err(x.cpu().numpy(), x_o) < 1e-8
+
+
+def test_hydro_mult(pair):
+    """LagrangianHydroOperator::Mult: one RHS evaluation on a distorted state"""
+    prob, g, o = pair
+    S = deformed_state(prob, seed=21)
+    o.cg_tol, g.cg_tol = 1e-14, 1e-14
+    dS_o = np.empty_like(S)
+    o.qdata_is_current = False
+    o.mult(S, dS_o)
+    import torch
+    Sd = g.ctx.to_dev(S)
+    dS = g.ctx.zeros(S.size)
+    torch.cuda.synchronize()
+    g.reset_quadrature_data()
+    g.mult(Sd, dS)
+    g.ctx.sync()
+    dS = dS.cpu().numpy()
+    H1V = prob.H1V
+    assert rel_err(dS[:H1V], dS_o[:H1V]) < TOL
+    assert rel_err(dS[H1V:2 * H1V], dS_o[H1V:2 * H1V]) < 1e-10
+    assert rel_err(dS[2 * H1V:], dS_o[2 * H1V:]) < 1e-10
+
+
+def test_energies(pair):
+    prob, g, o = pair
+    S = deformed_state(prob, seed=22)
+    ie_o, ke_o = o.internal_energy(S), o.kinetic_energy(S)
+    Sd = g.ctx.to_dev(S)
+    import torch
+    torch.cuda.synchronize()
+    ie = g.ctx.internal_energy(Sd[2 * prob.H1V:])
+    ke = g.ctx.kinetic_energy(Sd[prob.H1V:2 * prob.H1V])
+    assert abs(ie - ie_o) / abs(ie_o) < 1e-12
+    assert abs(ke - ke_o) / abs(ke_o) < 1e-12
+
+
+def test_smallmat_device():
+    """device min-eigenpair / min-singular-value vs numpy"""
+    import torch
+    from oracle.fem import Problem
+    prob = Problem(mesh="cube01_hex", rs=0, order_v=2, order_e=1, problem=1)
+    g = make_gpu(prob)
+    rng = np.random.default_rng(0)
+    n = 20000
+    A = rng.standard_normal((n, 3, 3))
+    A = 0.5 * (A + np.transpose(A, (0, 2, 1)))
+    A[::5, 1, 1] = A[::5, 0, 0]
+    A[3::11] = 0.0
+    for i in range(0, n, 7):
+        A[i] = np.diag(rng.standard_normal(3))
+    Ad = g.ctx.to_dev(np.transpose(A, (0, 2, 1)).reshape(-1))
+    lam, vec = g.ctx.empty(n), g.ctx.empty(3 * n)
+    torch.cuda.synchronize()
+    g.ctx.test_eig(3, Ad, lam, vec)
+    g.ctx.sync()
+    lam, vec = lam.cpu().numpy(), vec.cpu().numpy().reshape(n, 3)
+    w = np.linalg.eigvalsh(A)
+    scale = np.maximum(np.abs(w).max(axis=1), 1e-300)
+    scale[scale < 1e-200] = 1.0
+    assert np.max(np.abs(lam - w[:, 0]) / scale) < 1e-14
+    res = np.linalg.norm(np.einsum("nij,nj->ni", A, vec) - lam[:, None] * vec, axis=1) / scale
+    assert np.max(res) < 1e-14
+    assert np.max(np.abs(np.linalg.norm(vec, axis=1) - 1.0)) < 1e-14
+    J = rng.standard_normal((n, 3, 3))
+    sv = g.ctx.empty(n)
+    g.ctx.test_singular(3, g.ctx.to_dev(np.transpose(J, (0, 2, 1)).reshape(-1)), sv)
+    g.ctx.sync()
+    s = np.linalg.svd(J, compute_uv=False)
+    assert np.max(np.abs(sv.cpu().numpy() - s[:, 2]) / s[:, 0]) < 1e-10
+    g.close()

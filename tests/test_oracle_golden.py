@@ -1,0 +1,37 @@
+"""Pins the CPU oracle against the reference's own golden vectors:
+the `--checks` table (laghos.cpp:1441-1463) and the README / `make tests` runs
+(README.md:225-235, makefile:271-278).  No GPU, no product code."""
+import pytest
+
+from oracle.driver import run
+from oracle.fem import Problem
+
+CHECK_NAMES = ["chk-3D-Sedov", "chk-2D-Sedov", "chk-3D-TG", "chk-2D-TG", "chk-3D-p3", "chk-2D-p3"]
+
+
+@pytest.mark.parametrize("name", CHECK_NAMES)
+def test_checks_table(golden, name):
+    g = next(c for c in golden["checks"] if c["name"] == name)
+    probes = {int(k): v for k, v in g["probes"].items()}
+    # options asserted by the reference for --checks: laghos.cpp:909-917, makefile:199
+    r = run(Problem(mesh=g["mesh"], rs=0, order_v=2, order_e=1, problem=g["problem"]),
+            t_final=0.6, cfl=0.5, cg_tol=1e-14, probe_steps=tuple(probes))
+    for step, ref in probes.items():
+        got = r["probes"][step]
+        # reference bar: rel 1e-13 (laghos.cpp:1419-1429); the oracle is held to 1e-12
+        assert abs(got - ref) / ref < 1e-12, (name, step, got, ref)
+
+
+README_NAMES = ["README-1", "README-2", "README-3", "README-4", "README-6", "README-7"]
+
+
+@pytest.mark.parametrize("name", README_NAMES)
+def test_readme_runs(golden, name):
+    g = next(c for c in golden["readme"] if c["name"] == name)
+    r = run(Problem(mesh=g["mesh"], rs=g["rs"], problem=g["problem"], blast_energy=g["E0"]),
+            t_final=g["tf"])  # default -cgt 1e-8, -cfl 0.5, Q2Q1, RK4
+    last = r["last"]
+    assert last["step"] == g["step"]
+    assert f"{last['dt']:.6f}" == g["dt"]
+    # the README prints 11 significant digits: "within round-off distance" (README.md:249-250)
+    assert f"{last['e_norm']:.10e}" == f"{g['e_norm']:.10e}", (last["e_norm"], g["e_norm"])
