@@ -1,6 +1,7 @@
 // lgh_api.hip — C ABI of liblaghos_hip.so: context life cycle, vector helpers,
 // timers, and the operator-level entry points declared in include/laghos_hip.h.
 #include <cstdarg>
+#include <cstdlib>
 #include <algorithm>
 #include <limits>
 
@@ -92,7 +93,7 @@ int vec_zero_list(lgh_ctx *c, double *y, const int *list, int n)
 int vec_dot(lgh_ctx *c, const double *x, const double *y, const double *w, long n, double *dev_out)
 {
    hipLaunchKernelGGL(vec_dot_k, dim3(grid_for(n)), dim3(256), 0, c->stream, x, y, w, n,
-                      c->partials + 3 * (size_t)c->part_stride, c->tickets + 3, dev_out);
+                      c->partials + 3 * (size_t)c->part_stride, c->tickets + 3 * kTicketSlot, dev_out);
    LGH_HIP_CHECK(hipGetLastError());
    return LGH_OK;
 }
@@ -220,6 +221,15 @@ int lgh_create(const lgh_config *cfg, lgh_ctx **out)
       for (size_t i = 0; i < nmap; i++) { idx[pos[cfg->h1_map[i]]++] = (int)i; }
       LGH_TRY(dev_alloc_copy(&c->t_off, off.data(), off.size()));
       LGH_TRY(dev_alloc_copy(&c->t_idx, idx.data(), idx.size()));
+      int deg = 0;
+      for (int n = 0; n < c->N; n++) { deg = std::max(deg, off[(size_t)n + 1] - off[n]); }
+      std::vector<int> ell((size_t)deg * c->N, -1);
+      for (int n = 0; n < c->N; n++)
+         for (int k = off[n]; k < off[(size_t)n + 1]; k++) { ell[(size_t)(k - off[n]) * c->N + n] = idx[k]; }
+      c->t_deg = deg;
+      LGH_TRY(dev_alloc_copy(&c->t_ell, ell.data(), ell.size()));
+      const char *env = getenv("LGH_ATOMIC_SCATTER");
+      c->atomic_scatter = (env && env[0] == '1') ? 1 : 0;
    }
    for (int k = 0; k < 3; k++)
    {
@@ -253,9 +263,9 @@ int lgh_create(const lgh_config *cfg, lgh_ctx **out)
    LGH_TRY(dev_alloc_zero(&c->cg_d0, nv));
    LGH_TRY(dev_alloc_zero(&c->cg_d1, nv));
    LGH_TRY(dev_alloc_zero(&c->cg_y, nv));
-   c->part_stride = (int)std::max<size_t>(std::max<size_t>((size_t)c->NE, (nv + 255) / 256), 2048);
+   c->part_stride = (int)std::max<size_t>(std::max<size_t>((size_t)c->NE, (nv + 255) / 256), 2048) + (int)kShards;
    LGH_TRY(dev_alloc_zero(&c->partials, 4 * (size_t)c->part_stride));
-   LGH_TRY(dev_alloc_zero(&c->tickets, 8));
+   LGH_TRY(dev_alloc_zero(&c->tickets, 4 * (size_t)kTicketSlot));
    LGH_TRY(dev_alloc_zero(&c->cgs, 1));
    LGH_TRY(dev_alloc_zero(&c->scal, 16));
    LGH_HIP_CHECK(hipHostMalloc((void **)&c->host_pinned, 32 * sizeof(double), hipHostMallocDefault));
@@ -273,7 +283,7 @@ int lgh_destroy(lgh_ctx *c)
    if (!c) { return LGH_OK; }
    (void)hipSetDevice(c->device);
    (void)hipStreamSynchronize(c->stream);
-   void *ptrs[] = {c->B, c->G, c->Bl, c->W, c->gamma, c->h1map, c->t_off, c->t_idx, c->essmask[0],
+   void *ptrs[] = {c->B, c->G, c->Bl, c->W, c->gamma, c->h1map, c->t_off, c->t_idx, c->t_ell, c->essmask[0],
                    c->essmask[1], c->essmask[2], c->ess[0], c->ess[1], c->ess[2], c->owner,
                    c->stressJinvT, c->Jac0inv, c->rho0DetJ0w, c->massD, c->diagV, c->dinvV,
                    c->dt_est_dev, c->XE, c->YE, c->cg_r, c->cg_z, c->cg_d0, c->cg_d1, c->cg_y,

@@ -81,8 +81,11 @@ struct lgh_ctx
    double *B, *G, *Bl, *W, *gamma;
    // element restriction: gather map, and its transpose in CSR form
    int *h1map;   // NE*ND
-   int *t_off;   // N+1
+   int *t_off;   // N+1   (CSR transpose, used by the multi-component force gather)
    int *t_idx;   // NE*ND: E-vector positions (e*ND + d) contributing to node
+   int *t_ell;   // t_deg*N: the same in ELL format, [k*N + n], -1 = none
+   int t_deg;    // max contributions per node (8 for hexes, 4 for quads)
+   int atomic_scatter; // LGH_ATOMIC_SCATTER=1: f64 atomics instead of E-vector + gather
    uint8_t *essmask[3]; // N each (0/1)
    int *ess[3];
    int ess_count[3];
@@ -97,8 +100,8 @@ struct lgh_ctx
    double *YE;           // NE*ND*dim
    double *cg_r, *cg_z, *cg_d0, *cg_d1, *cg_y; // max(N, L2V)
    double *partials;     // 4 reduction slots of part_stride block partials each
-   int part_stride;      // >= max #blocks of any reducing launch
-   unsigned int *tickets;// 8 counters
+   int part_stride;      // slot size: >= max #blocks of any reducing launch + kShards
+   unsigned int *tickets;// 4 reduction slots of lgh::kTicketSlot counters (sharded tickets)
    lgh::CgScalars *cgs;  // device
    double *scal;         // small device scalar pool (16 doubles)
    double *host_pinned;  // pinned host staging (16 doubles)
@@ -112,16 +115,27 @@ namespace lgh
 {
 
 // ---- wave / block reductions (wave64 shuffles) ------------------------------
-__device__ __forceinline__ double wave_sum(double v)
+// Workgroups here are Q*Q*NEB threads, not always a multiple of 64, so the last
+// wave may be partial: a shuffle from a lane beyond `nact` (the number of live
+// lanes of this wave) returns garbage and must not be folded in.
+__device__ __forceinline__ double wave_sum(double v, const int lane, const int nact)
 {
 #pragma unroll
-   for (int off = 32; off > 0; off >>= 1) { v += __shfl_down(v, off, 64); }
+   for (int off = 32; off > 0; off >>= 1)
+   {
+      const double o = __shfl_down(v, off, 64);
+      if (lane + off < nact) { v += o; }
+   }
    return v;
 }
-__device__ __forceinline__ double wave_min(double v)
+__device__ __forceinline__ double wave_min(double v, const int lane, const int nact)
 {
 #pragma unroll
-   for (int off = 32; off > 0; off >>= 1) { v = fmin(v, __shfl_down(v, off, 64)); }
+   for (int off = 32; off > 0; off >>= 1)
+   {
+      const double o = __shfl_down(v, off, 64);
+      if (lane + off < nact) { v = fmin(v, o); }
+   }
    return v;
 }
 
@@ -131,7 +145,8 @@ __device__ __forceinline__ double block_sum(double v, double *red)
    const int tid = threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z);
    const int nthr = blockDim.x * blockDim.y * blockDim.z;
    const int lane = tid & 63, wid = tid >> 6, nw = (nthr + 63) >> 6;
-   v = wave_sum(v);
+   const int nact = min(64, nthr - (wid << 6));
+   v = wave_sum(v, lane, nact);
    __syncthreads();
    if (lane == 0) { red[wid] = v; }
    __syncthreads();
@@ -147,7 +162,8 @@ __device__ __forceinline__ double block_min(double v, double *red)
    const int tid = threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z);
    const int nthr = blockDim.x * blockDim.y * blockDim.z;
    const int lane = tid & 63, wid = tid >> 6, nw = (nthr + 63) >> 6;
-   v = wave_min(v);
+   const int nact = min(64, nthr - (wid << 6));
+   v = wave_min(v, lane, nact);
    __syncthreads();
    if (lane == 0) { red[wid] = v; }
    __syncthreads();
@@ -160,40 +176,97 @@ __device__ __forceinline__ double block_min(double v, double *red)
    return s;
 }
 
-// Deterministic grid-wide sum without a second launch: every block publishes its
-// partial with an agent-scope (write-through) atomic store, drains, takes a
-// ticket; the last block re-reads all partials with agent-scope loads in block
-// order.  Both sides use 8-byte agent atomics (MI355X guide, Guideline 16), so no
-// L2 write-back fence is needed.  Returns true in ALL threads of the last block;
-// `total` is then valid in thread 0 of that block.  The ticket counter is reset
-// by the last block, so the slot is reusable by the next launch on the stream.
-__device__ __forceinline__ bool grid_sum_last_block(double block_partial /* thread 0 */,
-                                                    double *partials, unsigned int *ticket,
-                                                    double *red, double &total)
+// ---- deterministic grid-wide reductions without a second launch -----------------
+// Every block publishes its partial with an agent-scope (write-through) atomic
+// store, drains, and takes a ticket; the last block to arrive re-reads all
+// partials with agent-scope loads in block order (fixed summation tree ->
+// bit-reproducible).  Both sides use 8-byte agent atomics (MI355X guide,
+// Guideline 16), so no L2 write-back fence is needed.
+//
+// One device-scope counter serialises at ~12 ns per arrival (guide: "fanin"), so
+// thousands of blocks on ONE counter cost tens of microseconds - measured here as
+// the whole duration of the first CG kernels.  The ticket is therefore sharded:
+// block b arrives on shard b % kShards (one cache line each); the last arriver of
+// a shard arrives on the top counter; the last of those owns the final fold.
+// Counters are reset by their last arrivers, so a slot is reusable by the next
+// launch on the stream.
+constexpr unsigned kShards = 64;
+constexpr unsigned kTicketStride = 32;                               // uints: 128 B apart
+constexpr unsigned kTicketSlot = (kShards + 1) * kTicketStride;      // uints per reduction slot
+
+// Returns true in ALL threads of the globally last block; `total` is then valid in
+// thread 0.  `partials` must hold gridsize + kShards doubles: block partials, then
+// (at offset `shard_off`) one folded partial per shard.  Fold order is fixed:
+// shard s folds blocks s, s+kShards, ... through the block tree, the last block
+// folds the shard sums in shard order -> bit-reproducible, and the serial tail
+// after the last arrival is two memory round trips, not gridsize/blocksize.
+template <bool IS_MIN>
+__device__ __forceinline__ bool grid_reduce_last_block(double block_partial /* thread 0 */,
+                                                       double *partials, const unsigned shard_off,
+                                                       unsigned int *ticket, double *red, double &total)
 {
    const int tid = threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z);
    const int nthr = blockDim.x * blockDim.y * blockDim.z;
    const unsigned int nblk = gridDim.x * gridDim.y * gridDim.z;
    const unsigned int bid = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-   __shared__ unsigned int s_last;
+   const unsigned s = bid % kShards;
+   const unsigned cnt = nblk / kShards + ((s < nblk % kShards) ? 1u : 0u);
+   const unsigned nsh = nblk < kShards ? nblk : kShards;
+   unsigned int *t1 = ticket + s * kTicketStride;
+   unsigned int *t2 = ticket + kShards * kTicketStride;
+   const double ident = IS_MIN ? INFINITY : 0.0;
+   __shared__ unsigned int s_flag;
    if (tid == 0)
    {
       __hip_atomic_store(&partials[bid], block_partial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      s_last = (t == nblk - 1) ? 1u : 0u;
+      const unsigned a = __hip_atomic_fetch_add(t1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_flag = (a == cnt - 1) ? 1u : 0u;
    }
    __syncthreads();
-   if (!s_last) { return false; }
-   // fixed-order tree: thread t sums partials t, t+nthr, ...; then block_sum
-   double s = 0.0;
-   for (unsigned int i = tid; i < nblk; i += nthr)
+   if (!s_flag) { return false; }
+   // last arriver of shard s: fold the shard's block partials
+   double v = ident;
+   for (unsigned int i = tid; i < cnt; i += nthr)
    {
-      s += __hip_atomic_load(&partials[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const double p = __hip_atomic_load(&partials[s + kShards * i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      v = IS_MIN ? fmin(v, p) : v + p;
    }
-   total = block_sum(s, red);
-   if (tid == 0) { __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+   const double ssum = IS_MIN ? block_min(v, red) : block_sum(v, red);
+   __syncthreads();
+   if (tid == 0)
+   {
+      __hip_atomic_store(&partials[shard_off + s], ssum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(t1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned b = __hip_atomic_fetch_add(t2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_flag = (b == nsh - 1) ? 1u : 0u;
+      if (s_flag) { __hip_atomic_store(t2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+   }
+   __syncthreads();
+   if (!s_flag) { return false; }
+   v = ident;
+   for (unsigned int i = tid; i < nsh; i += nthr)
+   {
+      const double p = __hip_atomic_load(&partials[shard_off + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      v = IS_MIN ? fmin(v, p) : v + p;
+   }
+   total = IS_MIN ? block_min(v, red) : block_sum(v, red);
    return true;
+}
+// The shard sums live right after the block partials of a slot: every reduction
+// slot of the context is part_stride + kShards doubles (lgh_create).
+__device__ __forceinline__ bool grid_sum_last_block(double bp, double *partials, unsigned int *ticket,
+                                                    double *red, double &total)
+{
+   const unsigned nblk = gridDim.x * gridDim.y * gridDim.z;
+   return grid_reduce_last_block<false>(bp, partials, nblk, ticket, red, total);
+}
+__device__ __forceinline__ bool grid_min_last_block(double bp, double *partials, unsigned int *ticket,
+                                                    double *red, double &total)
+{
+   const unsigned nblk = gridDim.x * gridDim.y * gridDim.z;
+   return grid_reduce_last_block<true>(bp, partials, nblk, ticket, red, total);
 }
 
 // block index -> work chunk so that blocks resident on one XCD (observed:

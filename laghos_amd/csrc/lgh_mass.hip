@@ -8,16 +8,18 @@
 // instances configured at laghos_solver.cpp:264-284 (algorithm: SURVEY §3.2).
 //
 // MI355X design: one CG iteration is two kernels and no host round trip.
-//   K1 (element batches): beta = rz/rz_prev; d = z + beta*d fused into the
-//       gather (ping-pong direction buffers, so elements sharing a node never
-//       see a half-updated value); y_e = B^T D B d_e with the z contraction in
+//   K1 (element batches): beta = rz/rz_prev; the new direction d = z + beta*d is
+//       formed on the fly inside the gather (not stored: elements sharing a node
+//       all read the old z, d); y_e = B^T D B d_e with the z contraction in
 //       registers and tables in SGPRs; den = sum_e d_e.y_e (the E-vector form of
 //       (d, A d), so no extra pass over the L-vector is needed).
-//   K2 (nodes): z = sum of element contributions (deterministic CSR gather, no
-//       atomics), essential rows zeroed, alpha = rz/den, x += alpha d,
-//       r -= alpha z, z = r/diag, betanom = (r,z) with a wave64 shuffle
-//       reduction; the last block to finish folds the block partials in fixed
-//       order, updates the device scalars and the convergence flag.
+//   K2 (nodes): forms the same d = z + beta*d in place (one thread per node, no
+//       race), z = sum of element contributions (deterministic gather over an
+//       ELL-format transpose, coalesced index loads, no atomics), essential rows
+//       zeroed, alpha = rz/den, x += alpha d, r -= alpha z, z = r/diag,
+//       betanom = (r,z) with a wave64 shuffle reduction; the last block to
+//       finish folds the block partials in fixed order, updates the device
+//       scalars and the convergence flag.
 // The host only enqueues iterations in chunks and looks at the flag between
 // chunks; once `done` is set the remaining kernels of a chunk exit immediately.
 #include "lgh_common.hpp"
@@ -29,8 +31,8 @@ namespace lgh
 // element kernel: y_e = B^T diag(D_e) B x_e
 //   MODE 0: x is an E-vector (or L2 vector), plain apply
 //   MODE 1: x gathered from an L-vector through `map`
-//   MODE 2: CG K1 (H1): d_new = z[map] + beta * d_old[map]; write d_new; den
-//   MODE 3: CG K1 (L2, no map): d_new = r + beta*d_old (element-local vectors)
+//   MODE 2: CG K1 (H1): d = z[map] + beta * d_old[map] (not stored); den
+//   MODE 3: CG K1 (L2, no map): d = r + beta*d_old, stored in place (element-local)
 // ---------------------------------------------------------------------------
 struct MassArgs
 {
@@ -41,8 +43,8 @@ struct MassArgs
    const int *map;    // NE*ND or null
    double *y;         // E-vector (H1) or L2 vector output
    // CG
-   const double *d_old;
-   double *d_new;
+   double *d;         // direction vector (read; MODE 3 also writes it in place)
+   double *yL;        // atomic-scatter variant: L-vector accumulated with f64 atomics
    CgScalars *cgs;
    double *partials;
    unsigned int *ticket;
@@ -72,10 +74,12 @@ mass_apply_3d(const MassArgs a)
    double *sA = sX + SX;
 
    double beta = 0.0;
+   bool first = false;
    if (MODE >= 2)
    {
       if (a.cgs->done) { return; }
-      beta = a.cgs->first ? 0.0 : a.cgs->rz / a.cgs->rz_prev;
+      first = a.cgs->first != 0;
+      beta = first ? 0.0 : a.cgs->rz / a.cgs->rz_prev;
    }
 
    // ---- cooperative load of the block's element dofs
@@ -92,13 +96,14 @@ mass_apply_3d(const MassArgs a)
          else if (MODE == 2)
          {
             const int n = a.map[p];
-            val = a.x[n] + beta * a.d_old[n];
-            a.d_new[n] = val; // every element sharing n writes the same value
+            val = a.x[n]; // K2 stores the same value later
+            if (!first) { val += beta * a.d[n]; }
          }
          else
          {
-            val = a.x[p] + beta * a.d_old[p];
-            a.d_new[p] = val;
+            val = a.x[p];
+            if (!first) { val += beta * a.d[p]; }
+            a.d[p] = val;
          }
          smem[el * PER + d] = val;
       }
@@ -209,7 +214,9 @@ mass_apply_3d(const MassArgs a)
          double u = 0.0;
 #pragma unroll
          for (int qy = 0; qy < Q; qy++) { u += brow[qy] * sA[tx + D * (qy + Q * dz)]; }
-         a.y[tx + D * (ty + D * dz) + (size_t)ND * e] = u;
+         const size_t po = tx + D * (ty + D * dz) + (size_t)ND * e;
+         if (MODE == 2 && a.yL) { unsafeAtomicAdd(&a.yL[a.map[po]], u); }
+         else { a.y[po] = u; }
          if (MODE >= 2) { dot += xcol[dz] * u; }
       }
    }
@@ -247,10 +254,12 @@ mass_apply_2d(const MassArgs a)
    double *sA = sX + ND;         // [dy][qx] / [qy][dx]
    double *sQ = sA + D * Q;      // [qy][qx]
    double beta = 0.0;
+   bool first = false;
    if (MODE >= 2)
    {
       if (a.cgs->done) { return; }
-      beta = a.cgs->first ? 0.0 : a.cgs->rz / a.cgs->rz_prev;
+      first = a.cgs->first != 0;
+      beta = first ? 0.0 : a.cgs->rz / a.cgs->rz_prev;
    }
    {
       const int nthr = Q * Q * NEB;
@@ -265,13 +274,14 @@ mass_apply_2d(const MassArgs a)
          else if (MODE == 2)
          {
             const int n = a.map[p];
-            val = a.x[n] + beta * a.d_old[n];
-            a.d_new[n] = val;
+            val = a.x[n];
+            if (!first) { val += beta * a.d[n]; }
          }
          else
          {
-            val = a.x[p] + beta * a.d_old[p];
-            a.d_new[p] = val;
+            val = a.x[p];
+            if (!first) { val += beta * a.d[p]; }
+            a.d[p] = val;
          }
          smem[el * PER + d] = val;
       }
@@ -302,7 +312,9 @@ mass_apply_2d(const MassArgs a)
    {
       double u = 0.0;
       for (int qy = 0; qy < Q; qy++) { u += a.B[qy + Q * ty] * sA[tx + D * qy]; }
-      a.y[tx + D * ty + (size_t)ND * e] = u;
+      const size_t po = tx + D * ty + (size_t)ND * e;
+      if (MODE == 2 && a.yL) { unsafeAtomicAdd(&a.yL[a.map[po]], u); }
+      else { a.y[po] = u; }
       if (MODE >= 2) { dot = sX[tx + D * ty] * u; }
    }
    if (MODE >= 2)
@@ -389,14 +401,28 @@ int mass_apply_E(lgh_ctx *c, int space, const double *xE, double *yE)
 
 // ---- node kernels -----------------------------------------------------------
 // y[n] = sum of element contributions; optional essential-row elimination.
+// ELL transpose: t_ell[k*N + n] = E-vector position of the k-th contribution to
+// node n (ascending element order), -1 when the node has fewer than k+1.
+__device__ __forceinline__ double ell_gather(const int n, const int N, const int deg,
+                                             const int *__restrict__ ell, const double *__restrict__ YE)
+{
+   double s = 0.0;
+#pragma unroll 8
+   for (int k = 0; k < deg; k++)
+   {
+      const int p = ell[(size_t)k * N + n];
+      if (p >= 0) { s += YE[p]; }
+   }
+   return s;
+}
+
 __global__ void __launch_bounds__(256)
-mass_gather_k(const int N, const int ND, const int *__restrict__ off, const int *__restrict__ idx,
+mass_gather_k(const int N, const int deg, const int *__restrict__ ell,
               const double *__restrict__ YE, const uint8_t *__restrict__ ess, double *__restrict__ y)
 {
    const int n = blockIdx.x * blockDim.x + threadIdx.x;
    if (n >= N) { return; }
-   double s = 0.0;
-   for (int k = off[n]; k < off[n + 1]; k++) { s += YE[idx[k]]; }
+   double s = ell_gather(n, N, deg, ell, YE);
    if (ess && ess[n]) { s = 0.0; }
    y[n] = s;
 }
@@ -412,7 +438,7 @@ int mass_apply_h1(lgh_ctx *c, const double *x, double *y, bool eliminate)
    const bool multi = (c->nranks > 1);
    const uint8_t *ess = (eliminate && c->cur_ess >= 0 && !multi) ? c->essmask[c->cur_ess] : nullptr;
    hipLaunchKernelGGL(mass_gather_k, dim3(ceil_div(c->N, 256)), dim3(256), 0, c->stream, c->N,
-                      c->ND, c->t_off, c->t_idx, c->YE, ess, y);
+                      c->t_deg, c->t_ell, c->YE, ess, y);
    LGH_HIP_CHECK(hipGetLastError());
    if (multi)
    {
@@ -492,7 +518,7 @@ int mass_assemble_diag(lgh_ctx *c)
    }
    LGH_HIP_CHECK(hipGetLastError());
    hipLaunchKernelGGL(mass_gather_k, dim3(ceil_div(c->N, 256)), dim3(256), 0, c->stream, c->N,
-                      c->ND, c->t_off, c->t_idx, c->YE, (const uint8_t *)nullptr, c->diagV);
+                      c->t_deg, c->t_ell, c->YE, (const uint8_t *)nullptr, c->diagV);
    LGH_HIP_CHECK(hipGetLastError());
    if (c->nranks > 1)
    {
@@ -511,15 +537,17 @@ int mass_assemble_diag(lgh_ctx *c)
 struct CgVecArgs
 {
    int n;              // N (H1) or L2V
-   const int *off;     // H1 fused gather (null: y already an L-vector)
-   const int *idx;
+   const int *ell;     // H1 fused gather (ELL transpose; null: y already an L-vector)
+   int deg;
    const double *YE;   // E-vector from K1 (H1) ...
-   const double *yL;   // ... or the operator result as an L-vector (L2, multi-GPU H1)
+   double *yL;         // ... or the operator result as an L-vector (L2, multi-GPU H1, atomics)
+   int zero_yL;        // atomic-scatter variant: reset yL[n] after consuming it
+   int d_in_place;     // 1: d already holds the new direction (L2); 0: form z + beta d here
    const uint8_t *ess; // essential mask or null
    const double *dinv; // Jacobi (null: no preconditioner)
    const double *owner;// ownership weights or null
    const double *b;
-   const double *d;
+   double *d;
    double *x, *r, *z;
    CgScalars *cgs;
    double *partials;
@@ -588,19 +616,30 @@ cg_update_k(const CgVecArgs a)
    __shared__ double red[16];
    if (a.cgs->done) { return; }
    const double alpha = a.cgs->rz / a.cgs->den;
+   // `first` was cleared by K1 of this iteration: iteration 1 is recognised by iter
+   const double beta = (a.iter == 1) ? 0.0 : a.cgs->rz / a.cgs->rz_prev;
    const int n = blockIdx.x * blockDim.x + threadIdx.x;
    double part = 0.0;
    if (n < a.n)
    {
       double zv;
-      if (FUSED_GATHER)
+      if (FUSED_GATHER) { zv = ell_gather(n, a.n, a.deg, a.ell, a.YE); }
+      else
       {
-         zv = 0.0;
-         for (int k = a.off[n]; k < a.off[n + 1]; k++) { zv += a.YE[a.idx[k]]; }
+         zv = a.yL[n];
+         if (a.zero_yL) { a.yL[n] = 0.0; }
       }
-      else { zv = a.yL[n]; }
       if (a.ess && a.ess[n]) { zv = 0.0; }
-      const double xv = a.x[n] + alpha * a.d[n];
+      double dv;
+      if (a.d_in_place) { dv = a.d[n]; }
+      else
+      {
+         // same expression as K1's gather: d = z_old + beta * d_old
+         dv = (a.dinv ? a.z[n] : a.r[n]);
+         if (a.iter != 1) { dv += beta * a.d[n]; }
+         a.d[n] = dv;
+      }
+      const double xv = a.x[n] + alpha * dv;
       const double rv = a.r[n] - alpha * zv;
       a.x[n] = xv;
       a.r[n] = rv;
@@ -701,10 +740,19 @@ int cg_solve(lgh_ctx *c, int space, const double *b, double *x, double rel_tol, 
    m.y = h1 ? c->YE : c->cg_y;
    m.cgs = c->cgs;
    m.partials = c->partials + c->part_stride;
-   m.ticket = c->tickets + 1;
+   m.ticket = c->tickets + 1 * kTicketSlot;
    m.multi = multi ? 1 : 0;
 
-   double *dbuf[2] = {c->cg_d0, c->cg_d1};
+   const bool atomic = h1 && !multi && c->atomic_scatter;
+   m.d = c->cg_d0;
+   v.d = c->cg_d0;
+   v.d_in_place = h1 ? 0 : 1;
+   if (atomic)
+   {
+      m.yL = c->cg_y;
+      rc = vec_set(c, c->cg_y, 0.0, n);
+      if (rc) { return rc; }
+   }
    int it = 0;
    CgScalars *hs = (CgScalars *)c->host_pinned;
    // chunk = iterations enqueued between two looks at the convergence flag
@@ -719,17 +767,20 @@ int cg_solve(lgh_ctx *c, int space, const double *b, double *x, double rel_tol, 
       for (; it < upto;)
       {
          ++it;
-         m.d_old = dbuf[(it - 1) & 1];
-         m.d_new = dbuf[it & 1];
          rc = h1 ? launch_mass<2>(c, space, m) : launch_mass<3>(c, space, m);
          if (rc) { return rc; }
-         v.d = m.d_new;
          v.iter = it;
          v.ess = ess;
-         if (h1 && !multi)
+         if (atomic)
          {
-            v.off = c->t_off;
-            v.idx = c->t_idx;
+            v.yL = c->cg_y;
+            v.zero_yL = 1;
+            hipLaunchKernelGGL(cg_update_k<false>, dim3(nb), dim3(256), 0, c->stream, v);
+         }
+         else if (h1 && !multi)
+         {
+            v.ell = c->t_ell;
+            v.deg = c->t_deg;
             v.YE = c->YE;
             hipLaunchKernelGGL(cg_update_k<true>, dim3(nb), dim3(256), 0, c->stream, v);
          }
@@ -738,8 +789,8 @@ int cg_solve(lgh_ctx *c, int space, const double *b, double *x, double rel_tol, 
             if (h1)
             {
                // multi-GPU: assemble the L-vector, sum shared nodes, reduce den
-               hipLaunchKernelGGL(mass_gather_k, dim3(nb), dim3(256), 0, c->stream, c->N, c->ND,
-                                  c->t_off, c->t_idx, c->YE, (const uint8_t *)nullptr, c->cg_y);
+               hipLaunchKernelGGL(mass_gather_k, dim3(nb), dim3(256), 0, c->stream, c->N, c->t_deg,
+                                  c->t_ell, c->YE, (const uint8_t *)nullptr, c->cg_y);
                rc = halo_sum(c, c->cg_y, 1);
                if (rc) { return rc; }
             }

@@ -52,32 +52,6 @@ __device__ __forceinline__ double smooth_step_01(double x, double eps)
    return (3.0 - 2.0 * y) * y * y;
 }
 
-__device__ __forceinline__ bool grid_min_last_block(double block_partial, double *partials,
-                                                    unsigned int *ticket, double *red, double &total)
-{
-   const int tid = threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z);
-   const int nthr = blockDim.x * blockDim.y * blockDim.z;
-   const unsigned int nblk = gridDim.x;
-   __shared__ unsigned int s_last;
-   if (tid == 0)
-   {
-      __hip_atomic_store(&partials[blockIdx.x], block_partial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      s_last = (t == nblk - 1) ? 1u : 0u;
-   }
-   __syncthreads();
-   if (!s_last) { return false; }
-   double s = INFINITY;
-   for (unsigned int i = tid; i < nblk; i += nthr)
-   {
-      s = fmin(s, __hip_atomic_load(&partials[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-   }
-   total = block_min(s, red);
-   if (tid == 0) { __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-   return true;
-}
-
 // The point-wise body: QUpdateBody (laghos_solver.cpp:1042-1168).  J and dV are
 // column-major [c + DIM*d] = d u_c / d xi_d.  Returns this point's dt candidate.
 template <int DIM>
@@ -515,7 +489,7 @@ static QArgs q_base(lgh_ctx *c)
    a.Jac0inv_in = c->Jac0inv;
    a.stressJinvT = c->stressJinvT;
    a.partials = c->partials + 2 * (size_t)c->part_stride;
-   a.ticket = c->tickets + 2;
+   a.ticket = c->tickets + 2 * kTicketSlot;
    a.h0 = c->h0;
    a.h1order = c->h1order;
    a.cfl = c->cfl;

