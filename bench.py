@@ -1,0 +1,253 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the MI355X Laghos partial-assembly hot path.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" is one accepted RK4 time step of 3D Sedov Q3/Q2 (-p 1 -ok 3 -ot 2 -pa):
+5 quadrature-data updates, 4 Force Mult, 4 Force MultTranspose, 12 H1 PCG solves
+and 4 L2 CG solves, all in liblaghos_hip.so through the C++ host layer.  At N=1
+the workload is BASELINE.json configs[1] (cube01_hex -rs 4: 32^3 elements); for
+N>1 every rank keeps a 32^3 block (weak scaling, element-sharded, RCCL for the
+shared-node sums and the CG dot products), N=8 is configs[3] (64^3 elements).
+
+Prints ONE JSON line on rank 0.  `value` = 1e-6 * (H1 + L2 global dofs) * RK
+stages executed / wall time of the K timed steps (the reference's FOM0 with the
+whole-step wall time in the denominator; laghos_solver.cpp:727, laghos.cpp:928-935).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def block_grid(n):
+    """ranks -> (px,py,pz) of 32^3-element blocks (same rule as laghos::Partition)"""
+    p = [1, 1, 1]
+    left, a = n, 0
+    while left > 1:
+        f = 2
+        while left % f:
+            f += 1
+        p[a % 3] *= f
+        left //= f
+        a += 1
+    return p
+
+
+def usable_cpus():
+    """CPUs this process may really use: affinity mask capped by the cgroup quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
+def cpu_baseline(threads):
+    """The oracle (CPU restatement of the reference -pa path) timed on the host
+    cores on a bounded sample of the same 32^3 Q3/Q2 Sedov workload: RK stages of
+    the first RK4 step from t=0 (each stage = 1 QUpdate, 1 Force, 1 ForceT, 3 H1
+    PCG, 1 L2 CG), as many of the 4 as fit in ~20 s.  Reported next to the GPU
+    number; never the thing shipped."""
+    import numpy as np
+    from oracle.driver import Hydro, lib
+    from oracle.fem import Problem
+    lib().lgo_set_num_threads(threads)
+    prob = Problem(mesh="cube01_hex", rs=4, order_v=3, order_e=2, problem=1)
+    h = Hydro(prob)
+    S = h.S0.copy()
+    k, y = np.empty_like(S), np.empty_like(S)
+    h.reset_time_step_estimate()
+    dt = h.get_time_step_estimate(S)
+    stages, wall = 0, 0.0
+    y[:] = S
+    for c in (0.5, 0.5, 1.0, None):  # the RK4 stage states (upstream RK4Solver)
+        t0 = time.time()
+        h.mult(y, k)
+        wall += time.time() - t0
+        stages += 1
+        if c is None or wall > 20.0:
+            break
+        np.add(S, (c * dt) * k, out=y)
+    dofs = prob.dim * prob.N + prob.L2V
+    tm = h.timers()
+    h.close()
+    return dict(value=1e-6 * dofs * stages / wall, unit="Mdofs*steps/s", cores=threads, kind="port",
+                sample="%d RK stage(s) of the first RK4 step of the same 3D Sedov Q3Q2 32^3 problem "
+                       "(oracle/ C++, OpenMP %d threads), %.1f s" % (stages, threads, wall),
+                seconds=wall, stages=stages, h1_cg_iters=tm["H1iter"])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    from laghos_amd import _lib, host_lib
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % a.gpus)
+        a.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X GPU (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    nccl_id = None
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+        buf = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            cid = ctypes.create_string_buffer(128)
+            _lib.check(_lib.load().lgh_comm_unique_id(cid))
+            buf.copy_(torch.tensor(list(cid.raw), dtype=torch.uint8))
+        dist.broadcast(buf, 0)
+        nccl_id = bytes(buf.cpu().tolist())
+
+    px, py, pz = block_grid(world)
+    if world == 1:
+        args = ["-m", "data/cube01_hex.mesh", "-rs", 4]
+        workload = "3D Sedov -p 1 -m cube01_hex -rs 4 -ok 3 -ot 2 -pa (32^3 elements, E0/2^dim = 0.125)"
+    else:
+        args = ["-dim", 3, "-nx", 32 * px, "-ny", 32 * py, "-nz", 32 * pz, "-Sx", px, "-Sy", py, "-Sz", pz,
+                "-rs", 0]
+        workload = ("3D Sedov -p 1 Cartesian %dx%dx%d elements (32^3 per GPU, h = 1/32), -ok 3 -ot 2 -pa"
+                    % (32 * px, 32 * py, 32 * pz))
+    args += ["-p", 1, "-ok", 3, "-ot", 2, "-pa", "-tf", 1e9, "-ms", a.warmup + a.steps + 64, "-vs", 10 ** 9,
+             "-dev", local_rank, "-q"]
+    sim = host_lib.Sim(args, nranks=world, rank=rank, nccl_id=nccl_id)
+    sim.enable_timers(False)  # region stopwatches synchronise; keep them out of the timed loop
+    sz = sim.sizes()
+
+    def barrier():
+        sim.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        sim.step()
+    barrier()
+    rk0 = sim.rk_steps
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        sim.step()
+    barrier()
+    wall = time.perf_counter() - t0
+    if dist is not None:
+        w = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        dist.all_reduce(w, op=dist.ReduceOp.MAX)
+        wall = float(w.item())
+    rk_steps = sim.rk_steps - rk0
+    dofs = sz["H1GTV"] + sz["L2GTV"]
+    value = 1e-6 * dofs * 4 * rk_steps / wall
+
+    out = {
+        "metric": "Mdofs*steps/s on 3D Sedov -pa (Q3/Q2)", "value": value, "unit": "Mdofs*steps/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * wall / a.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": workload, "elements": sz["global_NE"], "h1_dofs": sz["H1GTV"],
+                   "l2_dofs": sz["L2GTV"], "quad_points_per_element": sz["NQ"], "rk_stages_executed": 4 * rk_steps,
+                   "ode": "RK4", "cg_rel_tol": 1e-8, "parallelism": "elements%dx%dx%d" % (px, py, pz),
+                   "e_norm": sim.e_norm(), "t": sim.t, "dt": sim.dt},
+    }
+
+    # ---- per-region FOMs (reference formulas, laghos_solver.cpp:722-727) and the
+    # roofline of the dominant kernel: extra steps AFTER the timed region so the
+    # stopwatch synchronisations / event records do not perturb `value`.
+    if not a.no_roofline:
+        L = _lib.load()
+        ctx = sim.L.laghos_sim_context(sim.h)
+        sim.enable_timers(True)
+        sim.reset_timers()
+        r0 = sim.rk_steps
+        sim.step()
+        sim.step()
+        sim.sync()
+        tm = sim.timers()
+        n_rk = sim.rk_steps - r0
+        dim = sz["dim"]
+        if tm["cgH1"] > 0 and world == 1:
+            out["fom"] = {
+                "FOM1_cgH1": 1e-6 * sz["H1GTV"] * (tm["H1iter"] / dim) / tm["cgH1"],
+                "FOM2_forces": 1e-6 * 4 * n_rk * dofs / tm["force"],
+                "FOM3_qdata": 1e-6 * tm["quad_tstep"] * sz["NQ"] / tm["qdata"],
+                "h1_cg_iters_per_solve": tm["H1iter"] / (4.0 * n_rk * dim),
+                "seconds": {k: tm[k] for k in ("cgH1", "cgL2", "force", "qdata")},
+            }
+        sim.enable_timers(False)
+        # algorithmic bytes per element, fp64 (SURVEY §8d / DESIGN.md "Roofline accounting")
+        D, Q, Ld = sz["D1D"], sz["Q1D"], sz["L1D"]
+        NQ, ND, NL = sz["NQ"], D ** dim, Ld ** dim
+        bytes_per_elem = {
+            _lib_id: b for _lib_id, b in (
+                (0, 8 * (NQ + 2 * ND)),                              # mass apply (scalar H1): D + in + out
+                (2, 8 * (2 * dim * ND + NL + dim * dim * NQ + NQ + dim * dim * NQ) + 8),  # fused QUpdate
+                (3, 8 * (dim * dim * NQ + NL + dim * ND)),            # ForceMult
+                (4, 8 * (dim * dim * NQ + NL + dim * ND)),            # ForceMultTranspose
+            )}
+        names = {0: "mass_apply_3d<MODE 2> (H1 CG K1)", 2: "qpoint_kernel (fused QUpdate)",
+                 3: "force_mult_3d", 4: "force_mult_t_3d"}
+        kern = {}
+        for kid in (0, 2, 3, 4):
+            _lib.check(L.lgh_ktime_begin(ctx, kid, 4096))
+            sim.step()
+            n = ctypes.c_int()
+            mean = ctypes.c_double()
+            _lib.check(L.lgh_ktime_end(ctx, ctypes.byref(n), ctypes.byref(mean)))
+            if n.value:
+                bts = bytes_per_elem[kid] * sz["NE"]
+                kern[names[kid]] = {"launches": n.value, "mean_us": 1e6 * mean.value,
+                                    "algorithmic_bytes": bts, "GBs": 1e-9 * bts / mean.value}
+        dom = kern.get(names[0])
+        if dom:
+            traffic = None
+            pj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            if os.path.exists(pj):
+                try:
+                    traffic = json.load(open(pj)).get("mass_apply_cg_h1_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            out["roofline"] = {"bound": "hbm", "kernel": names[0], "achieved": dom["GBs"], "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": dom["GBs"] / HBM_PEAK_GBS, "traffic": traffic,
+                               "mean_launch_us": dom["mean_us"], "launches_sampled": dom["launches"],
+                               "algorithmic_bytes_per_launch": dom["algorithmic_bytes"]}
+        out["kernels"] = kern
+
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline(min(usable_cpus(), 64))
+        except Exception as e:  # the checker is optional for the measurement
+            out["cpu_baseline"] = {"error": repr(e)}
+    sim.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

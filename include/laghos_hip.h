@@ -152,6 +152,19 @@ int lgh_get_timers(lgh_ctx *ctx, double t[4], long c[3]);
 int lgh_reset_timers(lgh_ctx *ctx);
 int lgh_enable_timers(lgh_ctx *ctx, int on);
 
+/* ---- per-kernel timing with HIP events on the context stream (bench.py roofline):
+ * between begin and end every launch of kernel `which` is bracketed by an event
+ * pair (up to max_samples launches); end synchronises and returns the number of
+ * sampled launches and their mean duration in seconds. */
+#define LGH_KERNEL_MASS_CG_H1 0   /* K1: gather + B^T D B + (d,Ad), H1 CG */
+#define LGH_KERNEL_CG_UPDATE_H1 1 /* K2: transpose gather + vector updates + (r,z) */
+#define LGH_KERNEL_QUPDATE 2
+#define LGH_KERNEL_FORCE_MULT 3
+#define LGH_KERNEL_FORCE_MULT_T 4
+#define LGH_KERNEL_MASS_CG_L2 5
+int lgh_ktime_begin(lgh_ctx *ctx, int which, int max_samples);
+int lgh_ktime_end(lgh_ctx *ctx, int *launches, double *mean_seconds);
+
 /* ---- multi-GPU: element blocks per rank, shared H1 nodes summed
  * over RCCL, dot products / dt all-reduced.  unique_id is the 128-byte
  * ncclUniqueId produced by lgh_comm_unique_id on rank 0 and broadcast by the

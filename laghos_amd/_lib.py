@@ -72,6 +72,8 @@ SYMBOLS = {
     "lgh_get_timers": (_I, [_P, c_dbl_p, ctypes.POINTER(ctypes.c_long)]),
     "lgh_reset_timers": (_I, [_P]),
     "lgh_enable_timers": (_I, [_P, _I]),
+    "lgh_ktime_begin": (_I, [_P, _I, _I]),
+    "lgh_ktime_end": (_I, [_P, c_int_p, c_dbl_p]),
     "lgh_comm_unique_id": (_I, [ctypes.c_char_p]),
     "lgh_comm_init": (_I, [_P, _I, _I, ctypes.c_char_p]),
     "lgh_comm_set_neighbors": (_I, [_P, _I, c_int_p, c_int_p, ctypes.POINTER(c_int_p)]),

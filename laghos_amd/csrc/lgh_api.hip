@@ -292,6 +292,11 @@ int lgh_destroy(lgh_ctx *c)
    if (c->host_pinned) { (void)hipHostFree(c->host_pinned); }
    if (c->timers.ev[0]) { (void)hipEventDestroy(c->timers.ev[0]); }
    if (c->timers.ev[1]) { (void)hipEventDestroy(c->timers.ev[1]); }
+   if (c->ktime)
+   {
+      for (hipEvent_t e : c->ktime->ev) { (void)hipEventDestroy(e); }
+      delete c->ktime;
+   }
    extern void lgh_comm_free(lgh_ctx *);
    lgh_comm_free(c);
    if (c->own_stream) { (void)hipStreamDestroy(c->stream); }
@@ -344,7 +349,9 @@ int lgh_force_mult(lgh_ctx *c, const double *x_l2, double *y_h1)
 {
    LGH_CHECK_ARG(c && x_l2 && y_h1);
    // L2R->Mult is the identity for the lexicographic L2 space (assembly.cpp:559-560)
+   kt_begin(c, LGH_KERNEL_FORCE_MULT);
    int rc = force_mult_E(c, c->stressJinvT, x_l2, c->YE);
+   kt_end(c, LGH_KERNEL_FORCE_MULT);
    if (rc) { return rc; }
    rc = h1_transpose_gather(c, c->dim, c->YE, y_h1); // H1R->MultTranspose (:564)
    if (rc) { return rc; }
@@ -354,7 +361,10 @@ int lgh_force_mult(lgh_ctx *c, const double *x_l2, double *y_h1)
 int lgh_force_mult_transpose(lgh_ctx *c, const double *v_h1, double *y_l2)
 {
    LGH_CHECK_ARG(c && v_h1 && y_l2);
-   return force_mult_t_L(c, c->stressJinvT, v_h1, y_l2);
+   kt_begin(c, LGH_KERNEL_FORCE_MULT_T);
+   const int rc = force_mult_t_L(c, c->stressJinvT, v_h1, y_l2);
+   kt_end(c, LGH_KERNEL_FORCE_MULT_T);
+   return rc;
 }
 
 int lgh_mass_set_essential_tdofs(lgh_ctx *c, int comp)
@@ -391,7 +401,9 @@ int lgh_qupdate(lgh_ctx *c, const double *S)
 {
    LGH_CHECK_ARG(c && S);
    timer_start(c);
+   kt_begin(c, LGH_KERNEL_QUPDATE);
    int rc = qupdate(c, S);
+   kt_end(c, LGH_KERNEL_QUPDATE);
    timer_stop(c, 3);
    c->timers.c[2] += c->NE;
    return rc;
@@ -514,6 +526,40 @@ int lgh_enable_timers(lgh_ctx *c, int on)
 {
    LGH_CHECK_ARG(c);
    c->timers.enabled = on != 0;
+   return LGH_OK;
+}
+
+int lgh_ktime_begin(lgh_ctx *c, int which, int max_samples)
+{
+   LGH_CHECK_ARG(c && which >= 0 && max_samples > 0);
+   if (!c->ktime) { c->ktime = new KTime(); }
+   KTime *k = c->ktime;
+   while ((int)k->ev.size() < 2 * max_samples)
+   {
+      hipEvent_t e;
+      LGH_HIP_CHECK(hipEventCreate(&e));
+      k->ev.push_back(e);
+   }
+   k->which = which;
+   k->max = max_samples;
+   k->n = 0;
+   return LGH_OK;
+}
+int lgh_ktime_end(lgh_ctx *c, int *launches, double *mean_seconds)
+{
+   LGH_CHECK_ARG(c && launches && mean_seconds && c->ktime);
+   KTime *k = c->ktime;
+   LGH_HIP_CHECK(hipStreamSynchronize(c->stream));
+   double tot = 0.0;
+   for (int i = 0; i < k->n; i++)
+   {
+      float ms = 0.f;
+      LGH_HIP_CHECK(hipEventElapsedTime(&ms, k->ev[2 * i], k->ev[2 * i + 1]));
+      tot += 1e-3 * ms;
+   }
+   *launches = k->n;
+   *mean_seconds = k->n ? tot / k->n : 0.0;
+   k->which = -1;
    return LGH_OK;
 }
 

@@ -63,6 +63,13 @@ struct Timers
    long c[3] = {0, 0, 0};      // H1iter, L2iter, quad_tstep
 };
 
+// event pairs around the launches of one kernel (lgh_ktime_begin / _end)
+struct KTime
+{
+   int which = -1, max = 0, n = 0;
+   std::vector<hipEvent_t> ev; // 2 per sample
+};
+
 struct Comm; // RCCL state (lgh_comm.hip)
 
 } // namespace lgh
@@ -107,6 +114,8 @@ struct lgh_ctx
    double *host_pinned;  // pinned host staging (16 doubles)
 
    lgh::Timers timers;
+   lgh::KTime *ktime;
+   int cg_last_iters[2][3]; // iteration count of the previous solve per (space, component)
    lgh::Comm *comm;
    int nranks, rank;
 };
@@ -306,6 +315,18 @@ int vec_zero_list(lgh_ctx *c, double *y, const int *list, int n);
 int vec_dot(lgh_ctx *c, const double *x, const double *y, const double *w, long n, double *dev_out);
 int halo_sum(lgh_ctx *c, double *v, int ncomp);
 int allreduce_dev(lgh_ctx *c, double *dev, int count, int op);
+
+// bracket one launch of kernel `id` with an event pair when sampling is on
+inline void kt_begin(lgh_ctx *c, int id)
+{
+   KTime *k = c->ktime;
+   if (k && k->which == id && k->n < k->max) { (void)hipEventRecord(k->ev[2 * k->n], c->stream); }
+}
+inline void kt_end(lgh_ctx *c, int id)
+{
+   KTime *k = c->ktime;
+   if (k && k->which == id && k->n < k->max) { (void)hipEventRecord(k->ev[2 * k->n + 1], c->stream); k->n++; }
+}
 
 void timer_start(lgh_ctx *c);
 void timer_stop(lgh_ctx *c, int which);

@@ -755,19 +755,29 @@ int cg_solve(lgh_ctx *c, int space, const double *b, double *x, double rel_tol, 
    }
    int it = 0;
    CgScalars *hs = (CgScalars *)c->host_pinned;
-   // chunk = iterations enqueued between two looks at the convergence flag
-   int chunk = 8;
+   // chunk = iterations enqueued between two looks at the convergence flag.  The
+   // iteration count of a mass solve barely changes from one RK stage to the next,
+   // so the first chunk is the previous count for this (space, component): the
+   // common case costs two host round trips and no wasted launches; kernels
+   // enqueued past convergence exit on the device-side `done` flag.
+   int &last = c->cg_last_iters[h1 ? 0 : 1][(h1 && c->cur_ess >= 0) ? c->cur_ess : 0];
+   int chunk = last > 0 ? last : 8;
    bool done = false;
+   bool first_look = true;
    while (!done)
    {
       LGH_HIP_CHECK(hipMemcpyAsync(hs, c->cgs, sizeof(CgScalars), hipMemcpyDeviceToHost, c->stream));
       LGH_HIP_CHECK(hipStreamSynchronize(c->stream));
       if (hs->done || it >= max_iter) { break; }
+      if (!first_look) { chunk = 2; }
+      first_look = false;
       const int upto = std::min(max_iter, it + chunk);
       for (; it < upto;)
       {
          ++it;
+         kt_begin(c, h1 ? LGH_KERNEL_MASS_CG_H1 : LGH_KERNEL_MASS_CG_L2);
          rc = h1 ? launch_mass<2>(c, space, m) : launch_mass<3>(c, space, m);
+         kt_end(c, h1 ? LGH_KERNEL_MASS_CG_H1 : LGH_KERNEL_MASS_CG_L2);
          if (rc) { return rc; }
          v.iter = it;
          v.ess = ess;
@@ -782,7 +792,9 @@ int cg_solve(lgh_ctx *c, int space, const double *b, double *x, double rel_tol, 
             v.ell = c->t_ell;
             v.deg = c->t_deg;
             v.YE = c->YE;
+            kt_begin(c, LGH_KERNEL_CG_UPDATE_H1);
             hipLaunchKernelGGL(cg_update_k<true>, dim3(nb), dim3(256), 0, c->stream, v);
+            kt_end(c, LGH_KERNEL_CG_UPDATE_H1);
          }
          else
          {
@@ -811,11 +823,11 @@ int cg_solve(lgh_ctx *c, int space, const double *b, double *x, double rel_tol, 
          }
          LGH_HIP_CHECK(hipGetLastError());
       }
-      chunk = std::min(chunk * 2, 32);
    }
    // upstream: final_iter = max_iter when the loop runs out without converging
    int fin = hs->iters;
    if (!hs->done && it >= max_iter) { fin = max_iter; }
+   last = fin;
    if (iters) { *iters = fin; }
    return LGH_OK;
 }

@@ -1,0 +1,419 @@
+// laghos.cpp — driver of the MI355X-native Laghos hot path.
+//
+// Mirrors the command line, time loop and output format of the reference driver
+// (/root/reference/laghos.cpp:119-1092) for the subset this repository supports:
+// PA mode (-pa), dim 2/3, problems 0, 1, 3 on the structured meshes of data/,
+// RK4 (-s 4) and RK2Avg (-s 7).  Everything else the reference driver does
+// (visualisation, VisIt, -fa, AMR, METIS, Umpire, Caliper) is out of scope
+// (SURVEY §2).  Exposed both as the `laghos` executable and as C entry points
+// (laghos_sim_*) that bench.py drives through ctypes.
+#include <cmath>
+#include <cstring>
+#include <iomanip>
+#include <iostream>
+#include <limits>
+#include <memory>
+#include <sstream>
+#include <string>
+
+#include "laghos_solver.hpp"
+
+using namespace laghos;
+
+namespace
+{
+
+struct Options
+{
+   int dim = 3;
+   std::string mesh_file = "default";
+   int nx = 2, ny = 2, nz = 2;
+   double Sx = 1, Sy = 1, Sz = 1;
+   double blast_energy = 1;
+   int rs_levels = 2, rp_levels = 0;
+   int problem = 1;
+   int order_v = 2, order_e = 1, order_q = -1;
+   int ode_solver_type = 4;
+   double t_final = 0.6, cfl = 0.5, cg_tol = 1e-8;
+   int cg_max_iter = 300, max_tsteps = -1;
+   bool p_assembly = true;
+   int vis_steps = 5;
+   bool check = false, fom = false;
+   int dev = 0;
+   // multi-rank (set by the launcher, not the reference CLI)
+   int nranks = 1, rank = 0;
+   const char *nccl_id = nullptr;
+   bool quiet = false;
+};
+
+bool ParseArgs(int argc, const char *const *argv, Options &o, std::string &err)
+{
+   auto need = [&](int &i) -> const char * {
+      if (i + 1 >= argc) { err = std::string("missing value for ") + argv[i]; return nullptr; }
+      return argv[++i];
+   };
+   for (int i = 0; i < argc; i++)
+   {
+      const std::string a = argv[i];
+      const char *v = nullptr;
+#define OPT_INT(s, l, field) if (a == s || a == l) { if (!(v = need(i))) { return false; } o.field = std::atoi(v); continue; }
+#define OPT_DBL(s, l, field) if (a == s || a == l) { if (!(v = need(i))) { return false; } o.field = std::atof(v); continue; }
+      OPT_INT("-dim", "--dimension", dim)
+      if (a == "-m" || a == "--mesh") { if (!(v = need(i))) { return false; } o.mesh_file = v; continue; }
+      OPT_INT("-nx", "--xelems", nx) OPT_INT("-ny", "--yelems", ny) OPT_INT("-nz", "--zelems", nz)
+      OPT_DBL("-E0", "--blast-energy", blast_energy)
+      OPT_DBL("-Sx", "--xwidth", Sx) OPT_DBL("-Sy", "--ywidth", Sy) OPT_DBL("-Sz", "--zwidth", Sz)
+      OPT_INT("-rs", "--refine-serial", rs_levels) OPT_INT("-rp", "--refine-parallel", rp_levels)
+      OPT_INT("-p", "--problem", problem)
+      OPT_INT("-ok", "--order-kinematic", order_v) OPT_INT("-ot", "--order-thermo", order_e)
+      OPT_INT("-oq", "--order-intrule", order_q)
+      OPT_INT("-s", "--ode-solver", ode_solver_type)
+      OPT_DBL("-tf", "--t-final", t_final) OPT_DBL("-cfl", "--cfl", cfl) OPT_DBL("-cgt", "--cg-tol", cg_tol)
+      OPT_INT("-cgm", "--cg-max-steps", cg_max_iter) OPT_INT("-ms", "--max-steps", max_tsteps)
+      OPT_INT("-vs", "--visualization-steps", vis_steps) OPT_INT("-dev", "--dev", dev)
+#undef OPT_INT
+#undef OPT_DBL
+      if (a == "-pa" || a == "--partial-assembly") { o.p_assembly = true; continue; }
+      if (a == "-fa" || a == "--full-assembly") { o.p_assembly = false; continue; }
+      if (a == "-chk" || a == "--checks") { o.check = true; continue; }
+      if (a == "-no-chk" || a == "--no-checks") { o.check = false; continue; }
+      if (a == "-f" || a == "--fom") { o.fom = true; continue; }
+      if (a == "-no-fom" || a == "--no-fom") { o.fom = false; continue; }
+      if (a == "-q" || a == "--quiet") { o.quiet = true; continue; }
+      if (a == "-d" || a == "--device") { if (!need(i)) { return false; } continue; } // always the HIP path
+      if (a == "-no-vis" || a == "--no-visualization" || a == "-no-visit" || a == "-no-print") { continue; }
+      err = "unsupported option: " + a;
+      return false;
+   }
+   return true;
+}
+
+// the reference's --checks table for the problems supported here (laghos.cpp:1441-1463)
+bool CheckNorm(int dim, int problem, int ti, double nrm, int &chk)
+{
+   struct Row { int dim, p, it; double norm; };
+   static const Row rows[] = {
+      {2, 0, 5, 6.546538624534384e+00}, {2, 0, 27, 7.588576357792927e+00},
+      {2, 1, 5, 3.508254945225794e+00}, {2, 1, 15, 2.756444596823211e+00},
+      {2, 3, 5, 8.000000000000000e+00}, {2, 3, 16, 8.000000000000000e+00},
+      {3, 0, 5, 1.198510951452527e+03}, {3, 0, 188, 1.199384410059154e+03},
+      {3, 1, 5, 6.695818592962833e+00}, {3, 1, 20, 4.267902387082487e+00},
+      {3, 3, 5, 1.600000000000000e+01}, {3, 3, 16, 1.600000000000000e+01}};
+   bool ok = true;
+   for (const Row &r : rows)
+   {
+      if (r.dim == dim && r.p == problem && r.it == ti)
+      {
+         chk++;
+         // the reference compares at 1e-13 against its own CPU build; this GPU
+         // path is held to 1e-10 (north_star: 1e-6)
+         const double rel = std::fabs(nrm - r.norm) / r.norm;
+         if (!(rel < 1e-10))
+         {
+            std::printf("check P%d #%d: %.15e vs %.15e (rel %.2e)\n", problem, ti, nrm, r.norm, rel);
+            ok = false;
+         }
+      }
+   }
+   return ok;
+}
+
+} // namespace
+
+// ---- simulation object driven by main() and by bench.py ------------------------------------
+struct laghos_sim
+{
+   Options opt;
+   std::unique_ptr<Discretization> disc;
+   std::unique_ptr<hydrodynamics::LagrangianHydroOperator> hydro;
+   std::unique_ptr<ODESolver> ode;
+   Vector S, S_old;
+   double t = 0.0, dt = 0.0, t_old = 0.0;
+   int ti = 1, steps = 0, repeats = 0;
+   bool last_step = false;
+   double energy_init = 0.0;
+   int checks = 0;
+   bool checks_ok = true;
+   std::string error;
+};
+
+extern "C"
+{
+
+const char *laghos_sim_error(laghos_sim *s) { return s ? s->error.c_str() : "null sim"; }
+
+// argv: the reference's command-line options; nranks/rank/nccl_id describe the
+// process group (nccl_id: 128 bytes from lgh_comm_unique_id, may be NULL for 1 rank)
+laghos_sim *laghos_sim_create(int argc, const char *const *argv, int nranks, int rank,
+                              const char *nccl_id)
+{
+   std::unique_ptr<laghos_sim> s(new laghos_sim());
+   Options &o = s->opt;
+   o.nranks = nranks;
+   o.rank = rank;
+   o.nccl_id = nccl_id;
+   std::string err;
+   if (!ParseArgs(argc, argv, o, err))
+   {
+      std::fprintf(stderr, "laghos: %s\n", err.c_str());
+      return nullptr;
+   }
+   if (!o.p_assembly)
+   {
+      std::fprintf(stderr, "laghos: only the partial-assembly path (-pa) is implemented\n");
+      return nullptr;
+   }
+   try
+   {
+      CartMesh mesh = (o.mesh_file.compare(0, 7, "default") == 0)
+                         ? CartMesh::Cartesian(o.dim, o.nx, o.ny, o.nz, o.Sx, o.Sy, o.Sz)
+                         : CartMesh::Named(o.mesh_file);
+      for (int l = 0; l < o.rs_levels + o.rp_levels; l++) { mesh.UniformRefinement(); } // laghos.cpp:391, :483
+      o.dim = mesh.dim;
+      s->disc.reset(new Discretization(mesh, o.order_v, o.order_e, o.problem, nranks, rank, o.order_q, o.blast_energy));
+   }
+   catch (const std::exception &e)
+   {
+      std::fprintf(stderr, "laghos: %s\n", e.what());
+      return nullptr;
+   }
+   const Discretization &d = *s->disc;
+   const bool root = (rank == 0) && !o.quiet;
+   if (root)
+   {
+      std::cout << "Number of zones in the serial mesh: " << d.global_NE << std::endl;
+      std::cout << "Number of kinematic (position, velocity) dofs: " << (long)d.dim * d.global_N << std::endl;
+      std::cout << "Number of specific internal energy dofs: " << d.global_NE * d.NL << std::endl;
+   }
+   std::vector<double> S0, rho0_l2, gamma, rho0_q;
+   d.InitialState(S0, rho0_l2, gamma, rho0_q);
+   s->hydro.reset(new hydrodynamics::LagrangianHydroOperator(d, S0, rho0_l2, gamma, rho0_q, o.cfl, o.cg_tol,
+                                                             o.cg_max_iter, o.dev, nccl_id));
+   switch (o.ode_solver_type)
+   {
+      case 4: s->ode.reset(new RK4Solver); break;
+      case 7: s->ode.reset(new RK2AvgSolver); break;
+      default:
+         std::fprintf(stderr, "Unknown / unsupported ODE solver type: %d (4 = RK4, 7 = RK2Avg)\n", o.ode_solver_type);
+         return nullptr;
+   }
+   s->S.FromHost(S0);
+   s->S_old.SetSize(s->S.Size());
+   s->ode->Init(*s->hydro);
+   s->energy_init = s->hydro->InternalEnergy(s->S) + s->hydro->KineticEnergy(s->S); // laghos.cpp:664
+   s->hydro->ResetTimeStepEstimate();                                                // :707
+   s->t = 0.0;
+   s->dt = s->hydro->GetTimeStepEstimate(s->S);                                      // :708
+   return s.release();
+}
+
+void laghos_sim_destroy(laghos_sim *s) { delete s; }
+
+// One pass of the reference time loop body (laghos.cpp:742-920): advances one
+// ACCEPTED step (repeating with dt*0.85 as needed).  Returns 1 if a step was
+// taken, 0 when the run is finished.
+int laghos_sim_step(laghos_sim *s)
+{
+   Options &o = s->opt;
+   auto &hydro = *s->hydro;
+   const bool root = (o.rank == 0) && !o.quiet;
+   while (true)
+   {
+      if (s->last_step) { return 0; }
+      if (s->t + s->dt >= o.t_final)
+      {
+         s->dt = o.t_final - s->t;
+         s->last_step = true;
+      }
+      if (s->steps == o.max_tsteps) { s->last_step = true; }
+      hydro.Copy(s->S_old, s->S);
+      s->t_old = s->t;
+      hydro.ResetTimeStepEstimate();
+      s->ode->Step(s->S, s->t, s->dt);
+      s->steps++;
+      // Adaptive time step control (laghos.cpp:762-778)
+      const double dt_est = hydro.GetTimeStepEstimate(s->S);
+      if (dt_est < s->dt)
+      {
+         s->dt *= 0.85;
+         if (s->dt < std::numeric_limits<double>::epsilon())
+         {
+            s->error = "The time step crashed!";
+            std::fprintf(stderr, "%s\n", s->error.c_str());
+            return -1;
+         }
+         s->t = s->t_old;
+         hydro.Copy(s->S, s->S_old);
+         hydro.ResetQuadratureData();
+         s->repeats++;
+         if (root) { std::cout << "Repeating step " << s->ti << std::endl; }
+         if (s->steps < o.max_tsteps) { s->last_step = false; }
+         continue;
+      }
+      else if (dt_est > 1.25 * s->dt) { s->dt *= 1.02; }
+
+      if (s->last_step || (s->ti % o.vis_steps) == 0)
+      {
+         const double sqrt_norm = hydro.ENorm(s->S);
+         if (root)
+         {
+            std::cout << std::fixed;
+            std::cout << "step " << std::setw(5) << s->ti << ",\tt = " << std::setw(5) << std::setprecision(4)
+                      << s->t << ",\tdt = " << std::setw(5) << std::setprecision(6) << s->dt
+                      << ",\t|e| = " << std::setprecision(10) << std::scientific << sqrt_norm;
+            std::cout << std::fixed << std::endl;
+         }
+      }
+      if (o.check)
+      {
+         const double e_norm = hydro.ENorm(s->S);
+         s->checks_ok = CheckNorm(o.dim, o.problem, s->ti, e_norm, s->checks) && s->checks_ok;
+      }
+      s->ti++;
+      return 1;
+   }
+}
+
+// state / metrics access for bench.py
+double laghos_sim_time(laghos_sim *s) { return s->t; }
+double laghos_sim_dt(laghos_sim *s) { return s->dt; }
+int laghos_sim_steps(laghos_sim *s) { return s->steps; }   // RK steps taken incl. repeated ones
+int laghos_sim_ti(laghos_sim *s) { return s->ti - 1; }     // accepted steps
+double laghos_sim_enorm(laghos_sim *s) { return s->hydro->ENorm(s->S); }
+double laghos_sim_energy(laghos_sim *s) { return s->hydro->InternalEnergy(s->S) + s->hydro->KineticEnergy(s->S); }
+void laghos_sim_sync(laghos_sim *s) { s->hydro->Sync(); }
+void laghos_sim_enable_timers(laghos_sim *s, int on) { s->hydro->EnableTimers(on != 0); }
+void laghos_sim_reset_timers(laghos_sim *s) { s->hydro->ResetTiming(); }
+// t[0..3] = cgH1, cgL2, force, qdata seconds; c[0..2] = H1iter, L2iter, quad_tstep
+void laghos_sim_timers(laghos_sim *s, double *t, long *c)
+{
+   const auto &tm = s->hydro->Timing();
+   t[0] = tm.sw_cgH1; t[1] = tm.sw_cgL2; t[2] = tm.sw_force; t[3] = tm.sw_qdata;
+   c[0] = tm.H1iter; c[1] = tm.L2iter; c[2] = tm.quad_tstep;
+}
+// sizes: [dim, local NE, global NE, local N, global H1 vdofs, global L2 dofs, NQ, D1D, Q1D, L1D]
+void laghos_sim_sizes(laghos_sim *s, long *out)
+{
+   const Discretization &d = *s->disc;
+   out[0] = d.dim; out[1] = d.NE; out[2] = d.global_NE; out[3] = d.N;
+   out[4] = s->hydro->GlobalH1Size(); out[5] = s->hydro->GlobalL2Size();
+   out[6] = d.NQ; out[7] = d.tab.D1D; out[8] = d.tab.Q1D; out[9] = d.tab.L1D;
+}
+void *laghos_sim_context(laghos_sim *s) { return s->hydro->Context(); }
+long laghos_sim_state_size(laghos_sim *s) { return s->S.Size(); }
+void laghos_sim_get_state(laghos_sim *s, double *host) // for tests
+{
+   std::vector<double> h;
+   s->hydro->Sync();
+   s->S.ToHost(h);
+   std::memcpy(host, h.data(), h.size() * sizeof(double));
+}
+
+// host-only probes of the setup code (no GPU): tests compare them with the oracle
+int laghos_host_tables(int order_v, int order_e, double *qpts, double *qwts, double *gll, double *B,
+                       double *G, double *Bl)
+{
+   Tables t(order_v, order_e);
+   std::memcpy(qpts, t.qpts.data(), t.qpts.size() * sizeof(double));
+   std::memcpy(qwts, t.qwts.data(), t.qwts.size() * sizeof(double));
+   std::memcpy(gll, t.gll.data(), t.gll.size() * sizeof(double));
+   std::memcpy(B, t.B.data(), t.B.size() * sizeof(double));
+   std::memcpy(G, t.G.data(), t.G.size() * sizeof(double));
+   std::memcpy(Bl, t.Bl.data(), t.Bl.size() * sizeof(double));
+   return t.Q1D;
+}
+// Builds the discretisation of one rank and returns sizes; arrays are copied out
+// by laghos_host_disc_get.  kind: 0 h1map, 1 S0, 2 rho0_l2, 3 gamma, 4 rho0_q,
+// 5 ess[0], 6 ess[1], 7 ess[2], 8 owner, 9 W, 10 nbr_rank, 11.. nbr_nodes[k-11]
+struct laghos_host_disc
+{
+   std::unique_ptr<Discretization> d;
+   std::vector<double> S0, rho0_l2, gamma, rho0_q;
+};
+laghos_host_disc *laghos_host_disc_create(const char *mesh, int rs, int order_v, int order_e, int problem,
+                                          double blast_energy, int nranks, int rank)
+{
+   try
+   {
+      CartMesh m = CartMesh::Named(mesh);
+      for (int l = 0; l < rs; l++) { m.UniformRefinement(); }
+      std::unique_ptr<laghos_host_disc> h(new laghos_host_disc());
+      h->d.reset(new Discretization(m, order_v, order_e, problem, nranks, rank, -1, blast_energy));
+      h->d->InitialState(h->S0, h->rho0_l2, h->gamma, h->rho0_q);
+      return h.release();
+   }
+   catch (const std::exception &e)
+   {
+      std::fprintf(stderr, "laghos_host_disc_create: %s\n", e.what());
+      return nullptr;
+   }
+}
+void laghos_host_disc_destroy(laghos_host_disc *h) { delete h; }
+long laghos_host_disc_size(laghos_host_disc *h, int kind)
+{
+   const Discretization &d = *h->d;
+   switch (kind)
+   {
+      case 0: return (long)d.h1map.size();
+      case 1: return (long)h->S0.size();
+      case 2: return (long)h->rho0_l2.size();
+      case 3: return (long)h->gamma.size();
+      case 4: return (long)h->rho0_q.size();
+      case 5: case 6: case 7: return (long)d.ess[kind - 5].size();
+      case 8: return (long)d.owner.size();
+      case 9: return (long)d.W.size();
+      case 10: return (long)d.nbr_rank.size();
+      default:
+         if (kind - 11 < (int)d.nbr_nodes.size()) { return (long)d.nbr_nodes[kind - 11].size(); }
+         return -1;
+   }
+}
+void laghos_host_disc_get(laghos_host_disc *h, int kind, void *out)
+{
+   const Discretization &d = *h->d;
+   auto cp = [&](const void *p, size_t bytes) { std::memcpy(out, p, bytes); };
+   switch (kind)
+   {
+      case 0: cp(d.h1map.data(), d.h1map.size() * sizeof(int)); break;
+      case 1: cp(h->S0.data(), h->S0.size() * sizeof(double)); break;
+      case 2: cp(h->rho0_l2.data(), h->rho0_l2.size() * sizeof(double)); break;
+      case 3: cp(h->gamma.data(), h->gamma.size() * sizeof(double)); break;
+      case 4: cp(h->rho0_q.data(), h->rho0_q.size() * sizeof(double)); break;
+      case 5: case 6: case 7: cp(d.ess[kind - 5].data(), d.ess[kind - 5].size() * sizeof(int)); break;
+      case 8: cp(d.owner.data(), d.owner.size() * sizeof(double)); break;
+      case 9: cp(d.W.data(), d.W.size() * sizeof(double)); break;
+      case 10: cp(d.nbr_rank.data(), d.nbr_rank.size() * sizeof(int)); break;
+      default: cp(d.nbr_nodes[kind - 11].data(), d.nbr_nodes[kind - 11].size() * sizeof(int));
+   }
+}
+
+// the reference main(): returns the process exit code
+int laghos_main(int argc, const char *const *argv)
+{
+   laghos_sim *s = laghos_sim_create(argc, argv, 1, 0, nullptr);
+   if (!s) { return 1; }
+   const Options &o = s->opt;
+   int rc;
+   while ((rc = laghos_sim_step(s)) == 1) {}
+   if (rc < 0) { laghos_sim_destroy(s); return 1; }
+   int steps = s->steps * s->ode->Stages(); // laghos.cpp:928-935
+   s->hydro->PrintTimingData(true, steps, o.fom);
+   const double energy_final = laghos_sim_energy(s);
+   std::cout << std::endl;
+   std::cout << "Energy  diff: " << std::scientific << std::setprecision(2)
+             << std::fabs(s->energy_init - energy_final) << std::endl;
+   int ret = 0;
+   if (o.check && !(s->checks == 2 && s->checks_ok))
+   {
+      std::cout << "Check error!" << std::endl; // MFEM_VERIFY(!check || checks == 2) (laghos.cpp:926)
+      ret = 1;
+   }
+   laghos_sim_destroy(s);
+   return ret;
+}
+
+} // extern "C"
+
+#ifdef LAGHOS_MAIN
+int main(int argc, char *argv[]) { return laghos_main(argc - 1, argv + 1); }
+#endif

@@ -877,6 +877,7 @@ struct Ctx
    int N;           // scalar H1 nodes (local)
    int H1V, L2V;    // vector sizes
    std::vector<int> h1map;             // NE x ND -> scalar node
+   std::vector<int> t_off, t_idx;      // transpose of h1map (CSR by node, ascending e*ND+d)
    std::vector<double> B, G, Bt, Gt;   // H1: B,G (Q x D, q fastest), Bt,Gt (D x Q)
    std::vector<double> Bl, Blt;        // L2: B (Q x L), Bt (L x Q)
    std::vector<double> W;              // NQ weights
@@ -1026,13 +1027,21 @@ void h1_gather(const Ctx &c, int vdim, const double *xL, double *XE)
 // (the order of MFEM's offsets/indices table).
 void h1_scatter_add(const Ctx &c, int vdim, const double *YE, double *yL)
 {
-   std::memset(yL, 0, sizeof(double) * (size_t)vdim * c.N);
-   for (int e = 0; e < c.NE; e++)
+   // gather form over the transposed map: per node the contributions are added
+   // in ascending (element, local dof) order, i.e. exactly the order of the
+   // serial `for e: for d: y[map] += Y` loop, but nodes run in parallel.
+#pragma omp parallel for schedule(static)
+   for (int n = 0; n < c.N; n++)
       for (int cc = 0; cc < vdim; cc++)
-         for (int d = 0; d < c.ND; d++)
+      {
+         double s = 0.0;
+         for (int k = c.t_off[n]; k < c.t_off[n + 1]; k++)
          {
-            yL[(size_t)cc * c.N + c.h1map[(size_t)e * c.ND + d]] += YE[d + c.ND * (cc + vdim * (size_t)e)];
+            const int p = c.t_idx[k], e = p / c.ND, d = p - e * c.ND;
+            s += YE[d + c.ND * (cc + vdim * (size_t)e)];
          }
+         yL[(size_t)cc * c.N + n] = s;
+      }
 }
 
 double dot_owned(const Ctx &c, const double *a, const double *b)
@@ -1087,6 +1096,15 @@ void *lgo_create(int dim, int NE, int D1D, int Q1D, int L1D, int N, const int *h
    c->H1V = dim * N;
    c->L2V = NE * c->NL;
    c->h1map.assign(h1map, h1map + (size_t)NE * c->ND);
+   {
+      const size_t nmap = (size_t)NE * c->ND;
+      c->t_off.assign((size_t)N + 1, 0);
+      c->t_idx.resize(nmap);
+      for (size_t i = 0; i < nmap; i++) { c->t_off[(size_t)h1map[i] + 1]++; }
+      for (int n = 0; n < N; n++) { c->t_off[(size_t)n + 1] += c->t_off[n]; }
+      std::vector<int> pos(c->t_off.begin(), c->t_off.end() - 1);
+      for (size_t i = 0; i < nmap; i++) { c->t_idx[pos[h1map[i]]++] = (int)i; }
+   }
    c->B.assign(B, B + Q1D * D1D);
    c->G.assign(G, G + Q1D * D1D);
    c->Bt.resize(Q1D * D1D);

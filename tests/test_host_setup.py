@@ -1,0 +1,74 @@
+"""Host logic of the C++ layer (laghos_amd/host/fem.cpp) against the oracle's
+independent numpy setup: 1-D tables, element restriction, essential dofs, initial
+conditions, block partition / neighbour lists.  CPU only."""
+import numpy as np
+import pytest
+
+from laghos_amd import host_lib
+from oracle.fem import Problem
+
+
+@pytest.mark.parametrize("ok,ot", [(1, 0), (2, 1), (3, 2), (4, 3), (5, 4)])
+def test_tables(ok, ot):
+    t = host_lib.host_tables(ok, ot)
+    p = Problem(mesh="cube01_hex", rs=0, order_v=ok, order_e=ot, problem=1)
+    for key, ref in (("qpts", p.qpts), ("qwts", p.qwts), ("gll", p.gll), ("B", p.B), ("G", p.G), ("Bl", p.Bl)):
+        assert np.max(np.abs(t[key] - ref)) < 5e-14, key
+    # partition of unity / derivative sums, quadrature exactness
+    assert np.max(np.abs(t["B"].sum(axis=1) - 1.0)) < 1e-14
+    assert np.max(np.abs(t["G"].sum(axis=1))) < 1e-12
+    assert np.max(np.abs(t["Bl"].sum(axis=1) - 1.0)) < 1e-14
+    assert abs(t["qwts"].sum() - 1.0) < 1e-15
+
+
+CASES = [("cube01_hex", 1, 2, 1, 1), ("cube01_hex", 1, 3, 2, 0), ("square01_quad", 2, 2, 1, 1),
+         ("box01_hex", 1, 2, 1, 3), ("rectangle01_quad", 1, 3, 2, 3), ("square01_quad", 1, 2, 1, 0)]
+
+
+@pytest.mark.parametrize("mesh,rs,ok,ot,prob", CASES)
+def test_discretization_single_rank(mesh, rs, ok, ot, prob):
+    d = host_lib.host_disc(mesh, rs, ok, ot, prob, blast_energy=2.0)
+    p = Problem(mesh=mesh, rs=rs, order_v=ok, order_e=ot, problem=prob, blast_energy=2.0)
+    S, rho_l2, gamma, rho0_q = p.initial_state()
+    assert np.array_equal(d["h1map"], p.h1map.reshape(-1))
+    for a in range(p.dim):
+        assert np.array_equal(np.sort(d["ess"][a]), np.sort(p.ess[a]))
+    scale = max(np.abs(S).max(), 1.0)
+    assert np.max(np.abs(d["S0"] - S)) / scale < 1e-13
+    assert np.max(np.abs(d["rho0_l2"] - rho_l2)) < 1e-13
+    assert np.array_equal(d["gamma"], gamma)
+    assert np.array_equal(d["rho0_q"], rho0_q)
+    assert np.max(np.abs(d["W"] - p.W)) < 1e-16
+    assert np.all(d["owner"] == 1.0)
+
+
+@pytest.mark.parametrize("nranks", [2, 4, 8])
+def test_partition(nranks):
+    """block partition: every global node owned exactly once; neighbour lists are
+    symmetric and enumerate the same physical nodes on both sides"""
+    mesh, rs, ok, ot = "cube01_hex", 1, 2, 1
+    discs = [host_lib.host_disc(mesh, rs, ok, ot, 1, nranks=nranks, rank=r) for r in range(nranks)]
+    ref = Problem(mesh=mesh, rs=rs, order_v=ok, order_e=ot, problem=1)
+    owned = sum(int(d["owner"].sum()) for d in discs)
+    assert owned == ref.global_N
+    dim = 3
+    for r, d in enumerate(discs):
+        N = len(d["owner"])
+        X = d["S0"][:dim * N].reshape(dim, N)
+        for k, nr in enumerate(d["nbr_rank"]):
+            o = discs[nr]
+            kk = list(o["nbr_rank"]).index(r)
+            No = len(o["owner"])
+            Xo = o["S0"][:dim * No].reshape(dim, No)
+            mine, theirs = d["nbr_nodes"][k], o["nbr_nodes"][kk]
+            assert len(mine) == len(theirs) and len(mine) > 0
+            assert np.max(np.abs(X[:, mine] - Xo[:, theirs])) < 1e-14
+    # the Sedov energy lives on exactly one rank
+    nz = [np.count_nonzero(d["S0"][2 * dim * len(d["owner"]):]) for d in discs]
+    assert sum(1 for n in nz if n) == 1
+    # oracle partition agrees (same pgrid choice for the cube)
+    for r, d in enumerate(discs):
+        pr = Problem(mesh=mesh, rs=rs, order_v=ok, order_e=ot, problem=1, rank=r,
+                     pgrid={2: [2, 1, 1], 4: [2, 2, 1], 8: [2, 2, 2]}[nranks])
+        assert np.array_equal(d["h1map"], pr.h1map.reshape(-1))
+        assert np.array_equal(d["owner"], pr.owner)
