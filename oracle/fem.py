@@ -217,6 +217,38 @@ class Problem:
                         m[:, dx + D * (dy + D * dz)] = (ex * p + dx) + Nx * ((ey * p + dy) + Ny * (ez * p + dz))
         return m
 
+    def neighbors(self):
+        """Ranks sharing H1 nodes with this one (faces, edges, corners) and the shared
+        local node lists, enumerated in local lexicographic order (same order on both
+        sides).  Returns (ranks, [node arrays])."""
+        dim = self.dim
+        idx = np.arange(self.N).reshape(self.nn[::-1])
+        ranks, lists = [], []
+        rng = [(-1, 0, 1)] * dim
+        import itertools
+        for off in itertools.product(*rng[::-1]):
+            off = off[::-1]  # (ox, oy[, oz]), x fastest ordering of the loop
+            if all(o == 0 for o in off):
+                continue
+            nc = [self.rcoord[a] + off[a] for a in range(dim)]
+            if any(c < 0 or c >= self.pgrid[a] for a, c in enumerate(nc)):
+                continue
+            nr, stride = 0, 1
+            for a in range(dim):
+                nr += stride * nc[a]
+                stride *= self.pgrid[a]
+            sl = []
+            for a in range(dim):
+                if off[a] < 0:
+                    sl.append(slice(0, 1))
+                elif off[a] > 0:
+                    sl.append(slice(self.nn[a] - 1, self.nn[a]))
+                else:
+                    sl.append(slice(None))
+            ranks.append(nr)
+            lists.append(idx[tuple(sl[::-1])].reshape(-1).astype(np.int32))
+        return ranks, lists
+
     def node_coords(self):
         """(dim, N) initial node positions, byNODES."""
         grids = np.meshgrid(*self.coords1d[::-1], indexing="ij")  # [z,y,x] order
