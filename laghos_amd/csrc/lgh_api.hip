@@ -249,6 +249,7 @@ int lgh_create(const lgh_config *cfg, lgh_ctx **out)
    const size_t nq = (size_t)c->NE * c->NQ;
    LGH_TRY(dev_alloc_zero(&c->stressJinvT, nq * dim * dim));
    LGH_TRY(dev_alloc_zero(&c->Jac0inv, nq * dim * dim));
+   LGH_TRY(dev_alloc_zero(&c->Jac0inv_soa, nq * dim * dim));
    LGH_TRY(dev_alloc_zero(&c->rho0DetJ0w, nq));
    LGH_TRY(dev_alloc_zero(&c->massD, nq));
    LGH_TRY(dev_alloc_zero(&c->diagV, (size_t)c->N));
@@ -285,7 +286,7 @@ int lgh_destroy(lgh_ctx *c)
    (void)hipStreamSynchronize(c->stream);
    void *ptrs[] = {c->B, c->G, c->Bl, c->W, c->gamma, c->h1map, c->t_off, c->t_idx, c->t_ell, c->essmask[0],
                    c->essmask[1], c->essmask[2], c->ess[0], c->ess[1], c->ess[2], c->owner,
-                   c->stressJinvT, c->Jac0inv, c->rho0DetJ0w, c->massD, c->diagV, c->dinvV,
+                   c->stressJinvT, c->Jac0inv, c->Jac0inv_soa, c->rho0DetJ0w, c->massD, c->diagV, c->dinvV,
                    c->dt_est_dev, c->XE, c->YE, c->cg_r, c->cg_z, c->cg_d0, c->cg_d1, c->cg_y,
                    c->partials, c->tickets, c->cgs, c->scal};
    for (void *p : ptrs) { if (p) { (void)hipFree(p); } }

@@ -101,6 +101,7 @@ struct lgh_ctx
 
    // QuadratureData + mass PA data
    double *stressJinvT, *Jac0inv, *rho0DetJ0w, *massD, *diagV, *dinvV;
+   double *Jac0inv_soa;  // plane-major copy of Jac0inv for coalesced reads in QUpdate
    double *dt_est_dev;   // 1 double: running min of the point-wise estimate
    // scratch
    double *XE;           // max(L2V, NE*ND*dim)

@@ -28,7 +28,7 @@ namespace lgh
 // 3D  y_E = F x_E
 // ---------------------------------------------------------------------------
 template <int D, int Q, int L, int NEB>
-__global__ void __launch_bounds__(Q *Q *NEB)
+__global__ void __launch_bounds__(Q *Q *NEB, 3)
 force_mult_3d(const int NE, const double *__restrict__ Bl, // [q + Q*l]
               const double *__restrict__ B,                 // [q + Q*d]
               const double *__restrict__ G, const double *__restrict__ sJit,
@@ -103,6 +103,9 @@ force_mult_3d(const int NE, const double *__restrict__ Bl, // [q + Q*l]
 
    const size_t plane = (size_t)NE * NQ;
    const size_t col = (size_t)e * NQ + tx + Q * ty;
+   // one component at a time: unrolling lets the scheduler hoist all 54 plane loads
+   // and blows the register budget (256 VGPRs, 1 wave/SIMD)
+#pragma unroll 1
    for (int c = 0; c < 3; c++)
    {
       // stream the three planes (gd = 0,1,2) of component c for this column
@@ -191,7 +194,7 @@ force_mult_3d(const int NE, const double *__restrict__ Bl, // [q + Q*l]
 // 3D  y_l2 = F^T v   (v given as L-vector through the gather map, or as E-vector)
 // ---------------------------------------------------------------------------
 template <int D, int Q, int L, int NEB>
-__global__ void __launch_bounds__(Q *Q *NEB)
+__global__ void __launch_bounds__(Q *Q *NEB, 3)
 force_mult_t_3d(const int NE, const int N, const double *__restrict__ Bl,
                 const double *__restrict__ B, const double *__restrict__ G,
                 const double *__restrict__ sJit, const double *__restrict__ v,
@@ -246,6 +249,9 @@ force_mult_t_3d(const int NE, const int N, const double *__restrict__ Bl,
    const size_t plane = (size_t)NE * NQ;
    const size_t col = (size_t)e * NQ + tx + Q * ty;
 
+   // one component at a time: unrolling lets the scheduler hoist all 54 plane loads
+   // and blows the register budget (256 VGPRs, 1 wave/SIMD)
+#pragma unroll 1
    for (int c = 0; c < 3; c++)
    {
       // issue this component's plane loads early

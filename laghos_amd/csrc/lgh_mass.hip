@@ -609,7 +609,11 @@ __global__ void cg_init_finish_k(CgScalars *s)
 }
 
 // K2: see file header.
-template <bool FUSED_GATHER>
+// U nodes per thread with every load of all U nodes issued before first use: the
+// kernel is pure memory latency (PMC: 90 % of wave cycles waiting), so the number
+// of independent loads in flight per lane is what sets its speed.
+constexpr int kUpdU = 2;
+template <bool FUSED_GATHER, int DEG>
 __global__ void __launch_bounds__(256)
 cg_update_k(const CgVecArgs a)
 {
@@ -617,39 +621,87 @@ cg_update_k(const CgVecArgs a)
    if (a.cgs->done) { return; }
    const double alpha = a.cgs->rz / a.cgs->den;
    // `first` was cleared by K1 of this iteration: iteration 1 is recognised by iter
-   const double beta = (a.iter == 1) ? 0.0 : a.cgs->rz / a.cgs->rz_prev;
-   const int n = blockIdx.x * blockDim.x + threadIdx.x;
-   double part = 0.0;
-   if (n < a.n)
+   const bool it1 = (a.iter == 1);
+   const double beta = it1 ? 0.0 : a.cgs->rz / a.cgs->rz_prev;
+   const int base = blockIdx.x * (256 * kUpdU) + threadIdx.x;
+   int n[kUpdU];
+   bool ok[kUpdU];
+#pragma unroll
+   for (int k = 0; k < kUpdU; k++)
    {
-      double zv;
-      if (FUSED_GATHER) { zv = ell_gather(n, a.n, a.deg, a.ell, a.YE); }
-      else
+      n[k] = base + 256 * k;
+      ok[k] = n[k] < a.n;
+      if (!ok[k]) { n[k] = a.n - 1; }
+   }
+   // ---- phase 1: issue all independent loads
+   int pidx[kUpdU][DEG > 0 ? DEG : 1];
+   if (FUSED_GATHER)
+   {
+#pragma unroll
+      for (int k = 0; k < kUpdU; k++)
+#pragma unroll
+         for (int j = 0; j < DEG; j++) { pidx[k][j] = (j < a.deg) ? a.ell[(size_t)j * a.n + n[k]] : -1; }
+   }
+   double zold[kUpdU], dold[kUpdU], xo[kUpdU], ro[kUpdU], di[kUpdU], ow[kUpdU], zv[kUpdU];
+   bool es[kUpdU];
+#pragma unroll
+   for (int k = 0; k < kUpdU; k++)
+   {
+      ro[k] = a.r[n[k]];
+      xo[k] = a.x[n[k]];
+      di[k] = a.dinv ? a.dinv[n[k]] : 1.0;
+      zold[k] = a.dinv ? a.z[n[k]] : ro[k];
+      dold[k] = (a.d_in_place || !it1) ? a.d[n[k]] : 0.0;
+      ow[k] = a.owner ? a.owner[n[k]] : 1.0;
+      es[k] = a.ess ? (a.ess[n[k]] != 0) : false;
+      if (!FUSED_GATHER) { zv[k] = a.yL[n[k]]; }
+   }
+   // ---- phase 2: dependent E-vector reads
+   if (FUSED_GATHER)
+   {
+      double ye[kUpdU][DEG > 0 ? DEG : 1];
+#pragma unroll
+      for (int k = 0; k < kUpdU; k++)
+#pragma unroll
+         for (int j = 0; j < DEG; j++) { ye[k][j] = (pidx[k][j] >= 0) ? a.YE[pidx[k][j]] : 0.0; }
+#pragma unroll
+      for (int k = 0; k < kUpdU; k++)
       {
-         zv = a.yL[n];
-         if (a.zero_yL) { a.yL[n] = 0.0; }
+         // ascending contribution order, skipping absent slots (same sum as the CSR loop)
+         double s = 0.0;
+#pragma unroll
+         for (int j = 0; j < DEG; j++) { if (pidx[k][j] >= 0) { s += ye[k][j]; } }
+         zv[k] = s;
       }
-      if (a.ess && a.ess[n]) { zv = 0.0; }
+   }
+   // ---- phase 3: updates
+   double part = 0.0;
+#pragma unroll
+   for (int k = 0; k < kUpdU; k++)
+   {
+      if (!ok[k]) { continue; }
+      if (!FUSED_GATHER && a.zero_yL) { a.yL[n[k]] = 0.0; }
+      const double z_ = es[k] ? 0.0 : zv[k];
       double dv;
-      if (a.d_in_place) { dv = a.d[n]; }
+      if (a.d_in_place) { dv = dold[k]; }
       else
       {
          // same expression as K1's gather: d = z_old + beta * d_old
-         dv = (a.dinv ? a.z[n] : a.r[n]);
-         if (a.iter != 1) { dv += beta * a.d[n]; }
-         a.d[n] = dv;
+         dv = zold[k];
+         if (!it1) { dv += beta * dold[k]; }
+         a.d[n[k]] = dv;
       }
-      const double xv = a.x[n] + alpha * dv;
-      const double rv = a.r[n] - alpha * zv;
-      a.x[n] = xv;
-      a.r[n] = rv;
+      const double xv = xo[k] + alpha * dv;
+      const double rv = ro[k] - alpha * z_;
+      a.x[n[k]] = xv;
+      a.r[n[k]] = rv;
       double pz = rv;
       if (a.dinv)
       {
-         pz = rv * a.dinv[n];
-         a.z[n] = pz;
+         pz = rv * di[k];
+         a.z[n[k]] = pz;
       }
-      part = (a.owner ? a.owner[n] : 1.0) * rv * pz;
+      part += ow[k] * rv * pz;
    }
    const double bsum = block_sum(part, red);
    double total;
@@ -715,6 +767,7 @@ int cg_solve(lgh_ctx *c, int space, const double *b, double *x, double rel_tol, 
    v.allreduce_pending = multi ? 1 : 0;
    const uint8_t *ess = (h1 && c->cur_ess >= 0) ? c->essmask[c->cur_ess] : nullptr;
    const int nb = ceil_div(n, 256);
+   const int nbu = ceil_div(n, 256 * kUpdU);
 
    // --- r = b - A x  (iterative_mode for H1; L2 starts from x = 0: solvers.cpp)
    if (!h1) { rc = vec_set(c, x, 0.0, n); if (rc) { return rc; } x_is_zero = true; }
@@ -785,7 +838,7 @@ int cg_solve(lgh_ctx *c, int space, const double *b, double *x, double rel_tol, 
          {
             v.yL = c->cg_y;
             v.zero_yL = 1;
-            hipLaunchKernelGGL(cg_update_k<false>, dim3(nb), dim3(256), 0, c->stream, v);
+            hipLaunchKernelGGL((cg_update_k<false, 0>), dim3(nbu), dim3(256), 0, c->stream, v);
          }
          else if (h1 && !multi)
          {
@@ -793,7 +846,16 @@ int cg_solve(lgh_ctx *c, int space, const double *b, double *x, double rel_tol, 
             v.deg = c->t_deg;
             v.YE = c->YE;
             kt_begin(c, LGH_KERNEL_CG_UPDATE_H1);
-            hipLaunchKernelGGL(cg_update_k<true>, dim3(nb), dim3(256), 0, c->stream, v);
+            if (c->t_deg <= 4) { hipLaunchKernelGGL((cg_update_k<true, 4>), dim3(nbu), dim3(256), 0, c->stream, v); }
+            else if (c->t_deg <= 8) { hipLaunchKernelGGL((cg_update_k<true, 8>), dim3(nbu), dim3(256), 0, c->stream, v); }
+            else
+            {
+               // unusual valence (not a tensor-product mesh): unfused gather, then update
+               hipLaunchKernelGGL(mass_gather_k, dim3(nb), dim3(256), 0, c->stream, c->N, c->t_deg,
+                                  c->t_ell, c->YE, (const uint8_t *)nullptr, c->cg_y);
+               v.yL = c->cg_y;
+               hipLaunchKernelGGL((cg_update_k<false, 0>), dim3(nbu), dim3(256), 0, c->stream, v);
+            }
             kt_end(c, LGH_KERNEL_CG_UPDATE_H1);
          }
          else
@@ -813,7 +875,7 @@ int cg_solve(lgh_ctx *c, int space, const double *b, double *x, double rel_tol, 
                hipLaunchKernelGGL(cg_den_finish_k, dim3(1), dim3(1), 0, c->stream, c->cgs);
             }
             v.yL = c->cg_y;
-            hipLaunchKernelGGL(cg_update_k<false>, dim3(nb), dim3(256), 0, c->stream, v);
+            hipLaunchKernelGGL((cg_update_k<false, 0>), dim3(nbu), dim3(256), 0, c->stream, v);
             if (multi)
             {
                rc = allreduce_dev(c, &c->cgs->rz, 1, 0);

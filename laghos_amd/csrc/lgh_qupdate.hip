@@ -31,6 +31,8 @@ struct QArgs
    const double *gamma;
    const double *rho0DetJ0w_in;
    const double *Jac0inv_in;
+   const double *Jac0inv_soa; // [q + NQ*e + NE*NQ*k], k = i + dim*j (internal copy)
+   double *Jac0inv_soa_out;
    double *stressJinvT;
    // setup outputs
    double *Jac0inv_out, *rho0DetJ0w_out, *massD_out;
@@ -57,7 +59,8 @@ __device__ __forceinline__ double smooth_step_01(double x, double eps)
 template <int DIM>
 __device__ __forceinline__ double qpoint_body(const QArgs &a, const int e, const size_t eq,
                                               const double weight, const double *J, const double *dV,
-                                              const double e_val, const size_t plane)
+                                              const double e_val, const size_t plane,
+                                              const double *J0i, const double rho0DetJ0w)
 {
    constexpr int DIM2 = DIM * DIM;
    double Jinv[DIM2], stress[DIM2], sgrad_v[DIM2], stressJiT[DIM2];
@@ -65,7 +68,7 @@ __device__ __forceinline__ double qpoint_body(const QArgs &a, const int e, const
    const double inv_weight = 1. / weight;
    const double detJ = sm::det<DIM>(J);
    sm::inverse<DIM>(J, detJ, Jinv);
-   const double R = inv_weight * a.rho0DetJ0w_in[eq] / detJ;
+   const double R = inv_weight * rho0DetJ0w / detJ;
    const double E = fmax(0.0, e_val);
    const double P = (gamma - 1.0) * R * E;
    const double S = sqrt(gamma * (gamma - 1.0) * E);
@@ -85,10 +88,8 @@ __device__ __forceinline__ double qpoint_body(const QArgs &a, const int e, const
          vorticity_coeff = (grad_norm > 0.0) ? div_v / grad_norm : 1.0;
       }
       sm::symmetrize<DIM>(sgrad_v);
-      double mu, compr_dir[DIM], Jpi[DIM2], ph_dir[DIM], J0i[DIM2];
+      double mu, compr_dir[DIM], Jpi[DIM2], ph_dir[DIM];
       sm::min_eigenpair<DIM>(sgrad_v, mu, compr_dir);
-#pragma unroll
-      for (int k = 0; k < DIM2; k++) { J0i[k] = a.Jac0inv_in[eq * DIM2 + k]; }
       sm::matmul<DIM>(J, J0i, Jpi);
       sm::matvec<DIM>(Jpi, compr_dir, ph_dir);
       const double ph_dir_nl2 = sm::norml2<DIM>(ph_dir);
@@ -122,8 +123,13 @@ __device__ __forceinline__ double qpoint_body(const QArgs &a, const int e, const
 
 // One workgroup = NEB elements, one thread per quadrature point.
 //   3D: blockDim = Q^3 (NEB = 1); 2D: blockDim = Q^2 * NEB.
-// NF = H1 fields interpolated per LDS pass (3 unless LDS is short).
-template <int DIM, int D, int Q, int L, int NEB, int NF, int MODE>
+// NFMAX = H1 fields (components of x and v) interpolated per LDS pass; 6 = one
+// pass for the update (3 barriers in total), smaller when LDS is short.
+// All global reads of an element (x, v, e gathers and the point-wise
+// Jac0inv / rho0DetJ0w) are issued before the first barrier, so a workgroup pays
+// one global-memory latency, not five; the L2 (energy) interpolation shares the
+// barrier intervals of the H1 stages.
+template <int DIM, int D, int Q, int L, int NEB, int NFMAX, int MODE>
 __global__ void __launch_bounds__((DIM == 3 ? Q * Q * Q : Q * Q) * NEB)
 qpoint_kernel(const QArgs a)
 {
@@ -131,6 +137,11 @@ qpoint_kernel(const QArgs a)
    constexpr int NQ = (DIM == 3) ? Q * Q * Q : Q * Q;
    constexpr int NL = (DIM == 3) ? L * L * L : L * L;
    constexpr int NTE = NQ; // threads per element
+   constexpr bool NEED_X = (MODE == QMODE_UPDATE || MODE == QMODE_SETUP);
+   constexpr bool NEED_V = (MODE == QMODE_UPDATE || MODE == QMODE_KE);
+   constexpr bool NEED_E = (MODE != QMODE_KE);
+   constexpr int NFIELD = (NEED_X ? DIM : 0) + (NEED_V ? DIM : 0);
+   constexpr int NF = (NFIELD == 0) ? 1 : (NFMAX < NFIELD ? NFMAX : NFIELD);
    // LDS per element
    constexpr int SU = NF * ND;
    constexpr int SXs = (DIM == 3) ? 2 * NF * D * D * Q : 2 * NF * D * Q; // B,G applied in x
@@ -151,24 +162,15 @@ qpoint_kernel(const QArgs a)
    double *sX = sU + SU;
    double *sY = sX + SXs;
    double *sE = sY + SYs;
+   double *sE1 = sE + NL;                            // 3D [lz][ly][qx]; 2D [ly][qx]
+   double *sE2 = sE1 + ((DIM == 3) ? L * L * Q : 0); // 3D [lz][qy][qx]
 
+   const size_t eq = (size_t)ec * NQ + lt;
+
+   // ---- issue every global read of this element up front
    for (int i = tid; i < Q * D; i += NTE * NEB) { sB[i] = a.B[i]; sG[i] = a.G[i]; }
    for (int i = tid; i < Q * L; i += NTE * NEB) { sBl[i] = a.Bl[i]; }
-
-   constexpr bool NEED_X = (MODE == QMODE_UPDATE || MODE == QMODE_SETUP);
-   constexpr bool NEED_V = (MODE == QMODE_UPDATE || MODE == QMODE_KE);
-   constexpr bool NEED_E = (MODE != QMODE_KE);
-   constexpr int NFIELD = (NEED_X ? DIM : 0) + (NEED_V ? DIM : 0);
-
-   double grad[NFIELD > 0 ? NFIELD * DIM : 1]; // [field][d]
-   double val[NFIELD > 0 ? NFIELD : 1];
-   (void)grad;
-   (void)val;
-
-   for (int f0 = 0; f0 < NFIELD; f0 += NF)
-   {
-      __syncthreads(); // previous pass done with sU/sX/sY; tables visible
-      // gather NF fields of this element: field f -> (x or v, component)
+   auto gather_fields = [&](const int f0) {
       for (int i = lt; i < NF * ND; i += NTE)
       {
          const int fl = i / ND, d = i - fl * ND;
@@ -183,49 +185,107 @@ qpoint_kernel(const QArgs a)
          }
          sU[i] = u;
       }
+   };
+   if (NFIELD > 0) { gather_fields(0); }
+   if (NEED_E)
+   {
+      for (int i = lt; i < NL; i += NTE) { sE[i] = a.e[(size_t)ec * NL + i]; }
+   }
+   double J0i[DIM * DIM];
+   double rdw = 0.0;
+   if (MODE == QMODE_UPDATE)
+   {
+#pragma unroll
+      for (int k = 0; k < DIM * DIM; k++) { J0i[k] = a.Jac0inv_soa[eq + (size_t)a.NE * NQ * k]; } // plane-major copy: coalesced
+      rdw = a.rho0DetJ0w_in[eq];
+   }
+   else if (MODE == QMODE_IE || MODE == QMODE_KE) { rdw = a.rho0DetJ0w_in[eq]; }
+
+   double grad[NFIELD > 0 ? NFIELD * DIM : 1]; // [field][d]
+   double val[NFIELD > 0 ? NFIELD : 1];
+   (void)grad;
+   (void)val;
+   double e_val = 0.0;
+
+   for (int f0 = 0; f0 < (NFIELD > 0 ? NFIELD : 1); f0 += NF)
+   {
+      const bool first_pass = (f0 == 0);
+      if (!first_pass)
+      {
+         __syncthreads(); // previous pass done with sU/sX/sY
+         gather_fields(f0);
+      }
       __syncthreads();
       if (DIM == 3)
       {
          // x stage: [k][fl][dz][dy][qx]
-         for (int i = lt; i < NF * D * D * Q; i += NTE)
+         if (NFIELD > 0)
          {
-            const int qx = i % Q, dy = (i / Q) % D, dz = (i / (Q * D)) % D, fl = i / (Q * D * D);
-            double u = 0.0, w = 0.0;
-#pragma unroll
-            for (int dx = 0; dx < D; dx++)
+            for (int i = lt; i < NF * D * D * Q; i += NTE)
             {
-               const double s = sU[dx + D * (dy + D * dz) + ND * fl];
-               u += sB[qx + Q * dx] * s;
-               w += sG[qx + Q * dx] * s;
+               const int qx = i % Q, dy = (i / Q) % D, dz = (i / (Q * D)) % D, fl = i / (Q * D * D);
+               double u = 0.0, w = 0.0;
+#pragma unroll
+               for (int dx = 0; dx < D; dx++)
+               {
+                  const double s = sU[dx + D * (dy + D * dz) + ND * fl];
+                  u += sB[qx + Q * dx] * s;
+                  w += sG[qx + Q * dx] * s;
+               }
+               sX[i] = u;
+               sX[i + NF * D * D * Q] = w;
             }
-            sX[i] = u;
-            sX[i + NF * D * D * Q] = w;
+         }
+         if (NEED_E && first_pass)
+         {
+            for (int i = lt; i < L * L * Q; i += NTE)
+            {
+               const int qx = i % Q, ly = (i / Q) % L, lz = i / (Q * L);
+               double u = 0.0;
+#pragma unroll
+               for (int lx = 0; lx < L; lx++) { u += sBl[qx + Q * lx] * sE[lx + L * (ly + L * lz)]; }
+               sE1[i] = u;
+            }
          }
          __syncthreads();
          // y stage: BB, GB, BG [k][fl][dz][qy][qx]
-         for (int i = lt; i < NF * D * Q * Q; i += NTE)
+         if (NFIELD > 0)
          {
-            const int qx = i % Q, qy = (i / Q) % Q, dz = (i / (Q * Q)) % D, fl = i / (Q * Q * D);
-            double bb = 0.0, gb = 0.0, bg = 0.0;
-#pragma unroll
-            for (int dy = 0; dy < D; dy++)
+            for (int i = lt; i < NF * D * Q * Q; i += NTE)
             {
-               const int j = qx + Q * (dy + D * (dz + D * fl));
-               const double vb = sX[j], vg = sX[j + NF * D * D * Q];
-               bb += sB[qy + Q * dy] * vb;
-               gb += sB[qy + Q * dy] * vg;
-               bg += sG[qy + Q * dy] * vb;
+               const int qx = i % Q, qy = (i / Q) % Q, dz = (i / (Q * Q)) % D, fl = i / (Q * Q * D);
+               double bb = 0.0, gb = 0.0, bg = 0.0;
+#pragma unroll
+               for (int dy = 0; dy < D; dy++)
+               {
+                  const int j = qx + Q * (dy + D * (dz + D * fl));
+                  const double vb = sX[j], vg = sX[j + NF * D * D * Q];
+                  bb += sB[qy + Q * dy] * vb;
+                  gb += sB[qy + Q * dy] * vg;
+                  bg += sG[qy + Q * dy] * vb;
+               }
+               sY[i] = bb;
+               sY[i + NF * D * Q * Q] = gb;
+               sY[i + 2 * NF * D * Q * Q] = bg;
             }
-            sY[i] = bb;
-            sY[i + NF * D * Q * Q] = gb;
-            sY[i + 2 * NF * D * Q * Q] = bg;
+         }
+         if (NEED_E && first_pass)
+         {
+            for (int i = lt; i < L * Q * Q; i += NTE)
+            {
+               const int qx = i % Q, qy = (i / Q) % Q, lz = i / (Q * Q);
+               double u = 0.0;
+#pragma unroll
+               for (int ly = 0; ly < L; ly++) { u += sBl[qy + Q * ly] * sE1[qx + Q * (ly + L * lz)]; }
+               sE2[i] = u;
+            }
          }
          __syncthreads();
          // z stage: this thread's point
 #pragma unroll
          for (int fl = 0; fl < NF; fl++)
          {
-            if (f0 + fl < NFIELD)
+            if (NFIELD > 0 && f0 + fl < NFIELD)
             {
                double vv = 0.0, d0 = 0.0, d1 = 0.0, d2 = 0.0;
 #pragma unroll
@@ -245,28 +305,47 @@ qpoint_kernel(const QArgs a)
                grad[(f0 + fl) * DIM + (DIM - 1)] = d2;
             }
          }
+         if (NEED_E && first_pass)
+         {
+#pragma unroll
+            for (int lz = 0; lz < L; lz++) { e_val += sBl[tz + Q * lz] * sE2[tx + Q * (ty + Q * lz)]; }
+         }
       }
       else
       {
-         for (int i = lt; i < NF * D * Q; i += NTE)
+         if (NFIELD > 0)
          {
-            const int qx = i % Q, dy = (i / Q) % D, fl = i / (Q * D);
-            double u = 0.0, w = 0.0;
-#pragma unroll
-            for (int dx = 0; dx < D; dx++)
+            for (int i = lt; i < NF * D * Q; i += NTE)
             {
-               const double s = sU[dx + D * dy + ND * fl];
-               u += sB[qx + Q * dx] * s;
-               w += sG[qx + Q * dx] * s;
+               const int qx = i % Q, dy = (i / Q) % D, fl = i / (Q * D);
+               double u = 0.0, w = 0.0;
+#pragma unroll
+               for (int dx = 0; dx < D; dx++)
+               {
+                  const double s = sU[dx + D * dy + ND * fl];
+                  u += sB[qx + Q * dx] * s;
+                  w += sG[qx + Q * dx] * s;
+               }
+               sX[i] = u;
+               sX[i + NF * D * Q] = w;
             }
-            sX[i] = u;
-            sX[i + NF * D * Q] = w;
+         }
+         if (NEED_E && first_pass)
+         {
+            for (int i = lt; i < L * Q; i += NTE)
+            {
+               const int qx = i % Q, ly = i / Q;
+               double u = 0.0;
+#pragma unroll
+               for (int lx = 0; lx < L; lx++) { u += sBl[qx + Q * lx] * sE[lx + L * ly]; }
+               sE1[i] = u;
+            }
          }
          __syncthreads();
 #pragma unroll
          for (int fl = 0; fl < NF; fl++)
          {
-            if (f0 + fl < NFIELD)
+            if (NFIELD > 0 && f0 + fl < NFIELD)
             {
                double vv = 0.0, d0 = 0.0, d1 = 0.0;
 #pragma unroll
@@ -283,59 +362,14 @@ qpoint_kernel(const QArgs a)
                grad[(f0 + fl) * DIM + 1] = d1;
             }
          }
+         if (NEED_E && first_pass)
+         {
+#pragma unroll
+            for (int ly = 0; ly < L; ly++) { e_val += sBl[ty + Q * ly] * sE1[tx + Q * ly]; }
+         }
       }
    }
 
-   // ---- L2 field (e, or rho0 for SETUP) at this point
-   double e_val = 0.0;
-   if (NEED_E)
-   {
-      __syncthreads();
-      for (int i = lt; i < NL; i += NTE) { sE[i] = a.e[(size_t)ec * NL + i]; }
-      __syncthreads();
-      if (DIM == 3)
-      {
-         double *s1 = sE + NL;         // [lz][ly][qx]
-         double *s2 = s1 + L * L * Q;  // [lz][qy][qx]
-         for (int i = lt; i < L * L * Q; i += NTE)
-         {
-            const int qx = i % Q, ly = (i / Q) % L, lz = i / (Q * L);
-            double u = 0.0;
-#pragma unroll
-            for (int lx = 0; lx < L; lx++) { u += sBl[qx + Q * lx] * sE[lx + L * (ly + L * lz)]; }
-            s1[i] = u;
-         }
-         __syncthreads();
-         for (int i = lt; i < L * Q * Q; i += NTE)
-         {
-            const int qx = i % Q, qy = (i / Q) % Q, lz = i / (Q * Q);
-            double u = 0.0;
-#pragma unroll
-            for (int ly = 0; ly < L; ly++) { u += sBl[qy + Q * ly] * s1[qx + Q * (ly + L * lz)]; }
-            s2[i] = u;
-         }
-         __syncthreads();
-#pragma unroll
-         for (int lz = 0; lz < L; lz++) { e_val += sBl[tz + Q * lz] * s2[tx + Q * (ty + Q * lz)]; }
-      }
-      else
-      {
-         double *s1 = sE + NL; // [ly][qx]
-         for (int i = lt; i < L * Q; i += NTE)
-         {
-            const int qx = i % Q, ly = i / Q;
-            double u = 0.0;
-#pragma unroll
-            for (int lx = 0; lx < L; lx++) { u += sBl[qx + Q * lx] * sE[lx + L * ly]; }
-            s1[i] = u;
-         }
-         __syncthreads();
-#pragma unroll
-         for (int ly = 0; ly < L; ly++) { e_val += sBl[ty + Q * ly] * s1[tx + Q * ly]; }
-      }
-   }
-
-   const size_t eq = (size_t)ec * NQ + lt;
    const size_t plane = (size_t)a.NE * NQ;
    const double weight = a.W[lt];
 
@@ -352,7 +386,7 @@ qpoint_kernel(const QArgs a)
             dV[c + DIM * d] = grad[(DIM + c) * DIM + d];
          }
       double cand = INFINITY;
-      if (active) { cand = qpoint_body<DIM>(a, e, eq, weight, J, dV, e_val, plane); }
+      if (active) { cand = qpoint_body<DIM>(a, e, eq, weight, J, dV, e_val, plane, J0i, rdw); }
       const double bmin = block_min(cand, red);
       double total;
       if (grid_min_last_block(bmin, a.partials, a.ticket, red, total))
@@ -397,6 +431,7 @@ qpoint_kernel(const QArgs a)
             Ji[7] = r * ((J31 * J12) - (J32 * J11));
             Ji[8] = r * ((J11 * J22) - (J12 * J21));
          }
+         for (int k = 0; k < DIM * DIM; k++) { a.Jac0inv_soa_out[eq + plane * k] = Ji[k]; }
          a.rho0DetJ0w_out[eq] = weight * e_val * det; // e_val = rho0 grid function here
          a.massD_out[eq] = weight * det * a.rho0_q[eq];
          part = weight * det;
@@ -422,7 +457,7 @@ qpoint_kernel(const QArgs a)
 #pragma unroll
             for (int c = 0; c < DIM; c++) { f += val[c] * val[c]; }
          }
-         part = f * a.rho0DetJ0w_in[eq];
+         part = f * rdw;
       }
       const double bsum = block_sum(part, red);
       double total;
@@ -448,7 +483,7 @@ template <int MODE> static int launch_q(lgh_ctx *c, const QArgs &a)
 #define LGH_Q2(D_, Q_, L_)                                                                           \
    {                                                                                                 \
       constexpr int NEB_ = (256 / (Q_ * Q_)) > 0 ? (256 / (Q_ * Q_)) : 1;                            \
-      hipLaunchKernelGGL((qpoint_kernel<2, D_, Q_, L_, NEB_, 2, MODE>), dim3(ceil_div(c->NE, NEB_)), \
+      hipLaunchKernelGGL((qpoint_kernel<2, D_, Q_, L_, NEB_, 4, MODE>), dim3(ceil_div(c->NE, NEB_)), \
                          dim3(Q_ * Q_ * NEB_), 0, c->stream, a);                                     \
    }                                                                                                 \
    break
@@ -460,9 +495,9 @@ template <int MODE> static int launch_q(lgh_ctx *c, const QArgs &a)
       case 0x246: LGH_Q2(4, 6, 3);
       case 0x258: LGH_Q2(5, 8, 4);
       case 0x26A: LGH_Q2(6, 10, 5);
-      case 0x322: LGH_Q3(2, 2, 1, 3);
-      case 0x334: LGH_Q3(3, 4, 2, 3);
-      case 0x346: LGH_Q3(4, 6, 3, 3);
+      case 0x322: LGH_Q3(2, 2, 1, 6);
+      case 0x334: LGH_Q3(3, 4, 2, 6);
+      case 0x346: LGH_Q3(4, 6, 3, 6);
       case 0x358: LGH_Q3(5, 8, 4, 3);
       case 0x36A: LGH_Q3(6, 10, 5, 1); // extension: not in the reference table
       default: return unknown_kernel(c->kid);
@@ -487,6 +522,7 @@ static QArgs q_base(lgh_ctx *c)
    a.gamma = c->gamma;
    a.rho0DetJ0w_in = c->rho0DetJ0w;
    a.Jac0inv_in = c->Jac0inv;
+   a.Jac0inv_soa = c->Jac0inv_soa;
    a.stressJinvT = c->stressJinvT;
    a.partials = c->partials + 2 * (size_t)c->part_stride;
    a.ticket = c->tickets + 2 * kTicketSlot;
@@ -516,6 +552,7 @@ int setup_rho0detj0(lgh_ctx *c, const double *x0, const double *rho0_l2, const d
    a.e = rho0_l2;
    a.rho0_q = rho0_q;
    a.Jac0inv_out = c->Jac0inv;
+   a.Jac0inv_soa_out = c->Jac0inv_soa;
    a.rho0DetJ0w_out = c->rho0DetJ0w;
    a.massD_out = c->massD;
    a.result = c->scal;

@@ -149,15 +149,34 @@ template <int N> LGH_HD double fnorm(const double *A)
    return mx * sqrt(f2);
 }
 
-// power-of-two scale with d_max / mult in [0.5, 1)
-LGH_HD double scaling_factor(const double d_max)
+// power-of-two scale with d_max / mult in [0.5, 1): mult = 2^ex (the value the
+// reference obtains as d_max / frexp-mantissa, an exact quotient), and its exact
+// reciprocal, so the 6-9 scalings cost a multiply each instead of an fp64 divide
+// (bit-identical results: scaling by a power of two is exact either way).
+LGH_HD double scaling_factor(const double d_max, double &inv_mult)
 {
-   if (!(d_max > 0.)) { return 1.; }
+   if (!(d_max > 0.))
+   {
+      inv_mult = 1.;
+      return 1.;
+   }
    int ex;
-   double m = frexp(d_max, &ex);
-   if (ex == DBL_MAX_EXP) { m *= 2.0; }
-   return d_max / m;
+   (void)frexp(d_max, &ex);
+   if (ex == DBL_MAX_EXP) { ex -= 1; }
+   inv_mult = ldexp(1.0, -ex);
+   return ldexp(1.0, ex);
 }
+
+// sqrt(a^2 + b^2) for operands already scaled to O(1) (no overflow guard needed)
+LGH_HD double hypot_scaled(const double a, const double b) { return sqrt(a * a + b * b); }
+
+// Relative size below which the deviatoric part of a symmetric 3x3 matrix is
+// round-off of its isotropic part: Q <= (8 eps)^2 (tr/3)^2 perturbs eigenvalues
+// by <= 2e-15 relative.  In the singular-VALUE routine, treating it as Q = 0 keeps
+// whole wavefronts on the cheap path over undisturbed mesh (J = h I + round-off),
+// where otherwise random signs of R/Q^1.5 send some lane of every wave through
+// every branch (measured: 4300 VALU instructions per wave).
+#define LGH_SM_QTINY 3.2e-30
 
 // Jacobi rotation (c,s) for [d1 d12; d12 d2]; d1,d2 become the eigenvalues.
 LGH_HD void eigensystem2s(const double d12, double &d1, double &d2, double &c, double &s)
@@ -229,7 +248,7 @@ LGH_HD int kernel_vector_2g(const int mode, double &d1, double &d12, double &d21
       if (sw) { swap2(d1, d2); swap2(d12, d21); }
       else { swap2(d1, d12); swap2(d21, d2); }
    }
-   n1 = hypot(d1, d21);
+   n1 = hypot_scaled(d1, d21);
    if (d21 != 0.)
    {
       mu = copysign(n1, d1);
@@ -272,8 +291,8 @@ LGH_HD int kernel_vector_3g(const int mode, double &d1, double &d2, double &d3, 
 {
    int kdim;
    double mu, n1, n2, n3, s1, s2, s3;
-   s1 = hypot(c21, c31);
-   n1 = hypot(d1, s1);
+   s1 = hypot_scaled(c21, c31);
+   n1 = hypot_scaled(d1, s1);
    if (s1 != 0.)
    {
       mu = copysign(n1, d1);
@@ -429,7 +448,7 @@ LGH_HD int reduce_3s(const int mode, double &d1, double &d2, double &d3, double 
       swap2(d1, d3);
       swap2(z1, z3);
    }
-   double s = hypot(z2, z3);
+   double s = hypot_scaled(z2, z3);
    if (s == 0.)
    {
       v1 = v2 = v3 = 0.;
@@ -494,14 +513,15 @@ LGH_HD void min_eigenpair3(const double *data, double &lambda, double *vec)
    if (d_max < fabs(d12)) { d_max = fabs(d12); }
    if (d_max < fabs(d13)) { d_max = fabs(d13); }
    if (d_max < fabs(d23)) { d_max = fabs(d23); }
-   const double mult = scaling_factor(d_max);
-   d11 /= mult; d22 /= mult; d33 /= mult;
-   d12 /= mult; d13 /= mult; d23 /= mult;
+   double imult;
+   const double mult = scaling_factor(d_max, imult);
+   d11 *= imult; d22 *= imult; d33 *= imult;
+   d12 *= imult; d13 *= imult; d23 *= imult;
    double aa = (d11 + d22 + d33) / 3;
    double c1 = d11 - aa, c2 = d22 - aa, c3 = d33 - aa;
    const double Q = (2 * (d12 * d12 + d13 * d13 + d23 * d23) + c1 * c1 + c2 * c2 + c3 * c3) / 6;
    double R = (c1 * (d23 * d23 - c2 * c3) + d12 * (d12 * c3 - 2 * d13 * d23) + d13 * d13 * c2) / 2;
-   bool triple = (Q <= 0.);
+   bool triple = (Q <= 0.); // no tiny-Q shortcut here: the eigenVECTOR is not continuous in Q
    if (!triple)
    {
       const double sqrtQ = sqrt(Q);
@@ -586,8 +606,9 @@ LGH_HD double min_singular2(const double *data)
    if (d_max < fabs(d1)) { d_max = fabs(d1); }
    if (d_max < fabs(d2)) { d_max = fabs(d2); }
    if (d_max < fabs(d3)) { d_max = fabs(d3); }
-   const double mult = scaling_factor(d_max);
-   d0 /= mult; d1 /= mult; d2 /= mult; d3 /= mult;
+   double imult;
+   const double mult = scaling_factor(d_max, imult);
+   d0 *= imult; d1 *= imult; d2 *= imult; d3 *= imult;
    double t = 0.5 * ((d0 + d2) * (d0 - d2) + (d1 - d3) * (d1 + d3));
    double s = d0 * d2 + d1 * d3;
    s = sqrt(0.5 * (d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3) + sqrt(t * t + s * s));
@@ -610,10 +631,11 @@ LGH_HD double min_singular3(const double *data)
    if (d_max < fabs(d6)) { d_max = fabs(d6); }
    if (d_max < fabs(d7)) { d_max = fabs(d7); }
    if (d_max < fabs(d8)) { d_max = fabs(d8); }
-   const double mult = scaling_factor(d_max);
-   d0 /= mult; d1 /= mult; d2 /= mult;
-   d3 /= mult; d4 /= mult; d5 /= mult;
-   d6 /= mult; d7 /= mult; d8 /= mult;
+   double imult;
+   const double mult = scaling_factor(d_max, imult);
+   d0 *= imult; d1 *= imult; d2 *= imult;
+   d3 *= imult; d4 *= imult; d5 *= imult;
+   d6 *= imult; d7 *= imult; d8 *= imult;
    double b11 = d0 * d0 + d1 * d1 + d2 * d2;
    double b12 = d0 * d3 + d1 * d4 + d2 * d5;
    double b13 = d0 * d6 + d1 * d7 + d2 * d8;
@@ -632,7 +654,7 @@ LGH_HD double min_singular3(const double *data)
    }
    const double Q = (2 * (b12 * b12 + b13 * b13 + b23 * b23) + c1 * c1 + c2 * c2 + c3 * c3) / 6;
    double R = (c1 * (b23 * b23 - c2 * c3) + b12 * (b12 * c3 - 2 * b13 * b23) + b13 * b13 * c2) / 2;
-   if (Q > 0.)
+   if (Q > LGH_SM_QTINY * (aa * aa))
    {
       const double sqrtQ = sqrt(Q);
       const double sqrtQ3 = Q * sqrtQ;
