@@ -269,7 +269,7 @@ int lgh_create(const lgh_config *cfg, lgh_ctx **out)
    LGH_TRY(dev_alloc_zero(&c->tickets, 4 * (size_t)kTicketSlot));
    LGH_TRY(dev_alloc_zero(&c->cgs, 1));
    LGH_TRY(dev_alloc_zero(&c->scal, 16));
-   LGH_HIP_CHECK(hipHostMalloc((void **)&c->host_pinned, 32 * sizeof(double), hipHostMallocDefault));
+   LGH_HIP_CHECK(hipHostMalloc((void **)&c->host_pinned, 64 * sizeof(double), hipHostMallocDefault));
    LGH_HIP_CHECK(hipEventCreate(&c->timers.ev[0]));
    LGH_HIP_CHECK(hipEventCreate(&c->timers.ev[1]));
    const double inf = std::numeric_limits<double>::infinity();
@@ -288,7 +288,8 @@ int lgh_destroy(lgh_ctx *c)
                    c->essmask[1], c->essmask[2], c->ess[0], c->ess[1], c->ess[2], c->owner,
                    c->stressJinvT, c->Jac0inv, c->Jac0inv_soa, c->rho0DetJ0w, c->massD, c->diagV, c->dinvV,
                    c->dt_est_dev, c->XE, c->YE, c->cg_r, c->cg_z, c->cg_d0, c->cg_d1, c->cg_y,
-                   c->partials, c->tickets, c->cgs, c->scal};
+                   c->partials, c->tickets, c->cgs, c->scal, c->vcg_s, c->vcg_vec, c->vcg_partials,
+                   c->vcg_tickets};
    for (void *p : ptrs) { if (p) { (void)hipFree(p); } }
    if (c->host_pinned) { (void)hipHostFree(c->host_pinned); }
    if (c->timers.ev[0]) { (void)hipEventDestroy(c->timers.ev[0]); }
@@ -427,6 +428,30 @@ int lgh_solve_velocity(lgh_ctx *c, const double *S, double *dS_dt, const double 
    if (rc) { return rc; }
    rc = vec_neg_inplace(c, rhs_h1, c->H1V); // :358
    if (rc) { return rc; }
+   // the dim component solves in lockstep (lgh_vcg.hip) when the kernel id has it
+   {
+      for (int cc = 0; cc < dim; cc++)
+      {
+         // EliminateRHS with c_tdofs[cc] (:383-384); rhs_h1 is caller scratch
+         rc = vec_zero_list(c, rhs_h1 + (size_t)cc * N, c->ess[cc], c->ess_count[cc]);
+         if (rc) { return rc; }
+      }
+      int its[3] = {0, 0, 0};
+      timer_start(c);
+      rc = vcg_solve(c, rhs_h1, dv, rel_tol, max_iter, its); // :388 for all components
+      if (rc == LGH_OK)
+      {
+         timer_stop(c, 0);
+         for (int cc = 0; cc < dim; cc++)
+         {
+            c->timers.c[0] += its[cc]; // :392
+            if (h1_iters) { *h1_iters += its[cc]; }
+         }
+         c->cur_ess = dim - 1;
+         return LGH_OK;
+      }
+      if (rc != LGH_ERR_UNSUPPORTED) { return rc; }
+   }
    for (int cc = 0; cc < dim; cc++)
    {
       // B = rhs_c (Pconf is the identity on a conforming mesh; shared-node sums

@@ -114,6 +114,14 @@ struct lgh_ctx
    double *scal;         // small device scalar pool (16 doubles)
    double *host_pinned;  // pinned host staging (16 doubles)
 
+   // lockstep velocity CG (lgh_vcg.hip), allocated on first use
+   void *vcg_s;
+   double *vcg_vec, *vcg_partials;
+   unsigned int *vcg_tickets;
+   unsigned vcg_stride;
+   int vcg_last;
+   int vcg_grid;         // persistent grid size of the K1 kernel (one resident wave)
+
    lgh::Timers timers;
    lgh::KTime *ktime;
    int cg_last_iters[2][3]; // iteration count of the previous solve per (space, component)
@@ -301,6 +309,7 @@ int mass_apply_h1(lgh_ctx *c, const double *x, double *y, bool eliminate);
 int mass_apply_l2(lgh_ctx *c, const double *x, double *y);
 int mass_apply_E(lgh_ctx *c, int space, const double *xE, double *yE);
 int mass_assemble_diag(lgh_ctx *c);
+int vcg_solve(lgh_ctx *c, const double *B, double *X, double rel_tol, int max_iter, int iters[3]);
 int cg_solve(lgh_ctx *c, int space, const double *b, double *x, double rel_tol, int max_iter,
              int *iters, bool x_is_zero);
 int qupdate(lgh_ctx *c, const double *S);

@@ -28,7 +28,7 @@ namespace lgh
 // 3D  y_E = F x_E
 // ---------------------------------------------------------------------------
 template <int D, int Q, int L, int NEB>
-__global__ void __launch_bounds__(Q *Q *NEB, 3)
+__global__ void __launch_bounds__(Q *Q *NEB, (Q <= 6) ? 3 : 2)
 force_mult_3d(const int NE, const double *__restrict__ Bl, // [q + Q*l]
               const double *__restrict__ B,                 // [q + Q*d]
               const double *__restrict__ G, const double *__restrict__ sJit,
@@ -194,7 +194,7 @@ force_mult_3d(const int NE, const double *__restrict__ Bl, // [q + Q*l]
 // 3D  y_l2 = F^T v   (v given as L-vector through the gather map, or as E-vector)
 // ---------------------------------------------------------------------------
 template <int D, int Q, int L, int NEB>
-__global__ void __launch_bounds__(Q *Q *NEB, 3)
+__global__ void __launch_bounds__(Q *Q *NEB, (Q <= 6) ? 3 : 2)
 force_mult_t_3d(const int NE, const int N, const double *__restrict__ Bl,
                 const double *__restrict__ B, const double *__restrict__ G,
                 const double *__restrict__ sJit, const double *__restrict__ v,

@@ -1,0 +1,737 @@
+// lgh_vcg.hip — the three velocity-component mass solves of SolveVelocity run in
+// lockstep on the device.
+//
+// Reference: /root/reference/laghos_solver.cpp:363-398 calls CG_VMass.Mult once
+// per velocity component, each a Jacobi-PCG on the same scalar H1 mass operator
+// with its own right-hand side and essential-dof list.  Here the dim independent
+// CGSolver::Mult recurrences advance together: every component keeps
+// its own alpha, beta, residual norms, convergence flag and iteration count, and
+// performs exactly the operations of its stand-alone solve in the same order —
+// only the kernels are shared.
+//
+// Why (MI355X): the quadrature data D = w detJ0 rho0 is 63 % of the bytes of a mass
+// apply and the element->node maps are another 10 %; applying the operator to the
+// three directions in one pass reads them once instead of three times, halves the
+// launches, and amortises the grid reduction (one ticket, three sums).
+#include "lgh_common.hpp"
+
+namespace lgh
+{
+
+constexpr int kVC = 3; // velocity components handled in lockstep
+
+struct VcgScalars
+{
+   double rz[kVC], rz_prev[kVC], den[kVC], r0[kVC];
+   double rel_tol2;
+   int done[kVC], iters[kVC], first;
+   int all_done, pad;
+};
+
+// three-value variant of grid_reduce_last_block (sum): partials[v*stride + i]
+__device__ __forceinline__ bool grid_sum3_last_block(const double bp[kVC], double *partials,
+                                                     const unsigned stride, unsigned int *ticket,
+                                                     double *red, double total[kVC])
+{
+   const int tid = threadIdx.x;
+   const int nthr = blockDim.x;
+   const unsigned int nblk = gridDim.x, bid = blockIdx.x;
+   const unsigned s = bid % kShards;
+   const unsigned cnt = nblk / kShards + ((s < nblk % kShards) ? 1u : 0u);
+   const unsigned nsh = nblk < kShards ? nblk : kShards;
+   unsigned int *t1 = ticket + s * kTicketStride;
+   unsigned int *t2 = ticket + kShards * kTicketStride;
+   __shared__ unsigned int s_flag;
+   if (tid == 0)
+   {
+#pragma unroll
+      for (int v = 0; v < kVC; v++)
+      {
+         __hip_atomic_store(&partials[(size_t)v * stride + bid], bp[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned a = __hip_atomic_fetch_add(t1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_flag = (a == cnt - 1) ? 1u : 0u;
+   }
+   __syncthreads();
+   if (!s_flag) { return false; }
+   double ssum[kVC];
+#pragma unroll
+   for (int v = 0; v < kVC; v++)
+   {
+      double acc = 0.0;
+      for (unsigned int i = tid; i < cnt; i += nthr)
+      {
+         acc += __hip_atomic_load(&partials[(size_t)v * stride + s + kShards * i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      ssum[v] = block_sum(acc, red);
+      __syncthreads();
+   }
+   const unsigned shard_off = nblk; // shard sums follow the block partials of each value
+   if (tid == 0)
+   {
+#pragma unroll
+      for (int v = 0; v < kVC; v++)
+      {
+         __hip_atomic_store(&partials[(size_t)v * stride + shard_off + s], ssum[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(t1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned b = __hip_atomic_fetch_add(t2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_flag = (b == nsh - 1) ? 1u : 0u;
+      if (s_flag) { __hip_atomic_store(t2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+   }
+   __syncthreads();
+   if (!s_flag) { return false; }
+#pragma unroll
+   for (int v = 0; v < kVC; v++)
+   {
+      double acc = 0.0;
+      for (unsigned int i = tid; i < nsh; i += nthr)
+      {
+         acc += __hip_atomic_load(&partials[(size_t)v * stride + shard_off + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      total[v] = block_sum(acc, red);
+      __syncthreads();
+   }
+   return true;
+}
+
+struct VcgArgs
+{
+   int NE, N;
+   const double *B, *Dq;
+   const int *map;
+   const int *ell;
+   int deg;
+   const uint8_t *ess[kVC];
+   const double *dinv, *owner;
+   const double *b;       // kVC*N right-hand sides (byNODES)
+   double *x;             // kVC*N solutions
+   double *r, *z, *d;     // kVC*N each
+   double *YE;            // kVC * NE*ND
+   size_t ye_stride;      // NE*ND
+   double *yL;            // kVC*N (unfused path)
+   VcgScalars *s;
+   double *partials;
+   unsigned stride;
+   unsigned int *ticket;
+   int iter, multi;
+};
+
+// ---- K1: y_e^c = B^T D_e B d_e^c for the unconverged components, d^c = z^c + beta_c d^c.
+// Persistent workgroups: the grid is one resident wave of workgroups; each walks
+// batches b, b+G, ... of NEB elements.  Profiling the one-batch-per-workgroup form
+// showed it bound by the per-workgroup latency chain (map -> gather -> 4 barriers
+// -> store -> partial/ticket round trip) times 2.3 waves of workgroups, not by
+// bytes or FMAs.  Here the map entries, the gathers of all components and the
+// quadrature data of batch i+1 are in flight while batch i is contracted, and
+// the dot-product partials are published once per workgroup.
+template <int D, int Q, int NEB>
+__global__ void __launch_bounds__(Q *Q *NEB, 2)
+vcg_apply_3d(const VcgArgs a, const int nbatch)
+{
+   constexpr int NQ = Q * Q * Q, ND = D * D * D;
+   constexpr int SX = (ND > D * Q * Q) ? ND : D * Q * Q;
+   constexpr int SA = D * D * Q;
+   constexpr int SAE = (SA > D * Q * D) ? SA : D * Q * D;
+   constexpr int OFF_A = kVC * SX, OFF_IN = OFF_A + kVC * SAE;
+   constexpr int PER = OFF_IN + kVC * ND + 1; // per component: C, A/E work buffers, gathered direction
+   constexpr int NT = Q * Q * NEB;
+   constexpr int GPT = (NEB * ND + NT - 1) / NT; // gather items per thread
+   __shared__ double smem[NEB * PER];
+   __shared__ double red[16];
+
+   if (a.s->all_done) { return; }
+   const int tid = threadIdx.x;
+   const int tx = tid % Q, ty = (tid / Q) % Q, eb = tid / (Q * Q);
+   const int G = gridDim.x;
+   double *sX = smem + eb * PER;  // [c][SX]
+   double *sA = sX + OFF_A;       // [c][SAE]
+   double *sIn = sX + OFF_IN;     // [c][ND]
+   const bool first = a.s->first != 0;
+   bool todo[kVC];
+   double beta[kVC];
+#pragma unroll
+   for (int c = 0; c < kVC; c++)
+   {
+      todo[c] = a.s->done[c] == 0;
+      beta[c] = (first || !todo[c]) ? 0.0 : a.s->rz[c] / a.s->rz_prev[c];
+   }
+   // the 1-D table lives in LDS (thread-dependent rows are read at use: the
+   // persistent kernel is register-, not LDS-limited)
+   __shared__ double sB[Q * D];
+   for (int i = tid; i < Q * D; i += NT) { sB[i] = a.B[i]; }
+   const double *bxp = sB + tx;         // B[tx + Q*d]
+   const double *byp = sB + ty;         // B[ty + Q*d]
+   const double *brxp = sB + Q * (tx < D ? tx : 0); // B[q + Q*tx]
+   const double *bryp = sB + Q * (ty < D ? ty : 0); // B[q + Q*ty]
+
+   // in-flight state of the NEXT batch
+   int mi[GPT];
+   double gz[kVC][GPT], gd[kVC][GPT], dqn[Q];
+   auto load_map = [&](const int b) {
+      const int e0 = b * NEB, nel = min(NEB, a.NE - e0);
+#pragma unroll
+      for (int k = 0; k < GPT; k++)
+      {
+         const int i = tid + k * NT;
+         mi[k] = (i < nel * ND) ? a.map[(size_t)e0 * ND + i] : -1;
+      }
+   };
+   auto load_data = [&](const int b) {
+      const int e = b * NEB + eb;
+#pragma unroll
+      for (int c = 0; c < kVC; c++)
+      {
+         if (!todo[c]) { continue; }
+#pragma unroll
+         for (int k = 0; k < GPT; k++)
+         {
+            gz[c][k] = (mi[k] >= 0) ? a.z[(size_t)c * a.N + mi[k]] : 0.0;
+            gd[c][k] = (mi[k] >= 0 && !first) ? a.d[(size_t)c * a.N + mi[k]] : 0.0;
+         }
+      }
+      if (e < a.NE)
+      {
+         const double *p = a.Dq + (size_t)e * NQ + tx + Q * ty;
+#pragma unroll
+         for (int qz = 0; qz < Q; qz++) { dqn[qz] = p[Q * Q * qz]; }
+      }
+      else
+      {
+#pragma unroll
+         for (int qz = 0; qz < Q; qz++) { dqn[qz] = 0.0; }
+      }
+   };
+
+   double dots[kVC] = {0.0, 0.0, 0.0};
+   int b = xcd_swizzle(blockIdx.x, G);
+   if (b < nbatch)
+   {
+      load_map(b);
+      load_data(b);
+   }
+   for (; b < nbatch; b += G)
+   {
+      const int e0 = b * NEB;
+      const int e = e0 + eb;
+      const bool active = (e < a.NE);
+      // take ownership of the prefetched batch: quadrature data to registers, the
+      // directions d = z + beta d of every active component to LDS (K2 stores the
+      // same values later); after that the prefetch registers are free again
+      double dq[Q];
+#pragma unroll
+      for (int qz = 0; qz < Q; qz++) { dq[qz] = dqn[qz]; }
+      __syncthreads(); // previous batch finished with the LDS buffers
+#pragma unroll
+      for (int c = 0; c < kVC; c++)
+      {
+         if (!todo[c]) { continue; }
+#pragma unroll
+         for (int k = 0; k < GPT; k++)
+         {
+            const int i = tid + k * NT;
+            if (mi[k] >= 0)
+            {
+               const int el = i / ND, dd = i - el * ND;
+               smem[el * PER + OFF_IN + c * ND + dd] = first ? gz[c][k] : gz[c][k] + beta[c] * gd[c][k];
+            }
+         }
+      }
+      const int bn = b + G;
+      const bool have_next = bn < nbatch;
+      if (have_next) { load_map(bn); } // its gathers are issued one stage later
+      __syncthreads();
+      // All active components advance through each stage together: 5 barriers per
+      // batch instead of 5 per component.
+      // forward x: thread (qx = tx, dy = ty < D)
+      double xcol[kVC][D];
+#pragma unroll
+      for (int c = 0; c < kVC; c++)
+      {
+         if (!todo[c]) { continue; }
+         const double *sXc = sIn + c * ND;
+         double *sAc = sA + c * SAE;
+#pragma unroll
+         for (int dz = 0; dz < D; dz++) { xcol[c][dz] = (tx < D && ty < D) ? sXc[tx + D * (ty + D * dz)] : 0.0; }
+         if (ty < D)
+         {
+#pragma unroll
+            for (int dz = 0; dz < D; dz++)
+            {
+               double u = 0.0;
+#pragma unroll
+               for (int dx = 0; dx < D; dx++) { u += bxp[Q * dx] * sXc[dx + D * (ty + D * dz)]; }
+               sAc[tx + Q * (ty + D * dz)] = u;
+            }
+         }
+      }
+      __syncthreads();
+      if (have_next) { load_data(bn); } // map entries have had a stage to arrive
+      // forward y, z; scale by the quadrature data; backward z (registers)
+#pragma unroll
+      for (int c = 0; c < kVC; c++)
+      {
+         if (!todo[c]) { continue; }
+         const double *sAc = sA + c * SAE;
+         double *sCc = sX + c * SX;
+         double bb[D];
+#pragma unroll
+         for (int dz = 0; dz < D; dz++)
+         {
+            double u = 0.0;
+#pragma unroll
+            for (int dy = 0; dy < D; dy++) { u += byp[Q * dy] * sAc[tx + Q * (dy + D * dz)]; }
+            bb[dz] = u;
+         }
+         double qv[Q];
+#pragma unroll
+         for (int qz = 0; qz < Q; qz++)
+         {
+            double u = 0.0;
+#pragma unroll
+            for (int dz = 0; dz < D; dz++) { u += sB[qz + Q * dz] * bb[dz]; }
+            qv[qz] = u * dq[qz];
+         }
+#pragma unroll
+         for (int dz = 0; dz < D; dz++)
+         {
+            double u = 0.0;
+#pragma unroll
+            for (int qz = 0; qz < Q; qz++) { u += sB[qz + Q * dz] * qv[qz]; }
+            sCc[tx + Q * (ty + Q * dz)] = u;
+         }
+      }
+      __syncthreads();
+      // backward x: thread (dx = tx < D, qy = ty)
+      if (tx < D)
+      {
+#pragma unroll
+         for (int c = 0; c < kVC; c++)
+         {
+            if (!todo[c]) { continue; }
+            const double *sCc = sX + c * SX;
+            double *sEc = sA + c * SAE;
+#pragma unroll
+            for (int dz = 0; dz < D; dz++)
+            {
+               double u = 0.0;
+#pragma unroll
+               for (int qx = 0; qx < Q; qx++) { u += brxp[qx] * sCc[qx + Q * (ty + Q * dz)]; }
+               sEc[tx + D * (ty + Q * dz)] = u;
+            }
+         }
+      }
+      __syncthreads();
+      // backward y: thread (dx = tx < D, dy = ty < D)
+      if (tx < D && ty < D && active)
+      {
+#pragma unroll
+         for (int c = 0; c < kVC; c++)
+         {
+            if (!todo[c]) { continue; }
+            const double *sEc = sA + c * SAE;
+            double *yc = a.YE + (size_t)c * a.ye_stride;
+            double dot = 0.0;
+#pragma unroll
+            for (int dz = 0; dz < D; dz++)
+            {
+               double u = 0.0;
+#pragma unroll
+               for (int qy = 0; qy < Q; qy++) { u += bryp[qy] * sEc[tx + D * (qy + Q * dz)]; }
+               yc[tx + D * (ty + D * dz) + (size_t)ND * e] = u;
+               dot += xcol[c][dz] * u;
+            }
+            dots[c] += dot;
+         }
+      }
+   }
+   double bp[kVC];
+#pragma unroll
+   for (int c = 0; c < kVC; c++)
+   {
+      bp[c] = block_sum(dots[c], red);
+      __syncthreads();
+   }
+   double total[kVC];
+   if (grid_sum3_last_block(bp, a.partials, a.stride, a.ticket, red, total))
+   {
+      if (tid == 0)
+      {
+         VcgScalars *s = a.s;
+         for (int c = 0; c < kVC; c++)
+         {
+            if (s->done[c]) { continue; }
+            s->den[c] = total[c];
+            if (total[c] == 0.0 && !a.multi) { s->done[c] = 1; } // breakdown, as upstream
+         }
+         s->first = 0;
+      }
+   }
+}
+
+// ---- init: r = b (x = 0), z = r/diag, nom_c = (z_c, r_c)
+__global__ void __launch_bounds__(256)
+vcg_init_k(const VcgArgs a)
+{
+   __shared__ double red[16];
+   const int n = blockIdx.x * blockDim.x + threadIdx.x;
+   double part[kVC] = {0.0, 0.0, 0.0};
+   if (n < a.N)
+   {
+      const double di = a.dinv[n];
+      const double ow = a.owner ? a.owner[n] : 1.0;
+#pragma unroll
+      for (int c = 0; c < kVC; c++)
+      {
+         const size_t i = (size_t)c * a.N + n;
+         const double rv = a.b[i];
+         a.r[i] = rv;
+         const double zv = rv * di;
+         a.z[i] = zv;
+         part[c] = ow * zv * rv;
+      }
+   }
+   double bp[kVC], total[kVC];
+#pragma unroll
+   for (int c = 0; c < kVC; c++)
+   {
+      bp[c] = block_sum(part[c], red);
+      __syncthreads();
+   }
+   if (grid_sum3_last_block(bp, a.partials, a.stride, a.ticket, red, total))
+   {
+      if (threadIdx.x == 0)
+      {
+         VcgScalars *s = a.s;
+         int all = 1;
+         for (int c = 0; c < kVC; c++)
+         {
+            s->rz[c] = s->rz_prev[c] = total[c];
+            s->iters[c] = 0;
+            if (!a.multi)
+            {
+               s->r0[c] = fmax(total[c] * s->rel_tol2, 0.0);
+               s->done[c] = (total[c] < 0.0 || total[c] <= s->r0[c]) ? 1 : 0;
+               all = all && s->done[c];
+            }
+         }
+         s->first = 1;
+         if (!a.multi) { s->all_done = all; }
+      }
+   }
+}
+__global__ void vcg_init_finish_k(VcgScalars *s)
+{
+   int all = 1;
+   for (int c = 0; c < kVC; c++)
+   {
+      s->rz_prev[c] = s->rz[c];
+      s->r0[c] = fmax(s->rz[c] * s->rel_tol2, 0.0);
+      s->done[c] = (s->rz[c] < 0.0 || s->rz[c] <= s->r0[c]) ? 1 : 0;
+      all = all && s->done[c];
+   }
+   s->all_done = all;
+}
+__global__ void vcg_set_tol_k(VcgScalars *s, double rel_tol2)
+{
+   s->rel_tol2 = rel_tol2;
+   s->all_done = 0;
+   s->first = 1;
+   for (int c = 0; c < kVC; c++) { s->done[c] = 0; s->iters[c] = 0; }
+}
+__global__ void vcg_den_finish_k(VcgScalars *s)
+{
+   for (int c = 0; c < kVC; c++)
+   {
+      if (!s->done[c] && s->den[c] == 0.0) { s->done[c] = 1; }
+   }
+}
+__global__ void vcg_update_finish_k(VcgScalars *s, int iter)
+{
+   int all = 1;
+   for (int c = 0; c < kVC; c++)
+   {
+      if (!s->done[c])
+      {
+         s->iters[c] = iter;
+         if (s->rz[c] < 0.0 || s->rz[c] <= s->r0[c]) { s->done[c] = 1; }
+      }
+      all = all && s->done[c];
+   }
+   s->all_done = all;
+}
+
+// ---- K2: per node and component: z = sum of element contributions, ess rows,
+// d = z_old + beta d, x += alpha d, r -= alpha z, z = r/diag, (r, z)
+template <bool FUSED_GATHER, int DEG>
+__global__ void __launch_bounds__(256)
+vcg_update_k(const VcgArgs a)
+{
+   __shared__ double red[16];
+   if (a.s->all_done) { return; }
+   const bool it1 = (a.iter == 1);
+   const int n = blockIdx.x * blockDim.x + threadIdx.x;
+   const bool ok = n < a.N;
+   const int nn = ok ? n : a.N - 1;
+   double part[kVC] = {0.0, 0.0, 0.0};
+   int pidx[DEG > 0 ? DEG : 1];
+   if (FUSED_GATHER)
+   {
+#pragma unroll
+      for (int j = 0; j < DEG; j++) { pidx[j] = (j < a.deg) ? a.ell[(size_t)j * a.N + nn] : -1; }
+   }
+   const double di = a.dinv[nn];
+   const double ow = a.owner ? a.owner[nn] : 1.0;
+#pragma unroll 1
+   for (int c = 0; c < kVC; c++)
+   {
+      if (a.s->done[c]) { continue; } // uniform
+      const double alpha = a.s->rz[c] / a.s->den[c];
+      const double beta = it1 ? 0.0 : a.s->rz[c] / a.s->rz_prev[c];
+      const size_t i = (size_t)c * a.N + nn;
+      double zv;
+      if (FUSED_GATHER)
+      {
+         const double *yc = a.YE + (size_t)c * a.ye_stride;
+         zv = 0.0;
+#pragma unroll
+         for (int j = 0; j < DEG; j++) { if (pidx[j] >= 0) { zv += yc[pidx[j]]; } }
+      }
+      else { zv = a.yL[i]; }
+      if (a.ess[c] && a.ess[c][nn]) { zv = 0.0; }
+      double dv = a.z[i];
+      if (!it1) { dv += beta * a.d[i]; }
+      const double xv = a.x[i] + alpha * dv;
+      const double rv = a.r[i] - alpha * zv;
+      const double pz = rv * di;
+      if (ok)
+      {
+         a.d[i] = dv;
+         a.x[i] = xv;
+         a.r[i] = rv;
+         a.z[i] = pz;
+         part[c] = ow * rv * pz;
+      }
+   }
+   double bp[kVC], total[kVC];
+#pragma unroll
+   for (int c = 0; c < kVC; c++)
+   {
+      bp[c] = block_sum(part[c], red);
+      __syncthreads();
+   }
+   if (grid_sum3_last_block(bp, a.partials, a.stride, a.ticket, red, total))
+   {
+      if (threadIdx.x == 0)
+      {
+         VcgScalars *s = a.s;
+         int all = 1;
+         for (int c = 0; c < kVC; c++)
+         {
+            if (!s->done[c])
+            {
+               s->rz_prev[c] = s->rz[c];
+               s->rz[c] = total[c]; // betanom
+               if (!a.multi)
+               {
+                  s->iters[c] = a.iter;
+                  if (total[c] < 0.0 || total[c] <= s->r0[c]) { s->done[c] = 1; }
+               }
+            }
+            all = all && s->done[c];
+         }
+         if (!a.multi) { s->all_done = all; }
+      }
+   }
+}
+
+// unfused E -> L sum of the kVC planes (multi-GPU path, unusual valence)
+__global__ void __launch_bounds__(256)
+vcg_gather_k(const VcgArgs a)
+{
+   const int n = blockIdx.x * blockDim.x + threadIdx.x;
+   if (n >= a.N) { return; }
+   for (int c = 0; c < kVC; c++)
+   {
+      if (a.s->done[c]) { continue; }
+      const double *yc = a.YE + (size_t)c * a.ye_stride;
+      double s = 0.0;
+      for (int j = 0; j < a.deg; j++)
+      {
+         const int p = a.ell[(size_t)j * a.N + n];
+         if (p >= 0) { s += yc[p]; }
+      }
+      a.yL[(size_t)c * a.N + n] = s;
+   }
+}
+
+// ---- host side -----------------------------------------------------------------------
+static bool vcg_supported(const lgh_ctx *c)
+{
+   if (c->dim != 3) { return false; }
+   switch (c->kid)
+   {
+      case 0x322: case 0x334: case 0x346: case 0x358: case 0x36A: return true;
+   }
+   return false;
+}
+
+template <int D, int Q> static void launch_vcg_apply(lgh_ctx *c, const VcgArgs &a)
+{
+   constexpr int NEB = (256 / (Q * Q)) > 0 ? (256 / (Q * Q)) : 1;
+   const int nbatch = ceil_div(c->NE, NEB);
+   // one resident wave of workgroups (occupancy query is cached per context)
+   if (c->vcg_grid <= 0)
+   {
+      int per_cu = 0, ncu = 256;
+      hipDeviceProp_t prop;
+      if (hipGetDeviceProperties(&prop, c->device) == hipSuccess) { ncu = prop.multiProcessorCount; }
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, vcg_apply_3d<D, Q, NEB>, Q * Q * NEB, 0) != hipSuccess || per_cu <= 0)
+      {
+         per_cu = 2;
+      }
+      c->vcg_grid = per_cu * ncu;
+   }
+   const int grid = std::min(nbatch, c->vcg_grid);
+   hipLaunchKernelGGL((vcg_apply_3d<D, Q, NEB>), dim3(grid), dim3(Q * Q * NEB), 0, c->stream, a, nbatch);
+}
+
+// B, X: dim*N (byNODES).  X must be zero on entry (dv = 0, laghos_solver.cpp:338, :382).
+// iters[c] = GetNumIterations() of component c.
+int vcg_solve(lgh_ctx *c, const double *B, double *X, double rel_tol, int max_iter, int iters[3])
+{
+   if (!vcg_supported(c)) { return LGH_ERR_UNSUPPORTED; }
+   const bool multi = c->nranks > 1;
+   const size_t N = (size_t)c->N;
+   int rc;
+   if (!c->vcg_s)
+   {
+      LGH_HIP_CHECK(hipMalloc((void **)&c->vcg_s, sizeof(VcgScalars)));
+      LGH_HIP_CHECK(hipMemset(c->vcg_s, 0, sizeof(VcgScalars)));
+      LGH_HIP_CHECK(hipMalloc((void **)&c->vcg_vec, 4 * kVC * N * sizeof(double))); // r, z, d, yL
+      LGH_HIP_CHECK(hipMemset(c->vcg_vec, 0, 4 * kVC * N * sizeof(double)));
+      c->vcg_stride = (unsigned)(std::max<size_t>((size_t)c->NE, (N + 255) / 256) + kShards);
+      LGH_HIP_CHECK(hipMalloc((void **)&c->vcg_partials, 2 * kVC * (size_t)c->vcg_stride * sizeof(double)));
+      LGH_HIP_CHECK(hipMemset(c->vcg_partials, 0, 2 * kVC * (size_t)c->vcg_stride * sizeof(double)));
+      LGH_HIP_CHECK(hipMalloc((void **)&c->vcg_tickets, 2 * kTicketSlot * sizeof(unsigned int)));
+      LGH_HIP_CHECK(hipMemset(c->vcg_tickets, 0, 2 * kTicketSlot * sizeof(unsigned int)));
+   }
+   VcgScalars *ds = (VcgScalars *)c->vcg_s;
+   hipLaunchKernelGGL(vcg_set_tol_k, dim3(1), dim3(1), 0, c->stream, ds, rel_tol * rel_tol);
+
+   VcgArgs a;
+   memset(&a, 0, sizeof(a));
+   a.NE = c->NE;
+   a.N = c->N;
+   a.B = c->B;
+   a.Dq = c->massD;
+   a.map = c->h1map;
+   a.ell = c->t_ell;
+   a.deg = c->t_deg;
+   for (int k = 0; k < kVC; k++) { a.ess[k] = c->essmask[k]; }
+   a.dinv = c->dinvV;
+   a.owner = multi ? c->owner : nullptr;
+   a.b = B;
+   a.x = X;
+   a.r = c->vcg_vec;
+   a.z = c->vcg_vec + kVC * N;
+   a.d = c->vcg_vec + 2 * kVC * N;
+   a.yL = c->vcg_vec + 3 * kVC * N;
+   a.YE = c->YE;
+   a.ye_stride = (size_t)c->NE * c->ND;
+   a.s = ds;
+   a.stride = c->vcg_stride;
+   a.multi = multi ? 1 : 0;
+   const int nb = ceil_div((long)N, 256);
+
+   // init (vector kernels use reduction slot 0, the element kernel slot 1)
+   a.partials = c->vcg_partials;
+   a.ticket = c->vcg_tickets;
+   hipLaunchKernelGGL(vcg_init_k, dim3(nb), dim3(256), 0, c->stream, a);
+   LGH_HIP_CHECK(hipGetLastError());
+   if (multi)
+   {
+      rc = allreduce_dev(c, ds->rz, kVC, 0);
+      if (rc) { return rc; }
+      hipLaunchKernelGGL(vcg_init_finish_k, dim3(1), dim3(1), 0, c->stream, ds);
+   }
+
+   VcgScalars *hs = (VcgScalars *)(c->host_pinned + 32);
+   static_assert(sizeof(VcgScalars) <= 32 * sizeof(double), "pinned staging too small");
+   int it = 0;
+   // first chunk = iteration count of the previous velocity solve (see cg_solve)
+   int chunk = c->vcg_last > 0 ? c->vcg_last : 8;
+   bool first_look = true;
+   while (true)
+   {
+      LGH_HIP_CHECK(hipMemcpyAsync(hs, ds, sizeof(VcgScalars), hipMemcpyDeviceToHost, c->stream));
+      LGH_HIP_CHECK(hipStreamSynchronize(c->stream));
+      if (hs->all_done || it >= max_iter) { break; }
+      if (!first_look) { chunk = 2; }
+      first_look = false;
+      const int upto = std::min(max_iter, it + chunk);
+      while (it < upto)
+      {
+         ++it;
+         a.iter = it;
+         a.partials = c->vcg_partials + (size_t)kVC * c->vcg_stride;
+         a.ticket = c->vcg_tickets + kTicketSlot;
+         kt_begin(c, LGH_KERNEL_MASS_CG_H1);
+         switch (c->kid)
+         {
+            case 0x322: launch_vcg_apply<2, 2>(c, a); break;
+            case 0x334: launch_vcg_apply<3, 4>(c, a); break;
+            case 0x346: launch_vcg_apply<4, 6>(c, a); break;
+            case 0x358: launch_vcg_apply<5, 8>(c, a); break;
+            case 0x36A: launch_vcg_apply<6, 10>(c, a); break;
+         }
+         kt_end(c, LGH_KERNEL_MASS_CG_H1);
+         LGH_HIP_CHECK(hipGetLastError());
+         a.partials = c->vcg_partials;
+         a.ticket = c->vcg_tickets;
+         if (!multi && c->t_deg <= 8)
+         {
+            kt_begin(c, LGH_KERNEL_CG_UPDATE_H1);
+            hipLaunchKernelGGL((vcg_update_k<true, 8>), dim3(nb), dim3(256), 0, c->stream, a);
+            kt_end(c, LGH_KERNEL_CG_UPDATE_H1);
+         }
+         else
+         {
+            // assemble the L-vectors, sum shared nodes across ranks, all-reduce the scalars
+            hipLaunchKernelGGL(vcg_gather_k, dim3(nb), dim3(256), 0, c->stream, a);
+            LGH_HIP_CHECK(hipGetLastError());
+            if (multi)
+            {
+               rc = halo_sum(c, a.yL, kVC);
+               if (rc) { return rc; }
+               rc = allreduce_dev(c, ds->den, kVC, 0);
+               if (rc) { return rc; }
+               hipLaunchKernelGGL(vcg_den_finish_k, dim3(1), dim3(1), 0, c->stream, ds);
+            }
+            hipLaunchKernelGGL((vcg_update_k<false, 0>), dim3(nb), dim3(256), 0, c->stream, a);
+            if (multi)
+            {
+               rc = allreduce_dev(c, ds->rz, kVC, 0);
+               if (rc) { return rc; }
+               hipLaunchKernelGGL(vcg_update_finish_k, dim3(1), dim3(1), 0, c->stream, ds, it);
+            }
+         }
+         LGH_HIP_CHECK(hipGetLastError());
+      }
+   }
+   int mx = 0;
+   for (int k = 0; k < kVC; k++)
+   {
+      // upstream: final_iter = max_iter when the loop runs out without converging
+      int fin = hs->iters[k];
+      if (!hs->done[k] && it >= max_iter) { fin = max_iter; }
+      iters[k] = fin;
+      mx = std::max(mx, fin);
+   }
+   c->vcg_last = mx;
+   return LGH_OK;
+}
+
+} // namespace lgh
