@@ -184,6 +184,12 @@ int lgh_allreduce(lgh_ctx *ctx, double *value, int op);
 int lgh_force_mult_E(lgh_ctx *ctx, const double *sJit, const double *x_E, double *y_E);
 int lgh_force_mult_transpose_E(lgh_ctx *ctx, const double *sJit, const double *v_E, double *y_E);
 int lgh_mass_apply_E(lgh_ctx *ctx, int space, const double *x_E, double *y_E);
+/* halo pieces without the RCCL transport (tests emulate the exchange between
+ * several contexts on one GPU): rank bookkeeping, pack into / combine from caller
+ * buffers of 3*total doubles laid out as the send / receive buffers are. */
+int lgh_test_set_rank(lgh_ctx *ctx, int nranks, int rank);
+int lgh_test_halo_pack(lgh_ctx *ctx, const double *v_h1, int ncomp, double *sendbuf_out);
+int lgh_test_halo_combine(lgh_ctx *ctx, const double *recvbuf_in, double *v_h1, int ncomp);
 /* device small-matrix probes: n matrices (column-major, 9 or 4 doubles each) */
 int lgh_test_eig(lgh_ctx *ctx, int dim, int n, const double *A, double *lambda, double *vec);
 int lgh_test_singular(lgh_ctx *ctx, int dim, int n, const double *A, double *sv_min);

@@ -82,6 +82,9 @@ SYMBOLS = {
     "lgh_force_mult_E": (_I, [_P, _P, _P, _P]),
     "lgh_force_mult_transpose_E": (_I, [_P, _P, _P, _P]),
     "lgh_mass_apply_E": (_I, [_P, _I, _P, _P]),
+    "lgh_test_set_rank": (_I, [_P, _I, _I]),
+    "lgh_test_halo_pack": (_I, [_P, _P, _I, _P]),
+    "lgh_test_halo_combine": (_I, [_P, _P, _P, _I]),
     "lgh_test_eig": (_I, [_P, _I, _I, _P, _P, _P]),
     "lgh_test_singular": (_I, [_P, _I, _I, _P, _P]),
 }
@@ -89,10 +92,22 @@ SYMBOLS = {
 _lib = None
 
 
+def _preload_torch_hip():
+    """torch bundles its own libamdhip64; if this library pulled in /opt/rocm's copy
+    first, a later `import torch` would bring a second HIP runtime into the process
+    and fail with "No HIP GPUs are available".  Importing torch first makes both
+    share one runtime (the standalone `laghos` executable does not involve torch)."""
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
+
+
 def load():
     """Load liblaghos_hip.so; raises RuntimeError when the extension is missing."""
     global _lib
     if _lib is None:
+        _preload_torch_hip()
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "

@@ -250,6 +250,15 @@ class Context:
         arr = (ip * max(n, 1))(*[l.ctypes.data_as(ip) for l in lists])
         check(self.lib.lgh_comm_set_neighbors(self.h, n, ranks.ctypes.data_as(ip), counts.ctypes.data_as(ip), arr))
 
+    def test_set_rank(self, nranks, rank):
+        check(self.lib.lgh_test_set_rank(self.h, nranks, rank))
+
+    def test_halo_pack(self, v, ncomp, out):
+        check(self.lib.lgh_test_halo_pack(self.h, _ptr(v), ncomp, _ptr(out)))
+
+    def test_halo_combine(self, inp, v, ncomp):
+        check(self.lib.lgh_test_halo_combine(self.h, _ptr(inp), _ptr(v), ncomp))
+
     def halo_sum(self, v, ncomp):
         check(self.lib.lgh_halo_sum(self.h, _ptr(v), ncomp))
 

@@ -357,7 +357,7 @@ int lgh_force_mult(lgh_ctx *c, const double *x_l2, double *y_h1)
    if (rc) { return rc; }
    rc = h1_transpose_gather(c, c->dim, c->YE, y_h1); // H1R->MultTranspose (:564)
    if (rc) { return rc; }
-   if (c->nranks > 1) { rc = halo_sum(c, y_h1, c->dim); }
+   if (c->multi != 0) { rc = halo_sum(c, y_h1, c->dim); }
    return rc;
 }
 int lgh_force_mult_transpose(lgh_ctx *c, const double *v_h1, double *y_l2)

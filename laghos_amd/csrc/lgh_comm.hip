@@ -14,6 +14,7 @@
 // RCCL is resolved with dlopen at lgh_comm_init time so that the same library
 // loads on a host without RCCL (and reuses torch's copy when already loaded).
 #include <dlfcn.h>
+#include <cstdlib>
 
 #include <algorithm>
 #include <utility>
@@ -95,25 +96,32 @@ struct Comm
    double *sendbuf = nullptr, *recvbuf = nullptr; // device: total * 3 doubles
    int n_shared = 0;                               // unique shared nodes
    int *sh_node = nullptr, *sh_off = nullptr, *sh_src = nullptr; // device CSR (see halo_combine_k)
+   int *pos = nullptr, *cnt = nullptr; // per concatenated entry: buffer position, neighbour count
 };
 
+// Buffers: neighbour k owns the contiguous block [3*off_k, 3*off_k + ncomp*cnt_k):
+// component-major inside the block, so every neighbour is ONE send and ONE recv.
+// pos[j] = 3*off_k + i for entry j = off_k + i of the concatenated node lists;
+// cnt[j] = cnt_k.
 __global__ void __launch_bounds__(256)
 halo_pack_k(const int total, const int ncomp, const int N, const int *__restrict__ nodes,
-            const double *__restrict__ v, double *__restrict__ buf)
+            const int *__restrict__ pos, const int *__restrict__ cnt, const double *__restrict__ v,
+            double *__restrict__ buf)
 {
    const int i = blockIdx.x * blockDim.x + threadIdx.x;
    if (i >= total * ncomp) { return; }
-   const int c = i / total, k = i - c * total;
-   buf[i] = v[(size_t)c * N + nodes[k]];
+   const int c = i / total, j = i - c * total;
+   buf[(size_t)pos[j] + (size_t)c * cnt[j]] = v[(size_t)c * N + nodes[j]];
 }
 // Canonical sum of a shared node: contributions are added in ascending rank
 // order (own value at its rank's position), so every rank holding the node
 // computes bit-identical results, as MFEM's GroupCommunicator does.  CSR over the
-// unique shared nodes; src >= 0: index into the receive buffer, -1: own value.
+// unique shared nodes; src >= 0: entry j of the concatenated lists, -1: own value.
 __global__ void __launch_bounds__(256)
-halo_combine_k(const int n_shared, const int total, const int ncomp, const int N,
-               const int *__restrict__ sh_node, const int *__restrict__ sh_off,
-               const int *__restrict__ sh_src, const double *__restrict__ buf, double *__restrict__ v)
+halo_combine_k(const int n_shared, const int ncomp, const int N, const int *__restrict__ sh_node,
+               const int *__restrict__ sh_off, const int *__restrict__ sh_src,
+               const int *__restrict__ pos, const int *__restrict__ cnt,
+               const double *__restrict__ buf, double *__restrict__ v)
 {
    const int i = blockIdx.x * blockDim.x + threadIdx.x;
    if (i >= n_shared * ncomp) { return; }
@@ -122,8 +130,8 @@ halo_combine_k(const int n_shared, const int total, const int ncomp, const int N
    double s = 0.0;
    for (int k = sh_off[u]; k < sh_off[u + 1]; k++)
    {
-      const int src = sh_src[k];
-      const double val = (src < 0) ? v[(size_t)c * N + node] : buf[(size_t)c * total + src];
+      const int j = sh_src[k];
+      const double val = (j < 0) ? v[(size_t)c * N + node] : buf[(size_t)pos[j] + (size_t)c * cnt[j]];
       s = (k == sh_off[u]) ? val : s + val;
    }
    v[(size_t)c * N + node] = s;
@@ -132,26 +140,24 @@ halo_combine_k(const int n_shared, const int total, const int ncomp, const int N
 int halo_sum(lgh_ctx *c, double *v, int ncomp)
 {
    Comm *cm = c->comm;
-   if (!cm || c->nranks <= 1 || cm->n_nbr == 0) { return LGH_OK; }
+   if (!cm || cm->n_nbr == 0) { return LGH_OK; }
    if (ncomp > 3) { set_error("halo_sum: ncomp > 3"); return LGH_ERR_ARG; }
    const int tot = cm->total;
    hipLaunchKernelGGL(halo_pack_k, dim3(ceil_div((long)tot * ncomp, 256)), dim3(256), 0, c->stream, tot,
-                      ncomp, c->N, cm->nodes, v, cm->sendbuf);
+                      ncomp, c->N, cm->nodes, cm->pos, cm->cnt, v, cm->sendbuf);
    LGH_HIP_CHECK(hipGetLastError());
    LGH_NCCL_CHECK(g_nccl.GroupStart());
-   for (int comp = 0; comp < ncomp; comp++)
+   for (int k = 0; k < cm->n_nbr; k++)
    {
-      for (int k = 0; k < cm->n_nbr; k++)
-      {
-         const size_t o = (size_t)comp * tot + cm->nbr_off[k];
-         LGH_NCCL_CHECK(g_nccl.Send(cm->sendbuf + o, cm->nbr_count[k], ncclFloat64, cm->nbr_rank[k], cm->comm, c->stream));
-         LGH_NCCL_CHECK(g_nccl.Recv(cm->recvbuf + o, cm->nbr_count[k], ncclFloat64, cm->nbr_rank[k], cm->comm, c->stream));
-      }
+      const size_t o = 3 * (size_t)cm->nbr_off[k];
+      const size_t n = (size_t)ncomp * cm->nbr_count[k];
+      LGH_NCCL_CHECK(g_nccl.Send(cm->sendbuf + o, n, ncclFloat64, cm->nbr_rank[k], cm->comm, c->stream));
+      LGH_NCCL_CHECK(g_nccl.Recv(cm->recvbuf + o, n, ncclFloat64, cm->nbr_rank[k], cm->comm, c->stream));
    }
    LGH_NCCL_CHECK(g_nccl.GroupEnd());
    hipLaunchKernelGGL(halo_combine_k, dim3(ceil_div((long)cm->n_shared * ncomp, 256)), dim3(256), 0,
-                      c->stream, cm->n_shared, tot, ncomp, c->N, cm->sh_node, cm->sh_off, cm->sh_src,
-                      cm->recvbuf, v);
+                      c->stream, cm->n_shared, ncomp, c->N, cm->sh_node, cm->sh_off, cm->sh_src, cm->pos,
+                      cm->cnt, cm->recvbuf, v);
    LGH_HIP_CHECK(hipGetLastError());
    return LGH_OK;
 }
@@ -159,7 +165,7 @@ int halo_sum(lgh_ctx *c, double *v, int ncomp)
 int allreduce_dev(lgh_ctx *c, double *dev, int count, int op)
 {
    Comm *cm = c->comm;
-   if (!cm || c->nranks <= 1) { return LGH_OK; }
+   if (!cm || !cm->comm) { return LGH_OK; }
    LGH_NCCL_CHECK(g_nccl.AllReduce(dev, dev, (size_t)count, ncclFloat64, op == 0 ? ncclSum : ncclMin, cm->comm, c->stream));
    return LGH_OK;
 }
@@ -176,7 +182,7 @@ void lgh_comm_free(lgh_ctx *c)
    if (!c || !c->comm) { return; }
    Comm *cm = c->comm;
    if (cm->comm && g_nccl.CommDestroy) { g_nccl.CommDestroy(cm->comm); }
-   void *ptrs[] = {cm->nodes, cm->sendbuf, cm->recvbuf, cm->sh_node, cm->sh_off, cm->sh_src};
+   void *ptrs[] = {cm->nodes, cm->sendbuf, cm->recvbuf, cm->sh_node, cm->sh_off, cm->sh_src, cm->pos, cm->cnt};
    for (void *p : ptrs) { if (p) { (void)hipFree(p); } }
    delete cm;
    c->comm = nullptr;
@@ -205,6 +211,10 @@ int lgh_comm_init(lgh_ctx *c, int nranks, int rank, const char unique_id[128])
    LGH_NCCL_CHECK(g_nccl.CommInitRank(&c->comm->comm, nranks, id, rank));
    c->nranks = nranks;
    c->rank = rank;
+   {
+      const char *env = getenv("LGH_FORCE_MULTI");
+      c->multi = (nranks > 1 || (env && env[0] == '1')) ? 1 : 0;
+   }
    return LGH_OK;
 }
 
@@ -269,11 +279,55 @@ int lgh_comm_set_neighbors(lgh_ctx *c, int n_nbr, const int *nbr_rank, const int
       LGH_HIP_CHECK(hipMemcpy(cm->sh_off, off.data(), off.size() * sizeof(int), hipMemcpyHostToDevice));
       if (!src.empty()) { LGH_HIP_CHECK(hipMemcpy(cm->sh_src, src.data(), src.size() * sizeof(int), hipMemcpyHostToDevice)); }
    }
-   if (cm->nodes) { (void)hipFree(cm->nodes); (void)hipFree(cm->sendbuf); (void)hipFree(cm->recvbuf); }
+   if (cm->nodes) { (void)hipFree(cm->nodes); (void)hipFree(cm->sendbuf); (void)hipFree(cm->recvbuf); (void)hipFree(cm->pos); (void)hipFree(cm->cnt); }
+   {
+      std::vector<int> pos(std::max(tot, 1)), cnt(std::max(tot, 1));
+      for (int k = 0; k < n_nbr; k++)
+         for (int i = 0; i < nbr_count[k]; i++)
+         {
+            pos[cm->nbr_off[k] + i] = 3 * cm->nbr_off[k] + i;
+            cnt[cm->nbr_off[k] + i] = nbr_count[k];
+         }
+      LGH_HIP_CHECK(hipMalloc((void **)&cm->pos, pos.size() * sizeof(int)));
+      LGH_HIP_CHECK(hipMalloc((void **)&cm->cnt, cnt.size() * sizeof(int)));
+      LGH_HIP_CHECK(hipMemcpy(cm->pos, pos.data(), pos.size() * sizeof(int), hipMemcpyHostToDevice));
+      LGH_HIP_CHECK(hipMemcpy(cm->cnt, cnt.data(), cnt.size() * sizeof(int), hipMemcpyHostToDevice));
+   }
    LGH_HIP_CHECK(hipMalloc((void **)&cm->nodes, std::max<size_t>(tot, 1) * sizeof(int)));
    if (tot) { LGH_HIP_CHECK(hipMemcpy(cm->nodes, all.data(), (size_t)tot * sizeof(int), hipMemcpyHostToDevice)); }
    LGH_HIP_CHECK(hipMalloc((void **)&cm->sendbuf, std::max<size_t>(tot, 1) * 3 * sizeof(double)));
    LGH_HIP_CHECK(hipMalloc((void **)&cm->recvbuf, std::max<size_t>(tot, 1) * 3 * sizeof(double)));
+   return LGH_OK;
+}
+
+int lgh_test_set_rank(lgh_ctx *c, int nranks, int rank)
+{
+   LGH_CHECK_ARG(c && nranks >= 1 && rank >= 0 && rank < nranks);
+   c->nranks = nranks;
+   c->rank = rank;
+   return LGH_OK;
+}
+int lgh_test_halo_pack(lgh_ctx *c, const double *v, int ncomp, double *out)
+{
+   LGH_CHECK_ARG(c && v && out && c->comm && ncomp >= 1 && ncomp <= 3);
+   Comm *cm = c->comm;
+   if (cm->total == 0) { return LGH_OK; }
+   hipLaunchKernelGGL(halo_pack_k, dim3(ceil_div((long)cm->total * ncomp, 256)), dim3(256), 0, c->stream,
+                      cm->total, ncomp, c->N, cm->nodes, cm->pos, cm->cnt, v, cm->sendbuf);
+   LGH_HIP_CHECK(hipGetLastError());
+   LGH_HIP_CHECK(hipMemcpyAsync(out, cm->sendbuf, 3 * (size_t)cm->total * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+   return LGH_OK;
+}
+int lgh_test_halo_combine(lgh_ctx *c, const double *in, double *v, int ncomp)
+{
+   LGH_CHECK_ARG(c && v && in && c->comm && ncomp >= 1 && ncomp <= 3);
+   Comm *cm = c->comm;
+   if (cm->total == 0) { return LGH_OK; }
+   LGH_HIP_CHECK(hipMemcpyAsync(cm->recvbuf, in, 3 * (size_t)cm->total * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+   hipLaunchKernelGGL(halo_combine_k, dim3(ceil_div((long)cm->n_shared * ncomp, 256)), dim3(256), 0, c->stream,
+                      cm->n_shared, ncomp, c->N, cm->sh_node, cm->sh_off, cm->sh_src, cm->pos, cm->cnt,
+                      cm->recvbuf, v);
+   LGH_HIP_CHECK(hipGetLastError());
    return LGH_OK;
 }
 
@@ -286,7 +340,7 @@ int lgh_halo_sum(lgh_ctx *c, double *v_h1, int ncomp)
 int lgh_allreduce(lgh_ctx *c, double *value, int op)
 {
    LGH_CHECK_ARG(c && value);
-   if (c->nranks <= 1 || !c->comm) { return LGH_OK; }
+   if (!c->multi || !c->comm) { return LGH_OK; }
    LGH_HIP_CHECK(hipMemcpyAsync(c->scal + 2, value, sizeof(double), hipMemcpyHostToDevice, c->stream));
    int rc = allreduce_dev(c, c->scal + 2, 1, op);
    if (rc) { return rc; }

@@ -127,6 +127,7 @@ struct lgh_ctx
    int cg_last_iters[2][3]; // iteration count of the previous solve per (space, component)
    lgh::Comm *comm;
    int nranks, rank;
+   int multi;            // 1: run the multi-rank code path (nranks > 1, or LGH_FORCE_MULTI=1 for testing on one GPU)
 };
 
 namespace lgh

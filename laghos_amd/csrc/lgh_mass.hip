@@ -435,7 +435,7 @@ int mass_apply_h1(lgh_ctx *c, const double *x, double *y, bool eliminate)
    a.y = c->YE;
    int rc = launch_mass<1>(c, LGH_SPACE_H1, a);
    if (rc) { return rc; }
-   const bool multi = (c->nranks > 1);
+   const bool multi = (c->multi != 0);
    const uint8_t *ess = (eliminate && c->cur_ess >= 0 && !multi) ? c->essmask[c->cur_ess] : nullptr;
    hipLaunchKernelGGL(mass_gather_k, dim3(ceil_div(c->N, 256)), dim3(256), 0, c->stream, c->N,
                       c->t_deg, c->t_ell, c->YE, ess, y);
@@ -520,7 +520,7 @@ int mass_assemble_diag(lgh_ctx *c)
    hipLaunchKernelGGL(mass_gather_k, dim3(ceil_div(c->N, 256)), dim3(256), 0, c->stream, c->N,
                       c->t_deg, c->t_ell, c->YE, (const uint8_t *)nullptr, c->diagV);
    LGH_HIP_CHECK(hipGetLastError());
-   if (c->nranks > 1)
+   if (c->multi != 0)
    {
       int rc = halo_sum(c, c->diagV, 1);
       if (rc) { return rc; }
@@ -748,7 +748,7 @@ int cg_solve(lgh_ctx *c, int space, const double *b, double *x, double rel_tol, 
 {
    const bool h1 = (space == LGH_SPACE_H1);
    const int n = h1 ? c->N : c->L2V;
-   const bool multi = (c->nranks > 1);
+   const bool multi = (c->multi != 0);
    int rc;
    hipLaunchKernelGGL(cg_set_tol_k, dim3(1), dim3(1), 0, c->stream, c->cgs, rel_tol * rel_tol);
 

@@ -580,7 +580,7 @@ int interp_energy(lgh_ctx *c, int which, const double *vec, double *result)
       rc = launch_q<QMODE_KE>(c, a);
    }
    if (rc) { return rc; }
-   if (c->nranks > 1)
+   if (c->multi != 0)
    {
       rc = allreduce_dev(c, c->scal, 1, 0);
       if (rc) { return rc; }

@@ -603,7 +603,7 @@ template <int D, int Q> static void launch_vcg_apply(lgh_ctx *c, const VcgArgs &
 int vcg_solve(lgh_ctx *c, const double *B, double *X, double rel_tol, int max_iter, int iters[3])
 {
    if (!vcg_supported(c)) { return LGH_ERR_UNSUPPORTED; }
-   const bool multi = c->nranks > 1;
+   const bool multi = c->multi != 0;
    const size_t N = (size_t)c->N;
    int rc;
    if (!c->vcg_s)

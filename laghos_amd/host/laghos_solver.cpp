@@ -4,6 +4,7 @@
 #include "laghos_solver.hpp"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <iomanip>
 #include <iostream>
@@ -50,7 +51,12 @@ LagrangianHydroOperator::LagrangianHydroOperator(const Discretization &d, const 
       cfg.ess_count[c] = (c < dim) ? (int)d.ess[c].size() : 0;
       cfg.ess[c] = (c < dim) ? d.ess[c].data() : nullptr;
    }
-   const bool multi = d.part.nranks > 1;
+   // LGH_FORCE_MULTI=1 drives the multi-rank code path (unfused E->L sums, RCCL
+   // all-reduces of the device scalars) with a communicator of size 1: this is how
+   // that path is exercised on a single-GPU box.
+   const char *force_env = std::getenv("LGH_FORCE_MULTI");
+   const bool force_multi = (force_env && force_env[0] == '1' && d.part.nranks == 1);
+   const bool multi = d.part.nranks > 1 || force_multi;
    cfg.owner = multi ? d.owner.data() : nullptr;
    cfg.use_viscosity = d.UseViscosity();
    cfg.use_vorticity = 0;
@@ -61,6 +67,12 @@ LagrangianHydroOperator::LagrangianHydroOperator(const Discretization &d, const 
    LGH_VERIFY(lgh_create(&cfg, &ctx));
    if (multi)
    {
+      char self_id[128];
+      if (!nccl_id && force_multi)
+      {
+         LGH_VERIFY(lgh_comm_unique_id(self_id));
+         nccl_id = self_id;
+      }
       if (!nccl_id) { std::fprintf(stderr, "multi-rank run needs an RCCL unique id\n"); std::abort(); }
       LGH_VERIFY(lgh_comm_init(ctx, d.part.nranks, d.part.rank, nccl_id));
       std::vector<int> cnt;

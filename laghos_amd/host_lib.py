@@ -11,9 +11,21 @@ LIB_PATH = os.path.join(_HERE, "liblaghos_host.so")
 _lib = None
 
 
+def _preload_torch_hip():
+    """torch bundles its own libamdhip64; if this library pulled in /opt/rocm's copy
+    first, a later `import torch` would bring a second HIP runtime into the process
+    and fail with "No HIP GPUs are available".  Importing torch first makes both
+    share one runtime (the standalone `laghos` executable does not involve torch)."""
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
+
+
 def load():
     global _lib
     if _lib is None:
+        _preload_torch_hip()
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(f"{LIB_PATH} is missing: run __graft_entry__.build()")
         L = ctypes.CDLL(LIB_PATH)
