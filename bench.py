@@ -203,12 +203,12 @@ def main():
         NQ, ND, NL = sz["NQ"], D ** dim, Ld ** dim
         bytes_per_elem = {
             _lib_id: b for _lib_id, b in (
-                (0, 8 * (NQ + 2 * ND)),                              # mass apply (scalar H1): D + in + out
+                (0, 8 * (NQ + dim * 2 * ND)),                        # lockstep mass apply: D once + (in + out) per component
                 (2, 8 * (2 * dim * ND + NL + dim * dim * NQ + NQ + dim * dim * NQ) + 8),  # fused QUpdate
                 (3, 8 * (dim * dim * NQ + NL + dim * ND)),            # ForceMult
                 (4, 8 * (dim * dim * NQ + NL + dim * ND)),            # ForceMultTranspose
             )}
-        names = {0: "mass_apply_3d<MODE 2> (H1 CG K1)", 2: "qpoint_kernel (fused QUpdate)",
+        names = {0: "vcg_apply_3d (H1 CG K1, 3 velocity components per launch)", 2: "qpoint_kernel (fused QUpdate)",
                  3: "force_mult_3d", 4: "force_mult_t_3d"}
         kern = {}
         for kid in (0, 2, 3, 4):
