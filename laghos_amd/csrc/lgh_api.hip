@@ -230,6 +230,8 @@ int lgh_create(const lgh_config *cfg, lgh_ctx **out)
       LGH_TRY(dev_alloc_copy(&c->t_ell, ell.data(), ell.size()));
       const char *env = getenv("LGH_ATOMIC_SCATTER");
       c->atomic_scatter = (env && env[0] == '1') ? 1 : 0;
+      env = getenv("LGH_VCG_VARIANT"); // A/B switch of the lockstep K1 (lgh_vcg.hip)
+      c->vcg_variant = (env && env[0] >= '0' && env[0] <= '2') ? env[0] - '0' : 2;
    }
    for (int k = 0; k < 3; k++)
    {

@@ -121,6 +121,7 @@ struct lgh_ctx
    unsigned vcg_stride;
    int vcg_last;
    int vcg_grid;         // persistent grid size of the K1 kernel (one resident wave)
+   int vcg_variant;      // LGH_VCG_VARIANT: which K1 form vcg_solve launches (lgh_vcg.hip)
 
    lgh::Timers timers;
    lgh::KTime *ktime;

@@ -371,6 +371,277 @@ vcg_apply_3d(const VcgArgs a, const int nbatch)
    }
 }
 
+// ---- K1, plane-per-thread form --------------------------------------------------
+// The (qx, qy)-column form above is bound by LDS bandwidth: every contraction
+// stage re-reads its operands (and the 1-D table) from LDS, 474 doubles per thread
+// and batch, which at 128 B/clk/CU is 80 % of its run time.  Here a thread owns
+// one x-index of one component of one element and keeps the whole (y, z) plane of
+// that index in registers: only the two x contractions exchange data through LDS
+// (64 + 96 doubles read per thread), the y and z contractions and the scaling by
+// the quadrature data run on registers with the 1-D table in scalar registers
+// (its indices are loop constants there), i.e. as FMAs with an SGPR operand.
+__device__ __forceinline__ double uniform_f64(const double v)
+{
+   const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+   const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+   return __hiloint2double(hi, lo);
+}
+
+template <int D, int Q, int NEB, bool DQ_LDS>
+__global__ void __launch_bounds__(kVC *Q *NEB, DQ_LDS ? 2 : 1)
+vcg_apply_plane(const VcgArgs a, const int nbatch)
+{
+   constexpr int NQ = Q * Q * Q, ND = D * D * D, DD = D * D;
+   constexpr int TE = kVC * Q; // threads per element
+   constexpr int NT = TE * NEB;
+   // LDS strides: consecutive (element, component) groups of a wave are skewed by
+   // 16 B modulo 128 B, so the broadcast reads of different groups hit different banks
+   constexpr int CS = (ND + 3) & ~1;      // direction d of one component
+   constexpr int CE = (DD * Q + 3) & ~1;  // x-contracted result of one component, [dy,dz][qx]
+   constexpr int PER0 = kVC * (CS + CE);
+   constexpr int PER = PER0 + ((6 - PER0 % 16) + 16) % 16;
+   constexpr int GPT = (NEB * ND + NT - 1) / NT; // gather items per thread
+   // DQ_LDS: the quadrature data of a batch is staged through LDS (NQ/TE values in
+   // flight per thread, shared by the three components) instead of Q*Q prefetch
+   // registers per thread; that is what lets two workgroups share a CU.
+   constexpr int DPT = (NQ + TE - 1) / TE;
+   constexpr int DSTR = DQ_LDS ? ((NQ + 7) & ~1) : 0;
+   __shared__ double smem[NEB * (PER + DSTR)];
+   __shared__ double red[16];
+
+   if (a.s->all_done) { return; }
+   const int tid = threadIdx.x;
+   const int eb = tid / TE, lt = tid - eb * TE;
+   const int c = lt / Q, qx = lt - c * Q;
+   const int G = gridDim.x;
+   double *sIn = smem + eb * PER + c * CS;          // [dx + D*(dy + D*dz)]
+   double *sE = smem + eb * PER + kVC * CS + c * CE; // [qx + Q*(dy + D*dz)]
+   const bool first = a.s->first != 0;
+   bool todo[kVC];
+   double beta[kVC];
+#pragma unroll
+   for (int k = 0; k < kVC; k++)
+   {
+      todo[k] = a.s->done[k] == 0;
+      beta[k] = (first || !todo[k]) ? 0.0 : a.s->rz[k] / a.s->rz_prev[k];
+   }
+   const bool mine = a.s->done[c] == 0;
+   // 1-D table: scalar registers for the register-resident contractions, this
+   // thread's row / column for the two x contractions
+   double Bs[Q * D];
+#pragma unroll
+   for (int i = 0; i < Q * D; i++) { Bs[i] = uniform_f64(a.B[i]); }
+   double bx[D], bt[Q];
+#pragma unroll
+   for (int dx = 0; dx < D; dx++) { bx[dx] = a.B[qx + Q * dx]; }
+#pragma unroll
+   for (int q = 0; q < Q; q++) { bt[q] = a.B[q + Q * (qx < D ? qx : 0)]; }
+
+   // in-flight state of the NEXT batch
+   int mi[GPT];
+   double gz[kVC][GPT], gd[kVC][GPT], dq[DQ_LDS ? 1 : Q][DQ_LDS ? DPT : Q];
+   double *sD = smem + NEB * PER + eb * DSTR;
+   auto load_map = [&](const int b) {
+      const int e0 = b * NEB, nel = min(NEB, a.NE - e0);
+#pragma unroll
+      for (int k = 0; k < GPT; k++)
+      {
+         const int i = tid + k * NT;
+         mi[k] = (i < nel * ND) ? a.map[(size_t)e0 * ND + i] : -1;
+      }
+   };
+   auto load_gather = [&]() {
+#pragma unroll
+      for (int k2 = 0; k2 < kVC; k2++)
+      {
+         if (!todo[k2]) { continue; }
+#pragma unroll
+         for (int k = 0; k < GPT; k++)
+         {
+            gz[k2][k] = (mi[k] >= 0) ? a.z[(size_t)k2 * a.N + mi[k]] : 0.0;
+            gd[k2][k] = (mi[k] >= 0 && !first) ? a.d[(size_t)k2 * a.N + mi[k]] : 0.0;
+         }
+      }
+   };
+   auto load_dq = [&](const int b) {
+      const int e = b * NEB + eb;
+      if (DQ_LDS)
+      {
+#pragma unroll
+         for (int k = 0; k < DPT; k++)
+         {
+            const int j = lt + k * TE;
+            dq[0][k] = (e < a.NE && j < NQ) ? a.Dq[(size_t)e * NQ + j] : 0.0;
+         }
+      }
+      else if (e < a.NE && mine)
+      {
+         const double *p = a.Dq + (size_t)e * NQ + qx;
+#pragma unroll
+         for (int qy = 0; qy < Q; qy++)
+         {
+#pragma unroll
+            for (int qz = 0; qz < Q; qz++) { dq[qy][qz] = p[Q * (qy + Q * qz)]; }
+         }
+      }
+      else
+      {
+#pragma unroll
+         for (int qy = 0; qy < Q; qy++)
+         {
+#pragma unroll
+            for (int qz = 0; qz < Q; qz++) { dq[qy][qz] = 0.0; }
+         }
+      }
+   };
+
+   double dot = 0.0;
+   int b = xcd_swizzle(blockIdx.x, G);
+   if (b < nbatch)
+   {
+      load_map(b);
+      load_gather();
+      load_dq(b);
+   }
+   for (; b < nbatch; b += G)
+   {
+      const int e = b * NEB + eb;
+      const bool active = (e < a.NE) && mine;
+      __syncthreads(); // previous batch finished with the LDS buffers
+      // directions d = z + beta d of every active component (K2 stores the same values)
+#pragma unroll
+      for (int k2 = 0; k2 < kVC; k2++)
+      {
+         if (!todo[k2]) { continue; }
+#pragma unroll
+         for (int k = 0; k < GPT; k++)
+         {
+            const int i = tid + k * NT;
+            if (mi[k] >= 0)
+            {
+               const int el = i / ND, dd = i - el * ND;
+               smem[el * PER + k2 * CS + dd] = first ? gz[k2][k] : fma(beta[k2], gd[k2][k], gz[k2][k]);
+            }
+         }
+      }
+      if (DQ_LDS)
+      {
+#pragma unroll
+         for (int k = 0; k < DPT; k++)
+         {
+            const int j = lt + k * TE;
+            if (j < NQ) { sD[j] = dq[0][k]; }
+         }
+      }
+      const int bn = b + G;
+      const bool have_next = bn < nbatch;
+      if (have_next) { load_map(bn); } // its gathers are issued after the x contraction
+      __syncthreads();
+      // forward x: t[dy,dz] = sum_dx B[qx,dx] d[dx,dy,dz]
+      double t[DD];
+#pragma unroll
+      for (int k = 0; k < DD; k++)
+      {
+         double u = 0.0;
+#pragma unroll
+         for (int dx = 0; dx < D; dx++) { u = fma(bx[dx], sIn[dx + D * k], u); }
+         t[k] = u;
+      }
+      if (have_next)
+      {
+         load_gather();
+         if (DQ_LDS) { load_dq(bn); }
+      }
+      // forward y: w[qy][dz] = sum_dy B[qy,dy] t[dy,dz]
+      double w[Q][D];
+#pragma unroll
+      for (int qy = 0; qy < Q; qy++)
+      {
+#pragma unroll
+         for (int dz = 0; dz < D; dz++)
+         {
+            double u = 0.0;
+#pragma unroll
+            for (int dy = 0; dy < D; dy++) { u = fma(Bs[qy + Q * dy], t[dy + D * dz], u); }
+            w[qy][dz] = u;
+         }
+      }
+      // per qy row: forward z, scale by the quadrature data, backward z (in place)
+#pragma unroll
+      for (int qy = 0; qy < Q; qy++)
+      {
+         double cz[Q];
+#pragma unroll
+         for (int qz = 0; qz < Q; qz++)
+         {
+            double u = 0.0;
+#pragma unroll
+            for (int dz = 0; dz < D; dz++) { u = fma(Bs[qz + Q * dz], w[qy][dz], u); }
+            cz[qz] = u * (DQ_LDS ? sD[qx + Q * (qy + Q * qz)] : dq[qy][qz]);
+         }
+#pragma unroll
+         for (int dz = 0; dz < D; dz++)
+         {
+            double u = 0.0;
+#pragma unroll
+            for (int qz = 0; qz < Q; qz++) { u = fma(Bs[qz + Q * dz], cz[qz], u); }
+            w[qy][dz] = u;
+         }
+      }
+      if (have_next && !DQ_LDS) { load_dq(bn); } // the registers are free again
+      // backward y: t[dy,dz] = sum_qy B[qy,dy] w[qy][dz]; hand the plane over
+#pragma unroll
+      for (int dz = 0; dz < D; dz++)
+      {
+#pragma unroll
+         for (int dy = 0; dy < D; dy++)
+         {
+            double u = 0.0;
+#pragma unroll
+            for (int qy = 0; qy < Q; qy++) { u = fma(Bs[qy + Q * dy], w[qy][dz], u); }
+            sE[qx + Q * (dy + D * dz)] = u;
+         }
+      }
+      __syncthreads();
+      // backward x: thread dx = qx < D sums over the Q planes
+      if (qx < D && active)
+      {
+         double *yc = a.YE + (size_t)c * a.ye_stride + (size_t)ND * e;
+#pragma unroll
+         for (int k = 0; k < DD; k++)
+         {
+            double u = 0.0;
+#pragma unroll
+            for (int q = 0; q < Q; q++) { u = fma(bt[q], sE[q + Q * k], u); }
+            yc[qx + D * k] = u;
+            dot = fma(sIn[qx + D * k], u, dot);
+         }
+      }
+   }
+   double bp[kVC];
+#pragma unroll
+   for (int k = 0; k < kVC; k++)
+   {
+      bp[k] = block_sum(c == k ? dot : 0.0, red);
+      __syncthreads();
+   }
+   double total[kVC];
+   if (grid_sum3_last_block(bp, a.partials, a.stride, a.ticket, red, total))
+   {
+      if (tid == 0)
+      {
+         VcgScalars *s = a.s;
+         for (int k = 0; k < kVC; k++)
+         {
+            if (s->done[k]) { continue; }
+            s->den[k] = total[k];
+            if (total[k] == 0.0 && !a.multi) { s->done[k] = 1; } // breakdown, as upstream
+         }
+         s->first = 0;
+      }
+   }
+}
+
 // ---- init: r = b (x = 0), z = r/diag, nom_c = (z_c, r_c)
 __global__ void __launch_bounds__(256)
 vcg_init_k(const VcgArgs a)
@@ -578,6 +849,28 @@ static bool vcg_supported(const lgh_ctx *c)
    return false;
 }
 
+template <int D, int Q, bool DQ_LDS> static void launch_vcg_plane(lgh_ctx *c, const VcgArgs &a)
+{
+   // 160 KB of LDS per CU: with the staged quadrature data one element less per
+   // workgroup keeps two workgroups resident for Q = 6
+   constexpr int NEB0 = (256 / (kVC * Q)) > 0 ? (256 / (kVC * Q)) : 1;
+   constexpr int NEB = (DQ_LDS && Q == 6) ? NEB0 - 1 : NEB0;
+   const int nbatch = ceil_div(c->NE, NEB);
+   if (c->vcg_grid <= 0)
+   {
+      int per_cu = 0, ncu = 256;
+      hipDeviceProp_t prop;
+      if (hipGetDeviceProperties(&prop, c->device) == hipSuccess) { ncu = prop.multiProcessorCount; }
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, vcg_apply_plane<D, Q, NEB, DQ_LDS>, kVC * Q * NEB, 0) != hipSuccess || per_cu <= 0)
+      {
+         per_cu = 2;
+      }
+      c->vcg_grid = per_cu * ncu;
+   }
+   const int grid = std::min(nbatch, c->vcg_grid);
+   hipLaunchKernelGGL((vcg_apply_plane<D, Q, NEB, DQ_LDS>), dim3(grid), dim3(kVC * Q * NEB), 0, c->stream, a, nbatch);
+}
+
 template <int D, int Q> static void launch_vcg_apply(lgh_ctx *c, const VcgArgs &a)
 {
    constexpr int NEB = (256 / (Q * Q)) > 0 ? (256 / (Q * Q)) : 1;
@@ -597,6 +890,15 @@ template <int D, int Q> static void launch_vcg_apply(lgh_ctx *c, const VcgArgs &
    const int grid = std::min(nbatch, c->vcg_grid);
    hipLaunchKernelGGL((vcg_apply_3d<D, Q, NEB>), dim3(grid), dim3(Q * Q * NEB), 0, c->stream, a, nbatch);
 }
+
+// LGH_VCG_VARIANT: 0 = (qx,qy)-column K1, 1 = plane K1 with register prefetch of the
+// quadrature data (one workgroup per CU), 2 = plane K1 with LDS-staged quadrature data
+#define VCG_DISPATCH(D_, Q_)                                                       \
+   do {                                                                            \
+      if (c->vcg_variant == 0) { launch_vcg_apply<D_, Q_>(c, a); }                 \
+      else if (c->vcg_variant == 1) { launch_vcg_plane<D_, Q_, false>(c, a); }     \
+      else { launch_vcg_plane<D_, Q_, true>(c, a); }                               \
+   } while (0)
 
 // B, X: dim*N (byNODES).  X must be zero on entry (dv = 0, laghos_solver.cpp:338, :382).
 // iters[c] = GetNumIterations() of component c.
@@ -681,9 +983,9 @@ int vcg_solve(lgh_ctx *c, const double *B, double *X, double rel_tol, int max_it
          kt_begin(c, LGH_KERNEL_MASS_CG_H1);
          switch (c->kid)
          {
-            case 0x322: launch_vcg_apply<2, 2>(c, a); break;
-            case 0x334: launch_vcg_apply<3, 4>(c, a); break;
-            case 0x346: launch_vcg_apply<4, 6>(c, a); break;
+            case 0x322: VCG_DISPATCH(2, 2); break;
+            case 0x334: VCG_DISPATCH(3, 4); break;
+            case 0x346: VCG_DISPATCH(4, 6); break;
             case 0x358: launch_vcg_apply<5, 8>(c, a); break;
             case 0x36A: launch_vcg_apply<6, 10>(c, a); break;
          }
