@@ -169,7 +169,7 @@ vcg_apply_3d(const VcgArgs a, const int nbatch)
 
    // in-flight state of the NEXT batch
    int mi[GPT];
-   double gz[kVC][GPT], gd[kVC][GPT], dqn[Q];
+   double gz[kVC][GPT], gd[kVC][GPT], gi[GPT], dqn[Q];
    auto load_map = [&](const int b) {
       const int e0 = b * NEB, nel = min(NEB, a.NE - e0);
 #pragma unroll
@@ -182,13 +182,15 @@ vcg_apply_3d(const VcgArgs a, const int nbatch)
    auto load_data = [&](const int b) {
       const int e = b * NEB + eb;
 #pragma unroll
+      for (int k = 0; k < GPT; k++) { gi[k] = (mi[k] >= 0) ? a.dinv[mi[k]] : 0.0; }
+#pragma unroll
       for (int c = 0; c < kVC; c++)
       {
          if (!todo[c]) { continue; }
 #pragma unroll
          for (int k = 0; k < GPT; k++)
          {
-            gz[c][k] = (mi[k] >= 0) ? a.z[(size_t)c * a.N + mi[k]] : 0.0;
+            gz[c][k] = (mi[k] >= 0) ? a.r[(size_t)c * a.N + mi[k]] : 0.0;
             gd[c][k] = (mi[k] >= 0 && !first) ? a.d[(size_t)c * a.N + mi[k]] : 0.0;
          }
       }
@@ -235,7 +237,7 @@ vcg_apply_3d(const VcgArgs a, const int nbatch)
             if (mi[k] >= 0)
             {
                const int el = i / ND, dd = i - el * ND;
-               smem[el * PER + OFF_IN + c * ND + dd] = first ? gz[c][k] : gz[c][k] + beta[c] * gd[c][k];
+               smem[el * PER + OFF_IN + c * ND + dd] = fma(beta[c], gd[c][k], __dmul_rn(gz[c][k], gi[k]));
             }
          }
       }
@@ -374,12 +376,17 @@ vcg_apply_3d(const VcgArgs a, const int nbatch)
 // ---- K1, plane-per-thread form --------------------------------------------------
 // The (qx, qy)-column form above is bound by LDS bandwidth: every contraction
 // stage re-reads its operands (and the 1-D table) from LDS, 474 doubles per thread
-// and batch, which at 128 B/clk/CU is 80 % of its run time.  Here a thread owns
-// one x-index of one component of one element and keeps the whole (y, z) plane of
-// that index in registers: only the two x contractions exchange data through LDS
-// (64 + 96 doubles read per thread), the y and z contractions and the scaling by
-// the quadrature data run on registers with the 1-D table in scalar registers
-// (its indices are loop constants there), i.e. as FMAs with an SGPR operand.
+// and batch, 80 % of its run time.  Here a thread owns one x-index of one
+// component of one element and keeps the whole (y, z) plane of that index in
+// registers: only the two x contractions exchange data through LDS (64 + 96
+// doubles read per thread), the y and z contractions and the scaling by the
+// quadrature data run on registers with the 1-D table in scalar registers (its
+// indices are loop constants there), i.e. as FMAs with an SGPR operand.
+// The quadrature data of a batch is staged through LDS (NQ/TE values in flight per
+// thread, shared by the three components), which keeps the register count low
+// enough for two workgroups per CU.
+// Software pipeline: the element->node map runs two batches ahead, the gathers and
+// the quadrature data one batch ahead.
 __device__ __forceinline__ double uniform_f64(const double v)
 {
    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
@@ -387,8 +394,8 @@ __device__ __forceinline__ double uniform_f64(const double v)
    return __hiloint2double(hi, lo);
 }
 
-template <int D, int Q, int NEB, bool DQ_LDS>
-__global__ void __launch_bounds__(kVC *Q *NEB, DQ_LDS ? 2 : 1)
+template <int D, int Q, int NEB>
+__global__ void __launch_bounds__(kVC *Q *NEB, 2)
 vcg_apply_plane(const VcgArgs a, const int nbatch)
 {
    constexpr int NQ = Q * Q * Q, ND = D * D * D, DD = D * D;
@@ -396,26 +403,38 @@ vcg_apply_plane(const VcgArgs a, const int nbatch)
    constexpr int NT = TE * NEB;
    // LDS strides: consecutive (element, component) groups of a wave are skewed by
    // 16 B modulo 128 B, so the broadcast reads of different groups hit different banks
-   constexpr int CS = (ND + 3) & ~1;      // direction d of one component
-   constexpr int CE = (DD * Q + 3) & ~1;  // x-contracted result of one component, [dy,dz][qx]
+   constexpr int CS = (ND + 3) & ~1;     // direction d of one component
+   constexpr int CE = (DD * Q + 3) & ~1; // x-contracted result of one component, [dy,dz][qx]
    constexpr int PER0 = kVC * (CS + CE);
    constexpr int PER = PER0 + ((6 - PER0 % 16) + 16) % 16;
    constexpr int GPT = (NEB * ND + NT - 1) / NT; // gather items per thread
-   // DQ_LDS: the quadrature data of a batch is staged through LDS (NQ/TE values in
-   // flight per thread, shared by the three components) instead of Q*Q prefetch
-   // registers per thread; that is what lets two workgroups share a CU.
-   constexpr int DPT = (NQ + TE - 1) / TE;
-   constexpr int DSTR = DQ_LDS ? ((NQ + 7) & ~1) : 0;
+   constexpr int DPT = (NQ + TE - 1) / TE;       // quadrature values staged per thread
+   constexpr int DSTR = (NQ + 7) & ~1;
    __shared__ double smem[NEB * (PER + DSTR)];
    __shared__ double red[16];
 
-   if (a.s->all_done) { return; }
    const int tid = threadIdx.x;
    const int eb = tid / TE, lt = tid - eb * TE;
    const int c = lt / Q, qx = lt - c * Q;
    const int G = gridDim.x;
-   double *sIn = smem + eb * PER + c * CS;          // [dx + D*(dy + D*dz)]
+   double *sIn = smem + eb * PER + c * CS;           // [dx + D*(dy + D*dz)]
    double *sE = smem + eb * PER + kVC * CS + c * CE; // [qx + Q*(dy + D*dz)]
+   double *sD = smem + NEB * PER + eb * DSTR;        // [qx + Q*(qy + Q*qz)]
+
+   int mi[GPT];
+   auto load_map = [&](const int b) {
+      const int e0 = b * NEB, nel = min(NEB, a.NE - e0);
+#pragma unroll
+      for (int k = 0; k < GPT; k++)
+      {
+         const int i = tid + k * NT;
+         mi[k] = (i < nel * ND) ? a.map[(size_t)e0 * ND + i] : -1;
+      }
+   };
+   int b = xcd_swizzle(blockIdx.x, G);
+   if (b < nbatch) { load_map(b); } // in flight while the scalars are read
+
+   if (a.s->all_done) { return; }
    const bool first = a.s->first != 0;
    bool todo[kVC];
    double beta[kVC];
@@ -437,105 +456,74 @@ vcg_apply_plane(const VcgArgs a, const int nbatch)
 #pragma unroll
    for (int q = 0; q < Q; q++) { bt[q] = a.B[q + Q * (qx < D ? qx : 0)]; }
 
-   // in-flight state of the NEXT batch
-   int mi[GPT];
-   double gz[kVC][GPT], gd[kVC][GPT], dq[DQ_LDS ? 1 : Q][DQ_LDS ? DPT : Q];
-   double *sD = smem + NEB * PER + eb * DSTR;
-   auto load_map = [&](const int b) {
-      const int e0 = b * NEB, nel = min(NEB, a.NE - e0);
+   double gz[kVC][GPT], gd[kVC][GPT], gi[GPT], dq[DPT];
+   auto load_gather = [&]() { // nodes of mi[]: residual r, direction d, 1/diag
 #pragma unroll
-      for (int k = 0; k < GPT; k++)
-      {
-         const int i = tid + k * NT;
-         mi[k] = (i < nel * ND) ? a.map[(size_t)e0 * ND + i] : -1;
-      }
-   };
-   auto load_gather = [&]() {
+      for (int k = 0; k < GPT; k++) { gi[k] = (mi[k] >= 0) ? a.dinv[mi[k]] : 0.0; }
 #pragma unroll
       for (int k2 = 0; k2 < kVC; k2++)
       {
-         if (!todo[k2]) { continue; }
 #pragma unroll
          for (int k = 0; k < GPT; k++)
          {
-            gz[k2][k] = (mi[k] >= 0) ? a.z[(size_t)k2 * a.N + mi[k]] : 0.0;
+            gz[k2][k] = (mi[k] >= 0) ? a.r[(size_t)k2 * a.N + mi[k]] : 0.0;
             gd[k2][k] = (mi[k] >= 0 && !first) ? a.d[(size_t)k2 * a.N + mi[k]] : 0.0;
          }
       }
    };
-   auto load_dq = [&](const int b) {
-      const int e = b * NEB + eb;
-      if (DQ_LDS)
+   auto load_dq = [&](const int bb) {
+      const int e = bb * NEB + eb;
+#pragma unroll
+      for (int k = 0; k < DPT; k++)
       {
-#pragma unroll
-         for (int k = 0; k < DPT; k++)
-         {
-            const int j = lt + k * TE;
-            dq[0][k] = (e < a.NE && j < NQ) ? a.Dq[(size_t)e * NQ + j] : 0.0;
-         }
-      }
-      else if (e < a.NE && mine)
-      {
-         const double *p = a.Dq + (size_t)e * NQ + qx;
-#pragma unroll
-         for (int qy = 0; qy < Q; qy++)
-         {
-#pragma unroll
-            for (int qz = 0; qz < Q; qz++) { dq[qy][qz] = p[Q * (qy + Q * qz)]; }
-         }
-      }
-      else
-      {
-#pragma unroll
-         for (int qy = 0; qy < Q; qy++)
-         {
-#pragma unroll
-            for (int qz = 0; qz < Q; qz++) { dq[qy][qz] = 0.0; }
-         }
+         const int j = lt + k * TE;
+         dq[k] = (e < a.NE && j < NQ) ? a.Dq[(size_t)e * NQ + j] : 0.0;
       }
    };
 
    double dot = 0.0;
-   int b = xcd_swizzle(blockIdx.x, G);
    if (b < nbatch)
    {
-      load_map(b);
       load_gather();
       load_dq(b);
+      if (b + G < nbatch) { load_map(b + G); }
    }
    for (; b < nbatch; b += G)
    {
       const int e = b * NEB + eb;
       const bool active = (e < a.NE) && mine;
+      const int nit = min(NEB, a.NE - b * NEB) * ND;
       __syncthreads(); // previous batch finished with the LDS buffers
-      // directions d = z + beta d of every active component (K2 stores the same values)
+      // directions d = z + beta d of every active component (K2 stores the same
+      // values), quadrature data
 #pragma unroll
-      for (int k2 = 0; k2 < kVC; k2++)
+      for (int k = 0; k < GPT; k++)
       {
-         if (!todo[k2]) { continue; }
-#pragma unroll
-         for (int k = 0; k < GPT; k++)
+         const int i = tid + k * NT;
+         if (i < nit)
          {
-            const int i = tid + k * NT;
-            if (mi[k] >= 0)
+            const int el = i / ND, dd = i - el * ND;
+#pragma unroll
+            for (int k2 = 0; k2 < kVC; k2++)
             {
-               const int el = i / ND, dd = i - el * ND;
-               smem[el * PER + k2 * CS + dd] = first ? gz[k2][k] : fma(beta[k2], gd[k2][k], gz[k2][k]);
+               smem[el * PER + k2 * CS + dd] = fma(beta[k2], gd[k2][k], __dmul_rn(gz[k2][k], gi[k]));
             }
          }
       }
-      if (DQ_LDS)
-      {
 #pragma unroll
-         for (int k = 0; k < DPT; k++)
-         {
-            const int j = lt + k * TE;
-            if (j < NQ) { sD[j] = dq[0][k]; }
-         }
+      for (int k = 0; k < DPT; k++)
+      {
+         const int j = lt + k * TE;
+         if (j < NQ) { sD[j] = dq[k]; }
       }
+      // next batch: gathers and quadrature data now, the map of the one after
       const int bn = b + G;
-      const bool have_next = bn < nbatch;
-      if (have_next) { load_map(bn); } // its gathers are issued after the x contraction
+      if (bn < nbatch)
+      {
+         load_gather();
+         load_dq(bn);
+         if (bn + G < nbatch) { load_map(bn + G); }
+      }
       __syncthreads();
       // forward x: t[dy,dz] = sum_dx B[qx,dx] d[dx,dy,dz]
       double t[DD];
@@ -546,11 +534,6 @@ vcg_apply_plane(const VcgArgs a, const int nbatch)
 #pragma unroll
          for (int dx = 0; dx < D; dx++) { u = fma(bx[dx], sIn[dx + D * k], u); }
          t[k] = u;
-      }
-      if (have_next)
-      {
-         load_gather();
-         if (DQ_LDS) { load_dq(bn); }
       }
       // forward y: w[qy][dz] = sum_dy B[qy,dy] t[dy,dz]
       double w[Q][D];
@@ -577,7 +560,7 @@ vcg_apply_plane(const VcgArgs a, const int nbatch)
             double u = 0.0;
 #pragma unroll
             for (int dz = 0; dz < D; dz++) { u = fma(Bs[qz + Q * dz], w[qy][dz], u); }
-            cz[qz] = u * (DQ_LDS ? sD[qx + Q * (qy + Q * qz)] : dq[qy][qz]);
+            cz[qz] = u * sD[qx + Q * (qy + Q * qz)];
          }
 #pragma unroll
          for (int dz = 0; dz < D; dz++)
@@ -588,8 +571,7 @@ vcg_apply_plane(const VcgArgs a, const int nbatch)
             w[qy][dz] = u;
          }
       }
-      if (have_next && !DQ_LDS) { load_dq(bn); } // the registers are free again
-      // backward y: t[dy,dz] = sum_qy B[qy,dy] w[qy][dz]; hand the plane over
+      // backward y: sum_qy B[qy,dy] w[qy][dz]; hand the plane over
 #pragma unroll
       for (int dz = 0; dz < D; dz++)
       {
@@ -659,9 +641,7 @@ vcg_init_k(const VcgArgs a)
          const size_t i = (size_t)c * a.N + n;
          const double rv = a.b[i];
          a.r[i] = rv;
-         const double zv = rv * di;
-         a.z[i] = zv;
-         part[c] = ow * zv * rv;
+         part[c] = ow * __dmul_rn(rv, di) * rv; // z = r/diag is recomputed where it is used
       }
    }
    double bp[kVC], total[kVC];
@@ -734,8 +714,10 @@ __global__ void vcg_update_finish_k(VcgScalars *s, int iter)
    s->all_done = all;
 }
 
-// ---- K2: per node and component: z = sum of element contributions, ess rows,
-// d = z_old + beta d, x += alpha d, r -= alpha z, z = r/diag, (r, z)
+// ---- K2: per node and component: A d = sum of element contributions, ess rows,
+// d = r/diag + beta d, x += alpha d, r -= alpha A d, (r, r/diag).  The preconditioned
+// residual z = r/diag is never stored: K1 and K2 recompute it from r (one rounded
+// multiply, so both see the same value), which saves a vector read and a write.
 template <bool FUSED_GATHER, int DEG>
 __global__ void __launch_bounds__(256)
 vcg_update_k(const VcgArgs a)
@@ -772,17 +754,17 @@ vcg_update_k(const VcgArgs a)
       }
       else { zv = a.yL[i]; }
       if (a.ess[c] && a.ess[c][nn]) { zv = 0.0; }
-      double dv = a.z[i];
-      if (!it1) { dv += beta * a.d[i]; }
+      const double ro = a.r[i];
+      double dv = __dmul_rn(ro, di); // z of the previous iterate, not stored
+      if (!it1) { dv = fma(beta, a.d[i], dv); }
       const double xv = a.x[i] + alpha * dv;
-      const double rv = a.r[i] - alpha * zv;
-      const double pz = rv * di;
+      const double rv = ro - alpha * zv;
+      const double pz = __dmul_rn(rv, di);
       if (ok)
       {
          a.d[i] = dv;
          a.x[i] = xv;
          a.r[i] = rv;
-         a.z[i] = pz;
          part[c] = ow * rv * pz;
       }
    }
@@ -849,26 +831,26 @@ static bool vcg_supported(const lgh_ctx *c)
    return false;
 }
 
-template <int D, int Q, bool DQ_LDS> static void launch_vcg_plane(lgh_ctx *c, const VcgArgs &a)
+template <int D, int Q> static void launch_vcg_plane(lgh_ctx *c, const VcgArgs &a)
 {
    // 160 KB of LDS per CU: with the staged quadrature data one element less per
    // workgroup keeps two workgroups resident for Q = 6
    constexpr int NEB0 = (256 / (kVC * Q)) > 0 ? (256 / (kVC * Q)) : 1;
-   constexpr int NEB = (DQ_LDS && Q == 6) ? NEB0 - 1 : NEB0;
+   constexpr int NEB = (Q == 6) ? NEB0 - 1 : NEB0;
    const int nbatch = ceil_div(c->NE, NEB);
    if (c->vcg_grid <= 0)
    {
       int per_cu = 0, ncu = 256;
       hipDeviceProp_t prop;
       if (hipGetDeviceProperties(&prop, c->device) == hipSuccess) { ncu = prop.multiProcessorCount; }
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, vcg_apply_plane<D, Q, NEB, DQ_LDS>, kVC * Q * NEB, 0) != hipSuccess || per_cu <= 0)
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, vcg_apply_plane<D, Q, NEB>, kVC * Q * NEB, 0) != hipSuccess || per_cu <= 0)
       {
          per_cu = 2;
       }
       c->vcg_grid = per_cu * ncu;
    }
    const int grid = std::min(nbatch, c->vcg_grid);
-   hipLaunchKernelGGL((vcg_apply_plane<D, Q, NEB, DQ_LDS>), dim3(grid), dim3(kVC * Q * NEB), 0, c->stream, a, nbatch);
+   hipLaunchKernelGGL((vcg_apply_plane<D, Q, NEB>), dim3(grid), dim3(kVC * Q * NEB), 0, c->stream, a, nbatch);
 }
 
 template <int D, int Q> static void launch_vcg_apply(lgh_ctx *c, const VcgArgs &a)
@@ -891,13 +873,11 @@ template <int D, int Q> static void launch_vcg_apply(lgh_ctx *c, const VcgArgs &
    hipLaunchKernelGGL((vcg_apply_3d<D, Q, NEB>), dim3(grid), dim3(Q * Q * NEB), 0, c->stream, a, nbatch);
 }
 
-// LGH_VCG_VARIANT: 0 = (qx,qy)-column K1, 1 = plane K1 with register prefetch of the
-// quadrature data (one workgroup per CU), 2 = plane K1 with LDS-staged quadrature data
+// LGH_VCG_VARIANT: 0 = (qx,qy)-column K1, otherwise the plane-per-thread K1
 #define VCG_DISPATCH(D_, Q_)                                                       \
    do {                                                                            \
       if (c->vcg_variant == 0) { launch_vcg_apply<D_, Q_>(c, a); }                 \
-      else if (c->vcg_variant == 1) { launch_vcg_plane<D_, Q_, false>(c, a); }     \
-      else { launch_vcg_plane<D_, Q_, true>(c, a); }                               \
+      else { launch_vcg_plane<D_, Q_>(c, a); }                                     \
    } while (0)
 
 // B, X: dim*N (byNODES).  X must be zero on entry (dv = 0, laghos_solver.cpp:338, :382).

@@ -1,7 +1,11 @@
-set -x
 mkdir -p gpurun_out/var
-for v in 2 1 0; do
-  LGH_VCG_VARIANT=$v timeout 300 python -m pytest tests/test_gpu_pipeline.py -m gpu -x -q -k "golden or oracle or Q3Q2 or q3q2" 2>&1 | tail -3
+timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -4
+for v in 2 0; do
   LGH_VCG_VARIANT=$v timeout 300 python bench.py --steps 5 --warmup 2 > gpurun_out/var/bench_v$v.json 2> gpurun_out/var/bench_v$v.err
-  tail -c 1500 gpurun_out/var/bench_v$v.json
+  python - <<PY
+import json
+d=json.loads([l for l in open('gpurun_out/var/bench_v$v.json') if l.startswith('{')][-1])
+print($v, d['value'], d['ms_per_step'], d['fom'])
+for k,v in d['kernels'].items(): print('   ',k, round(v['mean_us'],1))
+PY
 done
