@@ -208,17 +208,23 @@ def main():
                 (3, 8 * (dim * dim * NQ + NL + dim * ND)),            # ForceMult
                 (4, 8 * (dim * dim * NQ + NL + dim * ND)),            # ForceMultTranspose
             )}
-        names = {0: "vcg_apply_3d (H1 CG K1, 3 velocity components per launch)", 2: "qpoint_kernel (fused QUpdate)",
-                 3: "force_mult_3d", 4: "force_mult_t_3d"}
+        names = {0: "vcg_apply_plane (H1 CG K1, 3 velocity components per launch)", 2: "qpoint_kernel (fused QUpdate)",
+                 3: "force_mult_3d", 4: "force_mult_t_3d",
+                 1: "vcg_update_k (H1 CG K2, 3 velocity components per launch)", 5: "mass_apply_3d (L2 CG K1)"}
+        # per-launch (not per-element) figures for the node kernel K2: r, d, x read and
+        # written, 1/diag, the element contributions (E-vector) and their ELL index table
+        N_h1 = sz["N"]
+        k2_bytes = 8 * N_h1 * (dim * 6 + 1) + 8 * dim * sz["NE"] * ND + 4 * 8 * N_h1
+        bytes_per_elem[5] = 8 * (NQ + 2 * NL)
         kern = {}
-        for kid in (0, 2, 3, 4):
+        for kid in (0, 1, 2, 3, 4, 5):
             _lib.check(L.lgh_ktime_begin(ctx, kid, 4096))
             sim.step()
             n = ctypes.c_int()
             mean = ctypes.c_double()
             _lib.check(L.lgh_ktime_end(ctx, ctypes.byref(n), ctypes.byref(mean)))
             if n.value:
-                bts = bytes_per_elem[kid] * sz["NE"]
+                bts = k2_bytes if kid == 1 else bytes_per_elem[kid] * sz["NE"]
                 kern[names[kid]] = {"launches": n.value, "mean_us": 1e6 * mean.value,
                                     "algorithmic_bytes": bts, "GBs": 1e-9 * bts / mean.value}
         dom = kern.get(names[0])

@@ -169,10 +169,17 @@ CartMesh CartMesh::Named(const std::string &name_in)
       m.brk[0] = {0., 1., 2., 3., 4., 5., 6., 7.};
       m.brk[1] = {0., 1., 2., 3.};
    }
+   else if (name == "square_gresho")
+   {
+      m.dim = 2;
+      m.brk[0] = {-0.5, 0.0, 0.5};
+      m.brk[1] = {-0.5, 0.0, 0.5};
+   }
    else
    {
       throw std::runtime_error("mesh '" + name_in + "' is not one of the structured meshes this "
-                               "harness supports (square01_quad, cube01_hex, box01_hex, rectangle01_quad)");
+                               "harness supports (square01_quad, cube01_hex, box01_hex, rectangle01_quad, "
+                               "square_gresho)");
    }
    return m;
 }
@@ -397,6 +404,20 @@ void Discretization::v0(const double *x, double *v) const
          v[2] = 0.0;
       }
    }
+   else if (problem == 4) // Gresho vortex, laghos.cpp:1161-1177
+   {
+      const double r = std::sqrt(x[0] * x[0] + x[1] * x[1]);
+      if (r < 0.2)
+      {
+         v[0] = 5.0 * x[1];
+         v[1] = -5.0 * x[0];
+      }
+      else if (r < 0.4)
+      {
+         v[0] = 2.0 * x[1] / r - 5.0 * x[1];
+         v[1] = -2.0 * x[0] / r + 5.0 * x[0];
+      }
+   }
 }
 double Discretization::e0(const double *x) const
 {
@@ -415,6 +436,19 @@ double Discretization::e0(const double *x) const
       }
       case 1: return 0.0;
       case 3: return ((x[0] > 1.0) ? 0.1 : 1.0) / rho0(x) / (gamma_func(x) - 1.0);
+      case 4: // laghos.cpp:1232-1247
+      {
+         const double rsq = x[0] * x[0] + x[1] * x[1], r = std::sqrt(rsq);
+         const double gamma = 5.0 / 3.0;
+         if (r < 0.2) { return (5.0 + 25.0 / 2.0 * rsq) / (gamma - 1.0); }
+         else if (r < 0.4)
+         {
+            const double t1 = 9.0 - 4.0 * std::log(0.2) + 25.0 / 2.0 * rsq;
+            const double t2 = 20.0 * r - 4.0 * std::log(r);
+            return (t1 - t2) / (gamma - 1.0);
+         }
+         return (3.0 + 4.0 * std::log(2.0)) / (gamma - 1.0);
+      }
       default: throw std::runtime_error("problem not supported by this harness");
    }
 }

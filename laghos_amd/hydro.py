@@ -104,10 +104,36 @@ def rk4_step(hydro, S, t, dt, work):
     return t + dt
 
 
+def rk2avg_step(hydro, S, t, dt, work):
+    """RK2AvgSolver::Step (laghos_solver.cpp:1447-1487): two SolveVelocity /
+    SolveEnergy sub-steps, the energy one with the half-step average velocity V."""
+    ctx, p = hydro.ctx, hydro.p
+    dS, S0, y = work
+    h1v = p.H1V
+    V = y[:h1v]
+    ctx.vec_copy(S0, S)
+    v0, dv = S0[h1v:2 * h1v], dS[h1v:2 * h1v]
+    for sub in (0, 1):
+        if sub == 1:
+            ctx.vec_axpby(S, 1.0, S0, 0.5 * dt, dS)                # S = S0 + dt/2 dS_dt
+            hydro.reset_quadrature_data()
+        hydro.update_quadrature_data(S)
+        ctx.solve_velocity(S, dS, hydro.one, hydro.rhs, hydro.work, hydro.cg_tol, hydro.cg_max_iter)
+        ctx.vec_axpby(V, 1.0, v0, 0.5 * dt, dv)                   # V = v0 + dt/2 dv_dt
+        ctx.solve_energy(S, V, dS, hydro.e_rhs, hydro.cg_tol, hydro.cg_max_iter)
+        ctx.vec_copy(dS[:h1v], V)                                  # dx_dt = V
+    ctx.vec_axpby(S, 1.0, S0, dt, dS)                              # S = S0 + dt dS_dt
+    hydro.reset_quadrature_data()
+    return t + dt
+
+
 class TimeLoop:
     """laghos.cpp:706-778 as a resumable object (bench.py steps it K times)."""
 
-    def __init__(self, hydro, t_final=0.6, max_steps=-1):
+    def __init__(self, hydro, t_final=0.6, max_steps=-1, ode_solver=4):
+        if ode_solver not in (4, 7):
+            raise ValueError("ode_solver: 4 (RK4) or 7 (RK2Avg)")
+        self.stepper = rk2avg_step if ode_solver == 7 else rk4_step
         self.h = hydro
         self.t_final, self.max_steps = t_final, max_steps
         self.S = hydro.S0.clone()
@@ -137,7 +163,7 @@ class TimeLoop:
             h.ctx.vec_copy(self.S_old, self.S)
             t_old = self.t
             h.reset_time_step_estimate()
-            self.t = rk4_step(h, self.S, self.t, self.dt, self.work)
+            self.t = self.stepper(h, self.S, self.t, self.dt, self.work)
             self.steps += 1
             dt_est = h.get_time_step_estimate(self.S)
             if dt_est < self.dt:
@@ -158,9 +184,9 @@ class TimeLoop:
 
 
 def run(prob, t_final=0.6, cfl=0.5, cg_tol=1e-8, cg_max_iter=300, max_steps=-1, probe_steps=(),
-        device=0, comm=None):
+        device=0, comm=None, ode_solver=4):
     hydro = HydroOperator(prob, cfl=cfl, cg_tol=cg_tol, cg_max_iter=cg_max_iter, device=device, comm=comm)
-    loop = TimeLoop(hydro, t_final=t_final, max_steps=max_steps)
+    loop = TimeLoop(hydro, t_final=t_final, max_steps=max_steps, ode_solver=ode_solver)
     probes = {}
     while loop.step():
         done_ti = loop.ti - 1

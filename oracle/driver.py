@@ -196,6 +196,20 @@ class Hydro:
                               self.cg_max_iter, _dp(src) if src is not None else None, 1)
         self.qdata_is_current = False  # :326
 
+    def solve_velocity(self, S, dS):
+        self.update_quadrature_data(S)
+        self.L.lgo_solve_velocity(self.h, _dp(S), _dp(dS), ctypes.c_double(self.cg_tol), self.cg_max_iter, 1)
+
+    def solve_energy(self, S, V, dS):
+        self.update_quadrature_data(S)
+        src = None
+        if self.source_type == 1:
+            src = np.empty(self.p.L2V)
+            self.L.lgo_tg_source_2d(self.h, _dp(S), _dp(src))
+        V = np.ascontiguousarray(V)
+        self.L.lgo_solve_energy(self.h, _dp(V), _dp(dS), ctypes.c_double(self.cg_tol), self.cg_max_iter,
+                                _dp(src) if src is not None else None)
+
     def force_mult(self, x_l2):
         y = np.empty(self.p.H1V)
         self.L.lgo_force_mult(self.h, _dp(x_l2), _dp(y))
@@ -263,8 +277,33 @@ def rk4_step(hydro, S, t, dt, work):
     return t + dt
 
 
+def rk2avg_step(hydro, S, t, dt, work):
+    """RK2AvgSolver::Step (laghos_solver.cpp:1447-1487)."""
+    dS, S0, _ = work
+    h1v = hydro.p.H1V
+    S0[:] = S
+    v0 = S0[h1v:2 * h1v]
+    dS[:] = 0.0  # dS_dt = 0 at Init; every block is overwritten below
+    # -- 1. S is S0
+    hydro.solve_velocity(S, dS)
+    V = v0 + (0.5 * dt) * dS[h1v:2 * h1v]
+    hydro.solve_energy(S, V, dS)
+    dS[:h1v] = V
+    # -- 2. S = S0 + 0.5 dt dS_dt
+    np.add(S0, (0.5 * dt) * dS, out=S)
+    hydro.reset_quadrature_data()
+    hydro.solve_velocity(S, dS)
+    V = v0 + (0.5 * dt) * dS[h1v:2 * h1v]
+    hydro.solve_energy(S, V, dS)
+    dS[:h1v] = V
+    # -- 3. S = S0 + dt dS_dt
+    np.add(S0, dt * dS, out=S)
+    hydro.reset_quadrature_data()
+    return t + dt
+
+
 def run(prob: Problem, t_final=0.6, cfl=0.5, cg_tol=1e-8, cg_max_iter=300, max_steps=-1,
-        vis_steps=5, probe_steps=(), verbose=False, comm=None, hydro=None):
+        vis_steps=5, probe_steps=(), verbose=False, comm=None, hydro=None, ode_solver=4):
     """The reference time loop (laghos.cpp:706-778).  Returns a dict with the last
     printed (step, t, dt, |e|), |e| at each step in probe_steps, and the FOM data."""
     own = hydro is None
@@ -292,7 +331,7 @@ def run(prob: Problem, t_final=0.6, cfl=0.5, cg_tol=1e-8, cg_max_iter=300, max_s
         S_old[:] = S
         t_old = t
         hydro.reset_time_step_estimate()
-        t = rk4_step(hydro, S, t, dt, work)
+        t = (rk2avg_step if ode_solver == 7 else rk4_step)(hydro, S, t, dt, work)
         steps += 1
         dt_est = hydro.get_time_step_estimate(S)
         if dt_est < dt:

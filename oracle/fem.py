@@ -89,6 +89,7 @@ MESHES = {
     "cube01_hex": [[0.0, 0.5, 1.0], [0.0, 0.5, 1.0], [0.0, 0.5, 1.0]],
     "box01_hex": [[0.0, 1.0, 3.0, 5.0, 7.0], [0.0, 1.5, 3.0], [0.0, 1.5, 3.0]],
     "rectangle01_quad": [[float(i) for i in range(8)], [0.0, 1.0, 2.0, 3.0]],
+    "square_gresho": [[-0.5, 0.0, 0.5], [-0.5, 0.0, 0.5]],
 }
 
 
@@ -332,6 +333,13 @@ class Problem:
             if dim == 3:
                 v[..., 0] *= np.cos(np.pi * x[..., 2])
                 v[..., 1] *= np.cos(np.pi * x[..., 2])
+        if p == 4:  # Gresho vortex, laghos.cpp:1161-1177
+            x0, x1 = x[..., 0], x[..., 1]
+            r = np.sqrt(x0 * x0 + x1 * x1)
+            rs = np.where(r > 0, r, 1.0)
+            inner, ring = r < 0.2, (r >= 0.2) & (r < 0.4)
+            v[..., 0] = np.where(inner, 5.0 * x1, np.where(ring, 2.0 * x1 / rs - 5.0 * x1, 0.0))
+            v[..., 1] = np.where(inner, -5.0 * x0, np.where(ring, -2.0 * x0 / rs + 5.0 * x0, 0.0))
         return v
 
     def e0(self, x):
@@ -348,6 +356,18 @@ class Problem:
             return np.zeros(x.shape[:-1])
         if p == 3:
             return np.where(x[..., 0] > 1.0, 0.1, 1.0) / self.rho0(x) / (self.gamma_func(x) - 1.0)
+        if p == 4:  # laghos.cpp:1232-1247
+            x0, x1 = x[..., 0], x[..., 1]
+            rsq = x0 * x0 + x1 * x1
+            r = np.sqrt(rsq)
+            gamma = 5.0 / 3.0
+            rs = np.where(r > 0, r, 1.0)
+            inner = (5.0 + 25.0 / 2.0 * rsq) / (gamma - 1.0)
+            t1 = 9.0 - 4.0 * np.log(0.2) + 25.0 / 2.0 * rsq
+            t2 = 20.0 * r - 4.0 * np.log(rs)
+            ring = (t1 - t2) / (gamma - 1.0)
+            outer = (3.0 + 4.0 * np.log(2.0)) / (gamma - 1.0)
+            return np.where(r < 0.2, inner, np.where(r < 0.4, ring, outer))
         raise ValueError
 
     def source_type(self):

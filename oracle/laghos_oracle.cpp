@@ -1416,19 +1416,16 @@ done:
 // SolveVelocity (:329-399) and SolveEnergy (:442-490), PA branch, no sources.
 // S = [x|v|e], dS = [dx|dv|de].  The caller owns the qdata_is_current flag
 // (laghos_solver.cpp:809-812, :326): when set, UpdateQuadratureData is skipped.
-void lgo_hydro_mult(void *h, const double *S, double *dS, double cg_tol, int cg_max_iter,
-                    const double *e_source /* optional L2 L-vector or NULL */,
-                    int qdata_is_current /* :809 early return */)
+// SolveVelocity (laghos_solver.cpp:328-398): dv_dt block of dS
+void lgo_solve_velocity(void *h, const double *S, double *dS, double cg_tol, int cg_max_iter,
+                        int qdata_is_current /* :809 early return */)
 {
    Ctx *c = (Ctx *)h;
    const int dim = c->dim, N = c->N, H1V = c->H1V, L2V = c->L2V;
-   const double *v = S + H1V;
-   double *dx = dS, *dv = dS + H1V, *de = dS + 2 * (size_t)H1V;
-   std::memcpy(dx, v, sizeof(double) * H1V); // :323
-   // --- SolveVelocity
+   double *dv = dS + H1V;
    if (!qdata_is_current) { lgo_qupdate(h, S); } // :332, :809
    std::fill(dv, dv + H1V, 0.0);
-   std::vector<double> one(L2V, 1.0), rhs(H1V), Bv(N), e_rhs(L2V);
+   std::vector<double> one(L2V, 1.0), rhs(H1V), Bv(N);
    double t0 = now();
    lgo_force_mult(h, one.data(), rhs.data()); // :354
    c->t_force += now() - t0;
@@ -1441,13 +1438,36 @@ void lgo_hydro_mult(void *h, const double *S, double *dS, double cg_tol, int cg_
       lgo_mass_eliminate_rhs(h, Bv.data());                                      // :384
       lgo_cg(h, 0, Bv.data(), X, cg_tol, cg_max_iter);                           // :388
    }
-   // --- SolveEnergy (quadrature data is current)
-   t0 = now();
+}
+
+// SolveEnergy (laghos_solver.cpp:400-493) with the velocity v (RK2Avg passes the
+// half-step average V, Mult passes the v block of S); the quadrature data is current
+void lgo_solve_energy(void *h, const double *v, double *dS, double cg_tol, int cg_max_iter,
+                      const double *e_source /* optional L2 L-vector or NULL */)
+{
+   Ctx *c = (Ctx *)h;
+   const int H1V = c->H1V, L2V = c->L2V;
+   double *de = dS + 2 * (size_t)H1V;
+   std::vector<double> e_rhs(L2V);
+   double t0 = now();
    lgo_force_mult_transpose(h, v, e_rhs.data()); // :473
    c->t_force += now() - t0;
    if (e_source)
       for (int i = 0; i < L2V; i++) { e_rhs[i] += e_source[i]; } // :477
    lgo_cg(h, 1, e_rhs.data(), de, cg_tol, cg_max_iter); // :481
+}
+
+// LagrangianHydroOperator::Mult (laghos_solver.cpp:308-326)
+void lgo_hydro_mult(void *h, const double *S, double *dS, double cg_tol, int cg_max_iter,
+                    const double *e_source /* optional L2 L-vector or NULL */,
+                    int qdata_is_current /* :809 early return */)
+{
+   Ctx *c = (Ctx *)h;
+   const int H1V = c->H1V;
+   const double *v = S + H1V;
+   std::memcpy(dS, v, sizeof(double) * H1V); // :323
+   lgo_solve_velocity(h, S, dS, cg_tol, cg_max_iter, qdata_is_current);
+   lgo_solve_energy(h, v, dS, cg_tol, cg_max_iter, e_source);
 }
 
 // ComputeVolumeIntegral users (laghos_solver.cpp:640-697): internal and kinetic energy

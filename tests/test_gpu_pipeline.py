@@ -39,6 +39,21 @@ def test_readme_run4_prefix_vs_oracle():
         assert abs(r["probes"][s] - o["probes"][s]) / o["probes"][s] < 1e-7, (s, r["probes"][s], o["probes"][s])
 
 
+def test_readme_run8_gresho_rk2avg(golden):
+    """README run 8 (README.md:222, :234): Gresho vortex, 2D Q3Q2 (kernel 0x246),
+    RK2AvgSolver, no artificial viscosity - the only published value at Q3/Q2.
+    Same comparison as the reference's `make tests`: step count, printed dt and the
+    11 printed digits of |e| (README.md:249-250)."""
+    from laghos_amd.hydro import run
+    from oracle.fem import Problem
+    g = next(c for c in golden["readme"] if c["name"] == "README-8")
+    r = run(Problem(mesh=g["mesh"], rs=g["rs"], problem=g["problem"], order_v=g["order_v"], order_e=g["order_e"]),
+            t_final=g["tf"], ode_solver=g["ode_solver"])
+    assert r["ti"] == g["step"]
+    assert f"{r['dt']:.6f}" == g["dt"]
+    assert abs(r["e_norm"] - g["e_norm"]) / g["e_norm"] < 5e-11, (r["e_norm"], g["e_norm"])
+
+
 def test_q3q2_sedov_vs_oracle():
     """BASELINE config shape (3D Sedov, Q3Q2) at a size the oracle finishes in
     seconds (rs1 = 64 elements): 10 steps, state vector parity."""
@@ -154,6 +169,22 @@ def test_cpp_driver_matches_python_driver():
     assert (r["steps"], r["ti"]) == (steps_cpp, ti_cpp)
     assert abs(e_cpp - r["e_norm"]) / r["e_norm"] < 1e-9
     assert rel_err(S_cpp, r["S"]) < 1e-9
+
+
+def test_cpp_driver_readme_run8(golden):
+    """README run 8 through the C++ driver (own fem.cpp setup, RK2AvgSolver of
+    laghos_amd/host/laghos_solver.cpp), the command line of README.md:222."""
+    from laghos_amd import host_lib
+    g = next(c for c in golden["readme"] if c["name"] == "README-8")
+    sim = host_lib.Sim(["-p", 4, "-m", "data/square_gresho.mesh", "-rs", 3, "-ok", 3, "-ot", 2,
+                        "-tf", 0.62831853, "-s", 7, "-pa", "-q"])
+    while sim.step() == 1:
+        pass
+    e, ti, dt = sim.e_norm(), sim.ti, sim.dt
+    sim.close()
+    assert ti == g["step"]
+    assert f"{dt:.6f}" == g["dt"]
+    assert abs(e - g["e_norm"]) / g["e_norm"] < 5e-11, (e, g["e_norm"])
 
 
 def test_cpp_driver_unknown_kernel():

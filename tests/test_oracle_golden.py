@@ -22,14 +22,15 @@ def test_checks_table(golden, name):
         assert abs(got - ref) / ref < 1e-12, (name, step, got, ref)
 
 
-README_NAMES = ["README-1", "README-2", "README-3", "README-4", "README-6", "README-7"]
+README_NAMES = ["README-1", "README-2", "README-3", "README-4", "README-6", "README-7", "README-8"]
 
 
 @pytest.mark.parametrize("name", README_NAMES)
 def test_readme_runs(golden, name):
     g = next(c for c in golden["readme"] if c["name"] == name)
-    r = run(Problem(mesh=g["mesh"], rs=g["rs"], problem=g["problem"], blast_energy=g["E0"]),
-            t_final=g["tf"])  # default -cgt 1e-8, -cfl 0.5, Q2Q1, RK4
+    r = run(Problem(mesh=g["mesh"], rs=g["rs"], problem=g["problem"], blast_energy=g["E0"],
+                    order_v=g.get("order_v", 2), order_e=g.get("order_e", 1)),
+            t_final=g["tf"], ode_solver=g.get("ode_solver", 4))  # default -cgt 1e-8, -cfl 0.5, Q2Q1, RK4
     last = r["last"]
     assert last["step"] == g["step"]
     assert f"{last['dt']:.6f}" == g["dt"]
