@@ -97,6 +97,51 @@ __device__ __forceinline__ bool grid_sum3_last_block(const double bp[kVC], doubl
    return true;
 }
 
+// Single-level variant for the persistent K1: its <= 1024 workgroups leave their
+// loops spread over ~15 us (profiles/r1_k1_block_timestamps.txt), so one ticket word
+// is not contended, and the last arrival sums all partials in one pass.  Saves the
+// second store / ticket / reload round trip of the sharded form at the kernel's tail.
+__device__ __forceinline__ bool grid_sum3_last_block_flat(const double bp[kVC], double *partials,
+                                                          const unsigned stride, unsigned int *ticket,
+                                                          double *red, double total[kVC])
+{
+   const int tid = threadIdx.x;
+   const int nthr = blockDim.x;
+   const unsigned int nblk = gridDim.x, bid = blockIdx.x;
+   unsigned int *t2 = ticket + kShards * kTicketStride; // the top word of the slot
+   __shared__ unsigned int s_flag;
+   if (tid == 0)
+   {
+#pragma unroll
+      for (int v = 0; v < kVC; v++)
+      {
+         __hip_atomic_store(&partials[(size_t)v * stride + bid], bp[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned a = __hip_atomic_fetch_add(t2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_flag = (a == nblk - 1) ? 1u : 0u;
+      if (s_flag) { __hip_atomic_store(t2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+   }
+   __syncthreads();
+   if (!s_flag) { return false; }
+   double acc[kVC] = {0.0, 0.0, 0.0};
+   for (unsigned int i = tid; i < nblk; i += nthr)
+   {
+#pragma unroll
+      for (int v = 0; v < kVC; v++)
+      {
+         acc[v] += __hip_atomic_load(&partials[(size_t)v * stride + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+   }
+#pragma unroll
+   for (int v = 0; v < kVC; v++)
+   {
+      total[v] = block_sum(acc[v], red);
+      __syncthreads();
+   }
+   return true;
+}
+
 struct VcgArgs
 {
    int NE, N;
@@ -117,6 +162,7 @@ struct VcgArgs
    unsigned stride;
    unsigned int *ticket;
    int iter, multi;
+   unsigned long long *trace; // debug (LGH_VCG_TRACE=file): per-workgroup time stamps of K1
 };
 
 // ---- K1: y_e^c = B^T D_e B d_e^c for the unconverged components, d^c = z^c + beta_c d^c.
@@ -414,6 +460,8 @@ vcg_apply_plane(const VcgArgs a, const int nbatch)
    __shared__ double red[16];
 
    const int tid = threadIdx.x;
+   unsigned long long t_start = 0, t_loop = 0;
+   if (a.trace) { t_start = wall_clock64(); }
    const int eb = tid / TE, lt = tid - eb * TE;
    const int c = lt / Q, qx = lt - c * Q;
    const int G = gridDim.x;
@@ -600,6 +648,7 @@ vcg_apply_plane(const VcgArgs a, const int nbatch)
          }
       }
    }
+   if (a.trace) { t_loop = wall_clock64(); }
    double bp[kVC];
 #pragma unroll
    for (int k = 0; k < kVC; k++)
@@ -608,7 +657,7 @@ vcg_apply_plane(const VcgArgs a, const int nbatch)
       __syncthreads();
    }
    double total[kVC];
-   if (grid_sum3_last_block(bp, a.partials, a.stride, a.ticket, red, total))
+   if (grid_sum3_last_block_flat(bp, a.partials, a.stride, a.ticket, red, total))
    {
       if (tid == 0)
       {
@@ -621,6 +670,16 @@ vcg_apply_plane(const VcgArgs a, const int nbatch)
          }
          s->first = 0;
       }
+   }
+   if (a.trace && tid == 0)
+   {
+      unsigned xcc = 0, hwid = 0;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+      a.trace[4 * blockIdx.x + 0] = t_start;
+      a.trace[4 * blockIdx.x + 1] = t_loop;
+      a.trace[4 * blockIdx.x + 2] = wall_clock64();
+      a.trace[4 * blockIdx.x + 3] = ((unsigned long long)xcc << 32) | hwid;
    }
 }
 
@@ -926,6 +985,12 @@ int vcg_solve(lgh_ctx *c, const double *B, double *X, double rel_tol, int max_it
    a.s = ds;
    a.stride = c->vcg_stride;
    a.multi = multi ? 1 : 0;
+   // debug: LGH_VCG_TRACE=<file> dumps "block start loop_end end (xcc<<32|hw_id)" of the
+   // last K1 launch of every solve, in 10 ns ticks
+   static const char *trace_path = getenv("LGH_VCG_TRACE");
+   static unsigned long long *trace_dev = nullptr;
+   if (trace_path && !trace_dev) { (void)hipMalloc((void **)&trace_dev, 4 * 4096 * sizeof(unsigned long long)); }
+   a.trace = trace_dev;
    const int nb = ceil_div((long)N, 256);
 
    // init (vector kernels use reduction slot 0, the element kernel slot 1)
@@ -1001,6 +1066,20 @@ int vcg_solve(lgh_ctx *c, const double *B, double *X, double rel_tol, int max_it
             }
          }
          LGH_HIP_CHECK(hipGetLastError());
+      }
+   }
+   if (trace_dev)
+   {
+      std::vector<unsigned long long> h(4 * 4096);
+      (void)hipMemcpy(h.data(), trace_dev, h.size() * 8, hipMemcpyDeviceToHost);
+      FILE *f = fopen(trace_path, "w");
+      if (f)
+      {
+         for (int i = 0; i < c->vcg_grid && i < 4096; i++)
+         {
+            fprintf(f, "%d %llu %llu %llu %llu\n", i, h[4 * i], h[4 * i + 1], h[4 * i + 2], h[4 * i + 3]);
+         }
+         fclose(f);
       }
    }
    int mx = 0;
