@@ -503,6 +503,12 @@ vcg_apply_plane(const VcgArgs a, const int nbatch)
    for (int dx = 0; dx < D; dx++) { bx[dx] = a.B[qx + Q * dx]; }
 #pragma unroll
    for (int q = 0; q < Q; q++) { bt[q] = a.B[q + Q * (qx < D ? qx : 0)]; }
+   // Everything loaded so far (map, scalars, tables) is complete before the pipelined
+   // loop starts: the compiler's wait-count analysis is loop-conservative and otherwise
+   // treats these one-time loads as possibly outstanding in EVERY iteration, which with
+   // in-order vmcnt put an s_waitcnt vmcnt(6) - i.e. a wait for the next batch's
+   // gathers - ahead of the first FMA of each batch.
+   __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
 
    double gz[kVC][GPT], gd[kVC][GPT], gi[GPT], dq[DPT];
    auto load_gather = [&]() { // nodes of mi[]: residual r, direction d, 1/diag
