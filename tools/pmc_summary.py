@@ -1,5 +1,5 @@
 """Developer tool: per-kernel summary of rocprofv3 --pmc counter_collection.csv files.
-usage: python tests/pmc_summary.py <dir-or-csv> [kernel-substring ...]"""
+usage: python tools/pmc_summary.py <dir-or-csv> [kernel-substring ...]"""
 import csv
 import glob
 import os
