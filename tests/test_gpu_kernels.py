@@ -1,9 +1,9 @@
 """GPU parity tests, kernel granularity: every HIP kernel is called through the
 C ABI (liblaghos_hip.so) and compared with the CPU oracle on the same seeded
 inputs.  Tolerances: the oracle follows the reference's summation order
-(x, y, z); the HIP kernels contract z first and use the same fp64 operations
-(-ffp-contract=off), so agreement is at round-off: <= 1e-13 relative to the
-largest entry (SURVEY §8c "Tolerances to state")."""
+(x, y, z) with -ffp-contract=off; the HIP kernels contract in a different order
+and allow FMA contraction, so agreement is at round-off: <= 1e-13
+relative to the largest entry (SURVEY §8c "Tolerances to state")."""
 import numpy as np
 import pytest
 
@@ -14,7 +14,9 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-13
 
 CONFIGS = [
-    # (mesh, rs, order_v, order_e) -> kernel ids 0x234, 0x246, 0x334, 0x346, 0x358, 0x322
+    # (mesh, rs, order_v, order_e) -> kernel ids 0x234, 0x246, 0x334, 0x346, 0x358, 0x322,
+    # and 0x36A (Q5Q4: not instantiated in the reference, laghos_assembly.cpp:544-547;
+    # oracle-only parity, BASELINE config 5)
     ("square01_quad", 2, 2, 1),
     ("square01_quad", 1, 3, 2),
     ("cube01_hex", 1, 2, 1),
@@ -22,6 +24,7 @@ CONFIGS = [
     ("cube01_hex", 0, 4, 3),
     ("cube01_hex", 1, 1, 0),
     ("box01_hex", 0, 3, 2),
+    ("cube01_hex", 0, 5, 4),
 ]
 
 
@@ -174,7 +177,9 @@ def test_cg_l2(pair):
     torch.cuda.synchronize()
     it = g.ctx.cg_solve(1, g.ctx.to_dev(b), x, 1e-10, 300)
     g.ctx.sync()
-    assert abs(it - it_o) <= 1
+    # unpreconditioned CG on the Bernstein mass matrix: at order 4 it needs > 60
+    # iterations and the count moves by a few with the summation order
+    assert abs(it - it_o) <= max(1, it_o // 20), (it, it_o)
     assert rel_err(x.cpu().numpy(), x_o) < 1e-8
 
 
