@@ -133,6 +133,16 @@ int lgh_solve_velocity(lgh_ctx *ctx, const double *S, double *dS_dt, const doubl
 int lgh_solve_energy(lgh_ctx *ctx, const double *S, const double *v_h1, double *dS_dt,
                      double *e_rhs, const double *e_source, double rel_tol, int max_iter,
                      int *l2_iters);
+/* The same SolveEnergy split in two so that LagrangianHydroOperator::Mult
+ * (laghos_solver.cpp:308-326) can overlap it with SolveVelocity, which it does not
+ * depend on: _begin enqueues F^T v and the L2 CG on a second stream, _end completes
+ * the solve and joins the context stream.  Call order: _begin, lgh_solve_velocity,
+ * _end; all pointers must stay valid until _end returns.  The pair is equivalent to
+ * one lgh_solve_energy call (identical iterates) and degrades to it when overlap is
+ * not possible (timers on, several ranks, 2D). */
+int lgh_solve_energy_begin(lgh_ctx *ctx, const double *S, const double *v_h1, double *dS_dt,
+                           double *e_rhs, const double *e_source, double rel_tol, int max_iter);
+int lgh_solve_energy_end(lgh_ctx *ctx, int *l2_iters);
 
 /* ---- vector helpers on the context stream (device pointers) */
 int lgh_vec_set(lgh_ctx *ctx, double *y, double a, long n);              /* y = a */

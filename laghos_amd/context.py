@@ -187,6 +187,16 @@ class Context:
                                         rel_tol, max_iter, ctypes.byref(it)))
         return it.value
 
+    def solve_energy_begin(self, S, v, dS, e_rhs, rel_tol, max_iter, e_source=None):
+        check(self.lib.lgh_solve_energy_begin(self.h, _ptr(S), _ptr(v), _ptr(dS), _ptr(e_rhs),
+                                              _ptr(e_source) if e_source is not None else None,
+                                              rel_tol, max_iter))
+
+    def solve_energy_end(self):
+        it = ctypes.c_int(0)
+        check(self.lib.lgh_solve_energy_end(self.h, ctypes.byref(it)))
+        return it.value
+
     def vec_axpby(self, z, a, x, b, y):
         check(self.lib.lgh_vec_axpby(self.h, _ptr(z), a, _ptr(x), b, _ptr(y), z.numel()))
 

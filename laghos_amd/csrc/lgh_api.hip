@@ -301,6 +301,14 @@ int lgh_destroy(lgh_ctx *c)
       for (hipEvent_t e : c->ktime->ev) { (void)hipEventDestroy(e); }
       delete c->ktime;
    }
+   cg_l2_free(c);
+   if (c->stream2)
+   {
+      (void)hipStreamSynchronize(c->stream2);
+      (void)hipStreamDestroy(c->stream2);
+      (void)hipEventDestroy(c->ev_fork);
+      (void)hipEventDestroy(c->ev_join);
+   }
    extern void lgh_comm_free(lgh_ctx *);
    lgh_comm_free(c);
    if (c->own_stream) { (void)hipStreamDestroy(c->stream); }
@@ -496,6 +504,69 @@ int lgh_solve_energy(lgh_ctx *c, const double *S, const double *v_h1, double *dS
    rc = cg_solve(c, LGH_SPACE_L2, e_rhs, de, rel_tol, max_iter, &it, true); // :481
    timer_stop(c, 1);
    if (rc) { return rc; }
+   const int counted = (it == 0) ? 1 : it; // :486
+   c->timers.c[1] += counted;
+   if (l2_iters) { *l2_iters += counted; }
+   return LGH_OK;
+}
+
+// SolveEnergy does not depend on SolveVelocity's result (it takes v from S), so
+// LagrangianHydroOperator::Mult may run the two concurrently: _begin enqueues F^T v
+// and the first chunk of the L2 CG on the second stream behind a fork event, _end
+// completes the solve and joins.  Falls back to the sequential lgh_solve_energy
+// inside _end when region timers / kernel timing are on (their semantics are
+// sequential, as in the reference), on several ranks (one RCCL communicator must not
+// be driven from two streams), or when the velocity solve would use the scalar CG
+// (shared scratch).  LGH_OVERLAP=0 switches it off.
+static bool energy_overlap_ok(const lgh_ctx *c)
+{
+   static const bool on = !(getenv("LGH_OVERLAP") && getenv("LGH_OVERLAP")[0] == '0');
+   return on && c->multi == 0 && !c->timers.enabled && !(c->ktime && c->ktime->which >= 0) && vcg_available(c);
+}
+int lgh_solve_energy_begin(lgh_ctx *c, const double *S, const double *v_h1, double *dS_dt, double *e_rhs,
+                           const double *e_source, double rel_tol, int max_iter)
+{
+   LGH_CHECK_ARG(c && S && v_h1 && dS_dt && e_rhs);
+   c->e_args = {S, v_h1, dS_dt, e_rhs, e_source, rel_tol, max_iter};
+   if (!energy_overlap_ok(c))
+   {
+      c->e_async = 2;
+      return LGH_OK;
+   }
+   if (!c->stream2)
+   {
+      LGH_HIP_CHECK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+      LGH_HIP_CHECK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+      LGH_HIP_CHECK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+   }
+   LGH_HIP_CHECK(hipEventRecord(c->ev_fork, c->stream));
+   LGH_HIP_CHECK(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+   std::swap(c->stream, c->stream2); // everything below is enqueued on the second stream
+   int rc = lgh_force_mult_transpose(c, v_h1, e_rhs); // :473
+   if (rc == LGH_OK && e_source) { rc = vec_axpby(c, e_rhs, 1.0, e_rhs, 1.0, e_source, c->L2V); } // :477
+   if (rc == LGH_OK) { rc = cg_l2_begin(c, e_rhs, dS_dt + 2 * (size_t)c->H1V, rel_tol, max_iter); } // :481
+   std::swap(c->stream, c->stream2);
+   if (rc) { return rc; }
+   c->e_async = 1;
+   return LGH_OK;
+}
+int lgh_solve_energy_end(lgh_ctx *c, int *l2_iters)
+{
+   LGH_CHECK_ARG(c && (c->e_async == 1 || c->e_async == 2));
+   const int mode = c->e_async;
+   c->e_async = 0;
+   if (mode == 2)
+   {
+      return lgh_solve_energy(c, c->e_args.S, c->e_args.v, c->e_args.dS, c->e_args.e_rhs, c->e_args.src,
+                              c->e_args.tol, c->e_args.maxit, l2_iters);
+   }
+   int it = 0;
+   std::swap(c->stream, c->stream2);
+   int rc = cg_l2_end(c, &it);
+   if (rc == LGH_OK) { rc = (hipEventRecord(c->ev_join, c->stream) == hipSuccess) ? LGH_OK : LGH_ERR_HIP; }
+   std::swap(c->stream, c->stream2);
+   if (rc) { return rc; }
+   LGH_HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
    const int counted = (it == 0) ? 1 : it; // :486
    c->timers.c[1] += counted;
    if (l2_iters) { *l2_iters += counted; }

@@ -82,6 +82,12 @@ struct lgh_ctx
    double cfl, h0, h1order;
    int device;
    hipStream_t stream;
+   // second stream + fork/join events: the energy solve overlaps the velocity solve (lgh_api.hip)
+   hipStream_t stream2;
+   hipEvent_t ev_fork, ev_join;
+   void *l2run;          // state of a split L2 solve (lgh_mass.hip)
+   int e_async;          // 1: lgh_solve_energy_begin enqueued the solve, 2: deferred to _end
+   struct { const double *S, *v; double *dS, *e_rhs; const double *src; double tol; int maxit; } e_args;
    bool own_stream;
 
    // tables (device): B_h1/G_h1 [q + Q*d], B_l2 [q + Q*l], weights [NQ]
@@ -312,6 +318,10 @@ int mass_apply_l2(lgh_ctx *c, const double *x, double *y);
 int mass_apply_E(lgh_ctx *c, int space, const double *xE, double *yE);
 int mass_assemble_diag(lgh_ctx *c);
 int vcg_solve(lgh_ctx *c, const double *B, double *X, double rel_tol, int max_iter, int iters[3]);
+bool vcg_available(const lgh_ctx *c);
+int cg_l2_begin(lgh_ctx *c, const double *b, double *x, double rel_tol, int max_iter);
+int cg_l2_end(lgh_ctx *c, int *iters);
+void cg_l2_free(lgh_ctx *c);
 int cg_solve(lgh_ctx *c, int space, const double *b, double *x, double rel_tol, int max_iter,
              int *iters, bool x_is_zero);
 int qupdate(lgh_ctx *c, const double *S);

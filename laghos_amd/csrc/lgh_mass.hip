@@ -894,4 +894,103 @@ int cg_solve(lgh_ctx *c, int space, const double *b, double *x, double rel_tol, 
    return LGH_OK;
 }
 
+// ---- the L2 (energy) solve split into an enqueue-only half and a completing half -----
+// SolveEnergy (laghos_solver.cpp:400-493) needs only the quadrature data and the
+// velocity block of S - not the result of SolveVelocity.  lgh_solve_energy_begin
+// enqueues F^T v and the first chunk of CG iterations on the context's second stream
+// (the caller swaps the stream in), the velocity solve then runs on the main stream
+// with its host round trips, and lgh_solve_energy_end looks at the convergence flag.
+// Same kernels, same order and same scalars as cg_solve(LGH_SPACE_L2): the iterates
+// are identical, only the initial look (rhs == 0) is folded into the first one.
+struct L2Run
+{
+   CgVecArgs v;
+   MassArgs m;
+   int it, max_iter, nbu;
+   bool active;
+};
+
+static int l2_enqueue(lgh_ctx *c, L2Run *r, int upto)
+{
+   for (; r->it < upto;)
+   {
+      ++r->it;
+      int rc = launch_mass<3>(c, LGH_SPACE_L2, r->m);
+      if (rc) { return rc; }
+      r->v.iter = r->it;
+      hipLaunchKernelGGL((cg_update_k<false, 0>), dim3(r->nbu), dim3(256), 0, c->stream, r->v);
+      LGH_HIP_CHECK(hipGetLastError());
+   }
+   return LGH_OK;
+}
+
+int cg_l2_begin(lgh_ctx *c, const double *b, double *x, double rel_tol, int max_iter)
+{
+   if (c->multi != 0) { return LGH_ERR_UNSUPPORTED; }
+   if (!c->l2run) { c->l2run = new L2Run(); }
+   L2Run *r = (L2Run *)c->l2run;
+   const int n = c->L2V;
+   hipLaunchKernelGGL(cg_set_tol_k, dim3(1), dim3(1), 0, c->stream, c->cgs, rel_tol * rel_tol);
+   CgVecArgs &v = r->v;
+   memset(&v, 0, sizeof(v));
+   v.n = n;
+   v.b = b;
+   v.x = x;
+   v.r = c->cg_r;
+   v.z = c->cg_r; // no preconditioner: z aliases r
+   v.cgs = c->cgs;
+   v.partials = c->partials;
+   v.ticket = c->tickets;
+   int rc = vec_set(c, x, 0.0, n); // the L2 solve starts from x = 0
+   if (rc) { return rc; }
+   hipLaunchKernelGGL(cg_init_k<false>, dim3(ceil_div(n, 256)), dim3(256), 0, c->stream, v);
+   LGH_HIP_CHECK(hipGetLastError());
+   MassArgs &m = r->m;
+   m = base_args(c, LGH_SPACE_L2);
+   m.x = c->cg_r;
+   m.map = nullptr;
+   m.y = c->cg_y;
+   m.cgs = c->cgs;
+   m.partials = c->partials + c->part_stride;
+   m.ticket = c->tickets + 1 * kTicketSlot;
+   m.multi = 0;
+   m.d = c->cg_d0;
+   v.d = c->cg_d0;
+   v.d_in_place = 1;
+   v.yL = c->cg_y;
+   r->it = 0;
+   r->max_iter = max_iter;
+   r->nbu = ceil_div(n, 256 * kUpdU);
+   r->active = true;
+   const int last = c->cg_last_iters[1][0];
+   return l2_enqueue(c, r, std::min(max_iter, last > 0 ? last : 8));
+}
+
+int cg_l2_end(lgh_ctx *c, int *iters)
+{
+   L2Run *r = (L2Run *)c->l2run;
+   if (!r || !r->active) { return LGH_ERR_ARG; }
+   CgScalars *hs = (CgScalars *)c->host_pinned;
+   while (true)
+   {
+      LGH_HIP_CHECK(hipMemcpyAsync(hs, c->cgs, sizeof(CgScalars), hipMemcpyDeviceToHost, c->stream));
+      LGH_HIP_CHECK(hipStreamSynchronize(c->stream));
+      if (hs->done || r->it >= r->max_iter) { break; }
+      const int rc = l2_enqueue(c, r, std::min(r->max_iter, r->it + 2));
+      if (rc) { return rc; }
+   }
+   int fin = hs->iters;
+   if (!hs->done && r->it >= r->max_iter) { fin = r->max_iter; }
+   c->cg_last_iters[1][0] = fin;
+   if (iters) { *iters = fin; }
+   r->active = false;
+   return LGH_OK;
+}
+void cg_l2_free(lgh_ctx *c)
+{
+   delete (L2Run *)c->l2run;
+   c->l2run = nullptr;
+}
+
+
 } // namespace lgh

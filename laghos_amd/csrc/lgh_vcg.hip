@@ -945,6 +945,8 @@ template <int D, int Q> static void launch_vcg_apply(lgh_ctx *c, const VcgArgs &
       else { launch_vcg_plane<D_, Q_>(c, a); }                                     \
    } while (0)
 
+bool vcg_available(const lgh_ctx *c) { return vcg_supported(c); }
+
 // B, X: dim*N (byNODES).  X must be zero on entry (dv = 0, laghos_solver.cpp:338, :382).
 // iters[c] = GetNumIterations() of component c.
 int vcg_solve(lgh_ctx *c, const double *B, double *X, double rel_tol, int max_iter, int iters[3])

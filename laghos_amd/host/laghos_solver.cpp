@@ -122,10 +122,15 @@ void LagrangianHydroOperator::Mult(const Vector &S, Vector &dS_dt) const
    UpdateMesh(S);
    // dx_dt = v (laghos_solver.cpp:323)
    LGH_VERIFY(lgh_vec_copy(ctx, dS_dt.Write(), S.Read() + H1Vsize, H1Vsize));
+   // SolveVelocity(S, dS_dt); SolveEnergy(S, v, dS_dt) (:324-325).  SolveEnergy takes v
+   // from S, not from SolveVelocity's result, so the library may overlap the two: the
+   // energy solve is enqueued first (second stream) and completed after the velocity solve.
+   UpdateQuadratureData(S); // :332 / :445
+   LGH_VERIFY(lgh_solve_energy_begin(ctx, S.Read(), S.Read() + H1Vsize, dS_dt.Write(), e_rhs.Write(), nullptr,
+                                     cg_rel_tol, cg_max_iter));
    SolveVelocity(S, dS_dt);
-   Vector v;
-   v.MakeRef(const_cast<double *>(S.Read()) + H1Vsize, H1Vsize);
-   SolveEnergy(S, v, dS_dt);
+   int it = 0;
+   LGH_VERIFY(lgh_solve_energy_end(ctx, &it));
    qdata_is_current = false; // :326
 }
 

@@ -68,6 +68,20 @@ def test_q3q2_sedov_vs_oracle():
     assert r["steps"] == o["steps"]
 
 
+def test_overlapped_energy_solve_is_bit_identical():
+    """lgh_solve_energy_begin/_end (energy solve on a second stream while the velocity
+    solve runs; active when the region timers are off) must give exactly the state of
+    the sequential SolveVelocity -> SolveEnergy order: same kernels, same reductions."""
+    from laghos_amd.hydro import run
+    from oracle.fem import Problem
+    kw = dict(mesh="cube01_hex", rs=2, order_v=3, order_e=2, problem=1)
+    seq = run(Problem(**kw), t_final=0.6, max_steps=12, timers=True)
+    ovl = run(Problem(**kw), t_final=0.6, max_steps=12, timers=False)
+    assert (seq["steps"], seq["ti"]) == (ovl["steps"], ovl["ti"])
+    assert seq["dt"] == ovl["dt"]
+    assert np.array_equal(seq["S"], ovl["S"])
+
+
 @pytest.fixture(scope="module")
 def full_size():
     """BASELINE configs[1]: 3D Sedov cube01_hex -rs 4 -ok 3 -ot 2 (32768 elements)"""
