@@ -17,6 +17,12 @@
 #include <cstdlib>
 
 #include <algorithm>
+#include <chrono>
+#include <condition_variable>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
 #include <utility>
 
 #include "lgh_common.hpp"
@@ -86,9 +92,54 @@ static int load_nccl()
       }                                                                                  \
    } while (0)
 
+// ---- in-process loopback communicator (test vehicle) -------------------------------
+// A unique id that starts with "LGHLOCAL" selects it: the ranks are contexts of ONE
+// process (one host thread each, any devices that can copy to each other - in the
+// tests all on the single GPU of the box) and the two collectives are carried out
+// with stream synchronisation, host barriers and device-to-device copies.  Everything
+// else - owner masks, pack / canonical combine kernels, the separate-gather CG
+// sequencing, finish kernels, dt and norm reductions - is the code that runs over RCCL
+// on a node, so a multi-rank run can be checked against a single-rank one without a
+// multi-GPU machine.  Not a product path: RCCL over xGMI is.
+struct LocalGroup
+{
+   int n = 0;
+   std::mutex m;
+   std::condition_variable cv;
+   int arrived = 0;
+   long gen = 0;
+   bool broken = false;
+   std::vector<lgh_ctx *> ctx;   // by rank
+   std::vector<double> slots;    // n * 8 doubles of all-reduce staging
+   bool barrier()
+   {
+      std::unique_lock<std::mutex> lk(m);
+      if (broken) { return false; }
+      const long g = gen;
+      if (++arrived == n)
+      {
+         arrived = 0;
+         gen++;
+         cv.notify_all();
+         return true;
+      }
+      // a rank that never arrives (diverged control flow) must fail the test, not hang it
+      if (!cv.wait_for(lk, std::chrono::seconds(60), [&] { return gen != g || broken; }))
+      {
+         broken = true;
+         cv.notify_all();
+         return false;
+      }
+      return !broken;
+   }
+};
+static std::mutex g_local_m;
+static std::map<std::string, std::shared_ptr<LocalGroup>> g_local;
+
 struct Comm
 {
    ncclComm_t comm = nullptr;
+   std::shared_ptr<LocalGroup> local;
    int n_nbr = 0;
    std::vector<int> nbr_rank, nbr_count, nbr_off; // offsets into the packed buffers
    int total = 0;        // sum of nbr_count
@@ -146,6 +197,32 @@ int halo_sum(lgh_ctx *c, double *v, int ncomp)
    hipLaunchKernelGGL(halo_pack_k, dim3(ceil_div((long)tot * ncomp, 256)), dim3(256), 0, c->stream, tot,
                       ncomp, c->N, cm->nodes, cm->pos, cm->cnt, v, cm->sendbuf);
    LGH_HIP_CHECK(hipGetLastError());
+   if (cm->local)
+   {
+      LocalGroup *g = cm->local.get();
+      LGH_HIP_CHECK(hipStreamSynchronize(c->stream)); // my send buffer is packed
+      if (!g->barrier()) { set_error("local communicator: barrier timed out (halo)"); return LGH_ERR_COMM; }
+      for (int k = 0; k < cm->n_nbr; k++)
+      {
+         const Comm *pc = g->ctx[cm->nbr_rank[k]]->comm;
+         int kk = -1;
+         for (int j = 0; j < pc->n_nbr; j++) { if (pc->nbr_rank[j] == c->rank) { kk = j; } }
+         if (kk < 0 || pc->nbr_count[kk] != cm->nbr_count[k])
+         {
+            set_error("local communicator: neighbour lists of ranks %d and %d do not match", c->rank, cm->nbr_rank[k]);
+            return LGH_ERR_COMM;
+         }
+         LGH_HIP_CHECK(hipMemcpyAsync(cm->recvbuf + 3 * (size_t)cm->nbr_off[k], pc->sendbuf + 3 * (size_t)pc->nbr_off[kk],
+                                      (size_t)ncomp * cm->nbr_count[k] * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+      }
+      LGH_HIP_CHECK(hipStreamSynchronize(c->stream));
+      if (!g->barrier()) { set_error("local communicator: barrier timed out (halo)"); return LGH_ERR_COMM; } // peers may repack
+      hipLaunchKernelGGL(halo_combine_k, dim3(ceil_div((long)cm->n_shared * ncomp, 256)), dim3(256), 0,
+                         c->stream, cm->n_shared, ncomp, c->N, cm->sh_node, cm->sh_off, cm->sh_src, cm->pos,
+                         cm->cnt, cm->recvbuf, v);
+      LGH_HIP_CHECK(hipGetLastError());
+      return LGH_OK;
+   }
    LGH_NCCL_CHECK(g_nccl.GroupStart());
    for (int k = 0; k < cm->n_nbr; k++)
    {
@@ -165,6 +242,31 @@ int halo_sum(lgh_ctx *c, double *v, int ncomp)
 int allreduce_dev(lgh_ctx *c, double *dev, int count, int op)
 {
    Comm *cm = c->comm;
+   if (cm && cm->local)
+   {
+      LocalGroup *g = cm->local.get();
+      if (count > 8) { set_error("local communicator: count > 8"); return LGH_ERR_ARG; }
+      double mine[8];
+      LGH_HIP_CHECK(hipMemcpyAsync(mine, dev, count * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+      LGH_HIP_CHECK(hipStreamSynchronize(c->stream));
+      for (int i = 0; i < count; i++) { g->slots[(size_t)c->rank * 8 + i] = mine[i]; }
+      if (!g->barrier()) { set_error("local communicator: barrier timed out (all-reduce)"); return LGH_ERR_COMM; }
+      double res[8];
+      for (int i = 0; i < count; i++)
+      {
+         double r = g->slots[i];
+         for (int k = 1; k < g->n; k++)
+         {
+            const double x = g->slots[(size_t)k * 8 + i];
+            r = (op == 0) ? r + x : std::min(r, x); // rank order: identical on every rank
+         }
+         res[i] = r;
+      }
+      if (!g->barrier()) { set_error("local communicator: barrier timed out (all-reduce)"); return LGH_ERR_COMM; }
+      LGH_HIP_CHECK(hipMemcpyAsync(dev, res, count * sizeof(double), hipMemcpyHostToDevice, c->stream));
+      LGH_HIP_CHECK(hipStreamSynchronize(c->stream));
+      return LGH_OK;
+   }
    if (!cm || !cm->comm) { return LGH_OK; }
    LGH_NCCL_CHECK(g_nccl.AllReduce(dev, dev, (size_t)count, ncclFloat64, op == 0 ? ncclSum : ncclMin, cm->comm, c->stream));
    return LGH_OK;
@@ -181,6 +283,21 @@ void lgh_comm_free(lgh_ctx *c)
 {
    if (!c || !c->comm) { return; }
    Comm *cm = c->comm;
+   if (cm->local)
+   {
+      std::lock_guard<std::mutex> lk(g_local_m);
+      for (auto it = g_local.begin(); it != g_local.end();)
+      {
+         if (it->second == cm->local)
+         {
+            it->second->ctx[c->rank] = nullptr;
+            bool any = false;
+            for (lgh_ctx *p : it->second->ctx) { any = any || p; }
+            it = any ? std::next(it) : g_local.erase(it);
+         }
+         else { ++it; }
+      }
+   }
    if (cm->comm && g_nccl.CommDestroy) { g_nccl.CommDestroy(cm->comm); }
    void *ptrs[] = {cm->nodes, cm->sendbuf, cm->recvbuf, cm->sh_node, cm->sh_off, cm->sh_src, cm->pos, cm->cnt};
    for (void *p : ptrs) { if (p) { (void)hipFree(p); } }
@@ -202,6 +319,32 @@ int lgh_comm_unique_id(char id_out[128])
 int lgh_comm_init(lgh_ctx *c, int nranks, int rank, const char unique_id[128])
 {
    LGH_CHECK_ARG(c && nranks >= 1 && rank >= 0 && rank < nranks && unique_id);
+   if (memcmp(unique_id, "LGHLOCAL", 8) == 0) // in-process loopback communicator (tests)
+   {
+      if (!c->comm) { c->comm = new Comm(); }
+      std::shared_ptr<LocalGroup> g;
+      {
+         std::lock_guard<std::mutex> lk(g_local_m);
+         const std::string key(unique_id, 128);
+         auto &slot = g_local[key];
+         if (!slot)
+         {
+            slot = std::make_shared<LocalGroup>();
+            slot->n = nranks;
+            slot->ctx.assign(nranks, nullptr);
+            slot->slots.assign((size_t)nranks * 8, 0.0);
+         }
+         if (slot->n != nranks || slot->ctx[rank]) { set_error("local communicator: rank %d registered twice", rank); return LGH_ERR_ARG; }
+         slot->ctx[rank] = c;
+         g = slot;
+      }
+      c->comm->local = g;
+      c->nranks = nranks;
+      c->rank = rank;
+      c->multi = 1;
+      if (!g->barrier()) { set_error("local communicator: not all %d ranks arrived", nranks); return LGH_ERR_COMM; }
+      return LGH_OK;
+   }
    int rc = load_nccl();
    if (rc) { return rc; }
    LGH_HIP_CHECK(hipSetDevice(c->device));

@@ -321,3 +321,50 @@ def test_halo_logic_emulated_ranks(pgrid):
             seen[g] = v
     for c in ctxs + [ref]:
         c.close()
+
+
+@pytest.mark.parametrize("nranks", [2, 8])
+def test_multi_rank_run_on_one_gpu(nranks):
+    """The complete multi-rank algorithm (block partition, owner-weighted dot products,
+    halo pack / canonical combine, separate-gather CG sequencing with its finish
+    kernels, dt / |e| reductions) on ONE GPU: the ranks are contexts driven by one host
+    thread each over the in-process loopback communicator (lgh_comm.hip, unique id
+    "LGHLOCAL..."), which replaces only the RCCL transport.  Must reproduce the
+    single-rank run of the same global problem: same accepted / repeated steps, dt and
+    |e| to round-off (the ranks sum shared-node contributions in a different order)."""
+    import os
+    import threading
+    from laghos_amd import host_lib
+    args = ["-p", 1, "-dim", 3, "-nx", 8, "-ny", 8, "-nz", 8, "-Sx", 1, "-Sy", 1, "-Sz", 1, "-rs", 0,
+            "-ok", 3, "-ot", 2, "-pa", "-tf", 0.6, "-ms", 6, "-q"]
+    ref = host_lib.Sim(args)
+    while ref.step() == 1:
+        pass
+    want = dict(e=ref.e_norm(), t=ref.t, dt=ref.dt, rk=ref.rk_steps, ti=ref.ti)
+    ref.close()
+
+    cid = (b"LGHLOCAL" + os.urandom(16).hex().encode()).ljust(128, b"\0")
+    out, err = {}, {}
+
+    def rank_main(rank):
+        try:
+            sim = host_lib.Sim(args, nranks=nranks, rank=rank, nccl_id=cid)
+            while sim.step() == 1:
+                pass
+            out[rank] = dict(e=sim.e_norm(), t=sim.t, dt=sim.dt, rk=sim.rk_steps, ti=sim.ti)
+            sim.close()
+        except Exception as ex:  # noqa: BLE001 - reported below
+            err[rank] = repr(ex)
+
+    threads = [threading.Thread(target=rank_main, args=(r,), daemon=True) for r in range(nranks)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=240)
+    assert not any(t.is_alive() for t in threads), "a rank did not finish (collective mismatch?)"
+    assert not err, err
+    for r in range(nranks):
+        got = out[r]
+        assert (got["rk"], got["ti"]) == (want["rk"], want["ti"]), (r, got, want)
+        assert abs(got["dt"] - want["dt"]) <= 1e-12 * want["dt"], (r, got, want)
+        assert abs(got["e"] - want["e"]) <= 1e-10 * want["e"], (r, got, want)
