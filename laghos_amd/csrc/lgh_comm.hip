@@ -148,6 +148,7 @@ struct Comm
    int n_shared = 0;                               // unique shared nodes
    int *sh_node = nullptr, *sh_off = nullptr, *sh_src = nullptr; // device CSR (see halo_combine_k)
    int *pos = nullptr, *cnt = nullptr; // per concatenated entry: buffer position, neighbour count
+   uint8_t *hmask = nullptr;           // device: 1 for every shared node
 };
 
 // Buffers: neighbour k owns the contiguous block [3*off_k, 3*off_k + ncomp*cnt_k):
@@ -239,6 +240,14 @@ int halo_sum(lgh_ctx *c, double *v, int ncomp)
    return LGH_OK;
 }
 
+void comm_shared_nodes(const lgh_ctx *c, const uint8_t **hmask, const int **sh_node, int *n_shared)
+{
+   const Comm *cm = c->comm;
+   *hmask = (cm && cm->hmask) ? cm->hmask : nullptr;
+   *sh_node = cm ? cm->sh_node : nullptr;
+   *n_shared = (cm && cm->hmask) ? cm->n_shared : 0;
+}
+
 int allreduce_dev(lgh_ctx *c, double *dev, int count, int op)
 {
    Comm *cm = c->comm;
@@ -299,7 +308,7 @@ void lgh_comm_free(lgh_ctx *c)
       }
    }
    if (cm->comm && g_nccl.CommDestroy) { g_nccl.CommDestroy(cm->comm); }
-   void *ptrs[] = {cm->nodes, cm->sendbuf, cm->recvbuf, cm->sh_node, cm->sh_off, cm->sh_src, cm->pos, cm->cnt};
+   void *ptrs[] = {cm->nodes, cm->sendbuf, cm->recvbuf, cm->sh_node, cm->sh_off, cm->sh_src, cm->pos, cm->cnt, cm->hmask};
    for (void *p : ptrs) { if (p) { (void)hipFree(p); } }
    delete cm;
    c->comm = nullptr;
@@ -421,6 +430,11 @@ int lgh_comm_set_neighbors(lgh_ctx *c, int n_nbr, const int *nbr_rank, const int
       if (!uniq.empty()) { LGH_HIP_CHECK(hipMemcpy(cm->sh_node, uniq.data(), uniq.size() * sizeof(int), hipMemcpyHostToDevice)); }
       LGH_HIP_CHECK(hipMemcpy(cm->sh_off, off.data(), off.size() * sizeof(int), hipMemcpyHostToDevice));
       if (!src.empty()) { LGH_HIP_CHECK(hipMemcpy(cm->sh_src, src.data(), src.size() * sizeof(int), hipMemcpyHostToDevice)); }
+      std::vector<uint8_t> hm((size_t)c->N, 0);
+      for (int n : uniq) { hm[n] = 1; }
+      if (cm->hmask) { (void)hipFree(cm->hmask); }
+      LGH_HIP_CHECK(hipMalloc((void **)&cm->hmask, std::max<size_t>(hm.size(), 1)));
+      LGH_HIP_CHECK(hipMemcpy(cm->hmask, hm.data(), hm.size(), hipMemcpyHostToDevice));
    }
    if (cm->nodes) { (void)hipFree(cm->nodes); (void)hipFree(cm->sendbuf); (void)hipFree(cm->recvbuf); (void)hipFree(cm->pos); (void)hipFree(cm->cnt); }
    {

@@ -319,6 +319,8 @@ int mass_apply_E(lgh_ctx *c, int space, const double *xE, double *yE);
 int mass_assemble_diag(lgh_ctx *c);
 int vcg_solve(lgh_ctx *c, const double *B, double *X, double rel_tol, int max_iter, int iters[3]);
 bool vcg_available(const lgh_ctx *c);
+// multi-rank: flags / list of the nodes shared with other ranks (nullptr / 0 without neighbours)
+void comm_shared_nodes(const lgh_ctx *c, const uint8_t **hmask, const int **sh_node, int *n_shared);
 int cg_l2_begin(lgh_ctx *c, const double *b, double *x, double rel_tol, int max_iter);
 int cg_l2_end(lgh_ctx *c, int *iters);
 void cg_l2_free(lgh_ctx *c);

@@ -163,6 +163,11 @@ struct VcgArgs
    unsigned int *ticket;
    int iter, multi;
    unsigned long long *trace; // debug (LGH_VCG_TRACE=file): per-workgroup time stamps of K1
+   // multi-rank: nodes shared with other ranks take their (halo-summed) A d from yL,
+   // all others gather it from the E-vector as on one rank
+   const uint8_t *hmask;      // N flags, or nullptr
+   const int *sh_node;        // the shared nodes
+   int n_shared;
 };
 
 // ---- K1: y_e^c = B^T D_e B d_e^c for the unconverged components, d^c = z^c + beta_c d^c.
@@ -802,6 +807,7 @@ vcg_update_k(const VcgArgs a)
    }
    const double di = a.dinv[nn];
    const double ow = a.owner ? a.owner[nn] : 1.0;
+   const bool shared = FUSED_GATHER && a.hmask && a.hmask[nn];
 #pragma unroll 1
    for (int c = 0; c < kVC; c++)
    {
@@ -812,10 +818,14 @@ vcg_update_k(const VcgArgs a)
       double zv;
       if (FUSED_GATHER)
       {
-         const double *yc = a.YE + (size_t)c * a.ye_stride;
-         zv = 0.0;
+         if (shared) { zv = a.yL[i]; } // summed over the ranks by halo_sum
+         else
+         {
+            const double *yc = a.YE + (size_t)c * a.ye_stride;
+            zv = 0.0;
 #pragma unroll
-         for (int j = 0; j < DEG; j++) { if (pidx[j] >= 0) { zv += yc[pidx[j]]; } }
+            for (int j = 0; j < DEG; j++) { if (pidx[j] >= 0) { zv += yc[pidx[j]]; } }
+         }
       }
       else { zv = a.yL[i]; }
       if (a.ess[c] && a.ess[c][nn]) { zv = 0.0; }
@@ -871,6 +881,27 @@ vcg_gather_k(const VcgArgs a)
 {
    const int n = blockIdx.x * blockDim.x + threadIdx.x;
    if (n >= a.N) { return; }
+   for (int c = 0; c < kVC; c++)
+   {
+      if (a.s->done[c]) { continue; }
+      const double *yc = a.YE + (size_t)c * a.ye_stride;
+      double s = 0.0;
+      for (int j = 0; j < a.deg; j++)
+      {
+         const int p = a.ell[(size_t)j * a.N + n];
+         if (p >= 0) { s += yc[p]; }
+      }
+      a.yL[(size_t)c * a.N + n] = s;
+   }
+}
+
+// E -> L sum at the listed (rank-shared) nodes only: what the halo exchange needs
+__global__ void __launch_bounds__(256)
+vcg_gather_list_k(const VcgArgs a)
+{
+   const int u = blockIdx.x * blockDim.x + threadIdx.x;
+   if (u >= a.n_shared) { return; }
+   const int n = a.sh_node[u];
    for (int c = 0; c < kVC; c++)
    {
       if (a.s->done[c]) { continue; }
@@ -999,6 +1030,7 @@ int vcg_solve(lgh_ctx *c, const double *B, double *X, double rel_tol, int max_it
    static unsigned long long *trace_dev = nullptr;
    if (trace_path && !trace_dev) { (void)hipMalloc((void **)&trace_dev, 4 * 4096 * sizeof(unsigned long long)); }
    a.trace = trace_dev;
+   if (multi) { comm_shared_nodes(c, &a.hmask, &a.sh_node, &a.n_shared); }
    const int nb = ceil_div((long)N, 256);
 
    // init (vector kernels use reduction slot 0, the element kernel slot 1)
@@ -1054,8 +1086,17 @@ int vcg_solve(lgh_ctx *c, const double *B, double *X, double rel_tol, int max_it
          }
          else
          {
-            // assemble the L-vectors, sum shared nodes across ranks, all-reduce the scalars
-            hipLaunchKernelGGL(vcg_gather_k, dim3(nb), dim3(256), 0, c->stream, a);
+            // A d as L-vectors: only at the nodes shared with other ranks when K2 can
+            // gather the rest itself; sum shared nodes across ranks, all-reduce the scalars
+            const bool mixed = multi && c->t_deg <= 8 && a.hmask != nullptr;
+            if (mixed)
+            {
+               if (a.n_shared > 0)
+               {
+                  hipLaunchKernelGGL(vcg_gather_list_k, dim3(ceil_div(a.n_shared, 256)), dim3(256), 0, c->stream, a);
+               }
+            }
+            else { hipLaunchKernelGGL(vcg_gather_k, dim3(nb), dim3(256), 0, c->stream, a); }
             LGH_HIP_CHECK(hipGetLastError());
             if (multi)
             {
@@ -1065,7 +1106,8 @@ int vcg_solve(lgh_ctx *c, const double *B, double *X, double rel_tol, int max_it
                if (rc) { return rc; }
                hipLaunchKernelGGL(vcg_den_finish_k, dim3(1), dim3(1), 0, c->stream, ds);
             }
-            hipLaunchKernelGGL((vcg_update_k<false, 0>), dim3(nb), dim3(256), 0, c->stream, a);
+            if (mixed) { hipLaunchKernelGGL((vcg_update_k<true, 8>), dim3(nb), dim3(256), 0, c->stream, a); }
+            else { hipLaunchKernelGGL((vcg_update_k<false, 0>), dim3(nb), dim3(256), 0, c->stream, a); }
             if (multi)
             {
                rc = allreduce_dev(c, ds->rz, kVC, 0);
