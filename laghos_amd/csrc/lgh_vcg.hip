@@ -179,7 +179,7 @@ struct VcgArgs
 // quadrature data of batch i+1 are in flight while batch i is contracted, and
 // the dot-product partials are published once per workgroup.
 template <int D, int Q, int NEB>
-__global__ void __launch_bounds__(Q *Q *NEB, 2)
+__global__ void __launch_bounds__(Q *Q *NEB, (Q >= 8) ? 1 : 2)
 vcg_apply_3d(const VcgArgs a, const int nbatch)
 {
    constexpr int NQ = Q * Q * Q, ND = D * D * D;
