@@ -537,8 +537,9 @@ LGH_HD void min_eigenpair3(const double *data, double &lambda, double *vec)
       else
       {
          R = R / sqrtQ3;
-         if (R < 0.) { r = -2 * sqrtQ * cos((acos(R) + 2.0 * M_PI) / 3); }
-         else { r = -2 * sqrtQ * cos(acos(R) / 3); }
+         // one acos / cos call site for both signs: (acos(R) + 0.0) / 3 is exactly the
+         // reference's acos(R) / 3, and a wave with both signs runs the pair once
+         r = -2 * sqrtQ * cos((acos(R) + ((R < 0.) ? 2.0 * M_PI : 0.0)) / 3);
       }
       aa += r;
       c1 = d11 - aa;
@@ -670,15 +671,18 @@ LGH_HD double min_singular3(const double *data)
       else
       {
          R = R / sqrtQ3;
-         if (fabs(R) <= 0.9)
+         // the three cases share one acos / cos call site (see min_eigenpair3)
+         const bool mid = (fabs(R) <= 0.9), neg = (R < 0.);
+         const double cs = cos((acos(R) + ((!mid && neg) ? 2.0 * M_PI : 0.0)) / 3);
+         if (mid)
          {
-            aa -= 2 * sqrtQ * cos(acos(R) / 3); // min root directly
+            aa -= 2 * sqrtQ * cs; // min root directly
             have = true;
          }
-         else if (R < 0.) { r = -2 * sqrtQ * cos((acos(R) + 2.0 * M_PI) / 3); } // max is isolated
+         else if (neg) { r = -2 * sqrtQ * cs; } // max is isolated
          else
          {
-            r = -2 * sqrtQ * cos(acos(R) / 3); // min is isolated
+            r = -2 * sqrtQ * cs; // min is isolated
             aa += r;
             have = true;
          }
