@@ -1053,10 +1053,16 @@ int vcg_solve(lgh_ctx *c, const double *B, double *X, double rel_tol, int max_it
    bool first_look = true;
    while (true)
    {
-      LGH_HIP_CHECK(hipMemcpyAsync(hs, ds, sizeof(VcgScalars), hipMemcpyDeviceToHost, c->stream));
-      LGH_HIP_CHECK(hipStreamSynchronize(c->stream));
-      if (hs->all_done || it >= max_iter) { break; }
-      if (!first_look) { chunk = 2; }
+      // The first chunk is enqueued without looking at the flag first (an all-zero
+      // right-hand side just makes its launches return at once): one host round trip,
+      // with the GPU idle meanwhile, less per solve.
+      if (!first_look || max_iter <= 0)
+      {
+         LGH_HIP_CHECK(hipMemcpyAsync(hs, ds, sizeof(VcgScalars), hipMemcpyDeviceToHost, c->stream));
+         LGH_HIP_CHECK(hipStreamSynchronize(c->stream));
+         if (hs->all_done || it >= max_iter) { break; }
+         chunk = 2;
+      }
       first_look = false;
       const int upto = std::min(max_iter, it + chunk);
       while (it < upto)
