@@ -141,7 +141,7 @@ struct Comm
    ncclComm_t comm = nullptr;
    std::shared_ptr<LocalGroup> local;
    int n_nbr = 0;
-   std::vector<int> nbr_rank, nbr_count, nbr_off; // offsets into the packed buffers
+   std::vector<int> nbr_rank, nbr_count, nbr_off, nbr_base; // node offsets / buffer bases of the neighbours
    int total = 0;        // sum of nbr_count
    int *nodes = nullptr; // device: concatenated neighbour node lists
    double *sendbuf = nullptr, *recvbuf = nullptr; // device: total * 3 doubles
@@ -149,11 +149,20 @@ struct Comm
    int *sh_node = nullptr, *sh_off = nullptr, *sh_src = nullptr; // device CSR (see halo_combine_k)
    int *pos = nullptr, *cnt = nullptr; // per concatenated entry: buffer position, neighbour count
    uint8_t *hmask = nullptr;           // device: 1 for every shared node
+   // piggy-backed scalars: when every other rank is a neighbour (block partitions of up
+   // to 2x2x2) a few doubles ride on each halo message and are summed in rank order by
+   // the combine kernel - one collective less per CG iteration
+   bool allpairs = false;
+   int *d_base = nullptr, *d_cnt = nullptr; // device, per neighbour: block base, node count
+   int *rank_src = nullptr;                 // device, per rank: neighbour index or -1 (self)
+   int bufsize = 0;                         // doubles in sendbuf / recvbuf
 };
+constexpr int kHaloSlack = 4; // doubles of room behind every neighbour's block (<= 3 scalars used)
 
-// Buffers: neighbour k owns the contiguous block [3*off_k, 3*off_k + ncomp*cnt_k):
-// component-major inside the block, so every neighbour is ONE send and ONE recv.
-// pos[j] = 3*off_k + i for entry j = off_k + i of the concatenated node lists;
+// Buffers: neighbour k owns the contiguous block starting at base_k = 3*off_k +
+// kHaloSlack*k: ncomp*cnt_k node values, component-major, then (optionally) nextra
+// piggy-backed scalars - so every neighbour is ONE send and ONE recv.
+// pos[j] = base_k + i for entry j = off_k + i of the concatenated node lists;
 // cnt[j] = cnt_k.
 __global__ void __launch_bounds__(256)
 halo_pack_k(const int total, const int ncomp, const int N, const int *__restrict__ nodes,
@@ -164,6 +173,33 @@ halo_pack_k(const int total, const int ncomp, const int N, const int *__restrict
    if (i >= total * ncomp) { return; }
    const int c = i / total, j = i - c * total;
    buf[(size_t)pos[j] + (size_t)c * cnt[j]] = v[(size_t)c * N + nodes[j]];
+}
+__global__ void halo_pack_extra_k(const int n_nbr, const int nextra, const int ncomp, const int *__restrict__ base,
+                                  const int *__restrict__ ncnt, const double *__restrict__ extra,
+                                  double *__restrict__ buf)
+{
+   const int i = threadIdx.x;
+   if (i >= n_nbr * nextra) { return; }
+   const int k = i / nextra, e = i - k * nextra;
+   buf[(size_t)base[k] + (size_t)ncomp * ncnt[k] + e] = extra[e];
+}
+// sum of the piggy-backed scalars over all ranks in ascending rank order (own value at
+// its rank's position): bit-identical on every rank
+__global__ void halo_reduce_extra_k(const int nranks, const int nextra, const int ncomp,
+                                    const int *__restrict__ rank_src, const int *__restrict__ base,
+                                    const int *__restrict__ ncnt, const double *__restrict__ buf,
+                                    double *__restrict__ extra)
+{
+   const int e = threadIdx.x;
+   if (e >= nextra) { return; }
+   double s = 0.0;
+   for (int r = 0; r < nranks; r++)
+   {
+      const int k = rank_src[r];
+      const double val = (k < 0) ? extra[e] : buf[(size_t)base[k] + (size_t)ncomp * ncnt[k] + e];
+      s = (r == 0) ? val : s + val;
+   }
+   extra[e] = s;
 }
 // Canonical sum of a shared node: contributions are added in ascending rank
 // order (own value at its rank's position), so every rank holding the node
@@ -189,15 +225,38 @@ halo_combine_k(const int n_shared, const int ncomp, const int N, const int *__re
    v[(size_t)c * N + node] = s;
 }
 
-int halo_sum(lgh_ctx *c, double *v, int ncomp)
+bool halo_can_piggyback(const lgh_ctx *c)
+{
+   static const bool on = !(getenv("LGH_HALO_PIGGYBACK") && getenv("LGH_HALO_PIGGYBACK")[0] == '0');
+   return on && c->comm && c->comm->allpairs;
+}
+
+// extra != nullptr (device, nextra <= 3 doubles, requires halo_can_piggyback): replaced
+// by its sum over all ranks, carried by the same messages
+int halo_sum(lgh_ctx *c, double *v, int ncomp, double *extra, int nextra)
 {
    Comm *cm = c->comm;
    if (!cm || cm->n_nbr == 0) { return LGH_OK; }
    if (ncomp > 3) { set_error("halo_sum: ncomp > 3"); return LGH_ERR_ARG; }
+   if (extra && (!cm->allpairs || nextra < 1 || nextra > 3)) { set_error("halo_sum: cannot piggy-back"); return LGH_ERR_ARG; }
+   const int nx = extra ? nextra : 0;
    const int tot = cm->total;
    hipLaunchKernelGGL(halo_pack_k, dim3(ceil_div((long)tot * ncomp, 256)), dim3(256), 0, c->stream, tot,
                       ncomp, c->N, cm->nodes, cm->pos, cm->cnt, v, cm->sendbuf);
    LGH_HIP_CHECK(hipGetLastError());
+   if (nx)
+   {
+      hipLaunchKernelGGL(halo_pack_extra_k, dim3(1), dim3(128), 0, c->stream, cm->n_nbr, nx, ncomp, cm->d_base,
+                         cm->d_cnt, extra, cm->sendbuf);
+      LGH_HIP_CHECK(hipGetLastError());
+   }
+   auto reduce_extra = [&]() {
+      if (nx)
+      {
+         hipLaunchKernelGGL(halo_reduce_extra_k, dim3(1), dim3(64), 0, c->stream, c->nranks, nx, ncomp, cm->rank_src,
+                            cm->d_base, cm->d_cnt, cm->recvbuf, extra);
+      }
+   };
    if (cm->local)
    {
       LocalGroup *g = cm->local.get();
@@ -213,22 +272,23 @@ int halo_sum(lgh_ctx *c, double *v, int ncomp)
             set_error("local communicator: neighbour lists of ranks %d and %d do not match", c->rank, cm->nbr_rank[k]);
             return LGH_ERR_COMM;
          }
-         LGH_HIP_CHECK(hipMemcpyAsync(cm->recvbuf + 3 * (size_t)cm->nbr_off[k], pc->sendbuf + 3 * (size_t)pc->nbr_off[kk],
-                                      (size_t)ncomp * cm->nbr_count[k] * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+         LGH_HIP_CHECK(hipMemcpyAsync(cm->recvbuf + cm->nbr_base[k], pc->sendbuf + pc->nbr_base[kk],
+                                      ((size_t)ncomp * cm->nbr_count[k] + nx) * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
       }
       LGH_HIP_CHECK(hipStreamSynchronize(c->stream));
       if (!g->barrier()) { set_error("local communicator: barrier timed out (halo)"); return LGH_ERR_COMM; } // peers may repack
       hipLaunchKernelGGL(halo_combine_k, dim3(ceil_div((long)cm->n_shared * ncomp, 256)), dim3(256), 0,
                          c->stream, cm->n_shared, ncomp, c->N, cm->sh_node, cm->sh_off, cm->sh_src, cm->pos,
                          cm->cnt, cm->recvbuf, v);
+      reduce_extra();
       LGH_HIP_CHECK(hipGetLastError());
       return LGH_OK;
    }
    LGH_NCCL_CHECK(g_nccl.GroupStart());
    for (int k = 0; k < cm->n_nbr; k++)
    {
-      const size_t o = 3 * (size_t)cm->nbr_off[k];
-      const size_t n = (size_t)ncomp * cm->nbr_count[k];
+      const size_t o = (size_t)cm->nbr_base[k];
+      const size_t n = (size_t)ncomp * cm->nbr_count[k] + nx;
       LGH_NCCL_CHECK(g_nccl.Send(cm->sendbuf + o, n, ncclFloat64, cm->nbr_rank[k], cm->comm, c->stream));
       LGH_NCCL_CHECK(g_nccl.Recv(cm->recvbuf + o, n, ncclFloat64, cm->nbr_rank[k], cm->comm, c->stream));
    }
@@ -236,6 +296,7 @@ int halo_sum(lgh_ctx *c, double *v, int ncomp)
    hipLaunchKernelGGL(halo_combine_k, dim3(ceil_div((long)cm->n_shared * ncomp, 256)), dim3(256), 0,
                       c->stream, cm->n_shared, ncomp, c->N, cm->sh_node, cm->sh_off, cm->sh_src, cm->pos,
                       cm->cnt, cm->recvbuf, v);
+   reduce_extra();
    LGH_HIP_CHECK(hipGetLastError());
    return LGH_OK;
 }
@@ -308,7 +369,8 @@ void lgh_comm_free(lgh_ctx *c)
       }
    }
    if (cm->comm && g_nccl.CommDestroy) { g_nccl.CommDestroy(cm->comm); }
-   void *ptrs[] = {cm->nodes, cm->sendbuf, cm->recvbuf, cm->sh_node, cm->sh_off, cm->sh_src, cm->pos, cm->cnt, cm->hmask};
+   void *ptrs[] = {cm->nodes, cm->sendbuf, cm->recvbuf, cm->sh_node, cm->sh_off, cm->sh_src, cm->pos, cm->cnt, cm->hmask,
+                   cm->d_base, cm->d_cnt, cm->rank_src};
    for (void *p : ptrs) { if (p) { (void)hipFree(p); } }
    delete cm;
    c->comm = nullptr;
@@ -380,11 +442,13 @@ int lgh_comm_set_neighbors(lgh_ctx *c, int n_nbr, const int *nbr_rank, const int
    cm->nbr_rank.assign(nbr_rank, nbr_rank + n_nbr);
    cm->nbr_count.assign(nbr_count, nbr_count + n_nbr);
    cm->nbr_off.resize(n_nbr);
+   cm->nbr_base.resize(n_nbr);
    std::vector<int> all;
    int tot = 0;
    for (int k = 0; k < n_nbr; k++)
    {
       cm->nbr_off[k] = tot;
+      cm->nbr_base[k] = 3 * tot + kHaloSlack * k;
       for (int i = 0; i < nbr_count[k]; i++)
       {
          const int n = nbr_nodes[k][i];
@@ -442,7 +506,7 @@ int lgh_comm_set_neighbors(lgh_ctx *c, int n_nbr, const int *nbr_rank, const int
       for (int k = 0; k < n_nbr; k++)
          for (int i = 0; i < nbr_count[k]; i++)
          {
-            pos[cm->nbr_off[k] + i] = 3 * cm->nbr_off[k] + i;
+            pos[cm->nbr_off[k] + i] = cm->nbr_base[k] + i;
             cnt[cm->nbr_off[k] + i] = nbr_count[k];
          }
       LGH_HIP_CHECK(hipMalloc((void **)&cm->pos, pos.size() * sizeof(int)));
@@ -452,8 +516,42 @@ int lgh_comm_set_neighbors(lgh_ctx *c, int n_nbr, const int *nbr_rank, const int
    }
    LGH_HIP_CHECK(hipMalloc((void **)&cm->nodes, std::max<size_t>(tot, 1) * sizeof(int)));
    if (tot) { LGH_HIP_CHECK(hipMemcpy(cm->nodes, all.data(), (size_t)tot * sizeof(int), hipMemcpyHostToDevice)); }
-   LGH_HIP_CHECK(hipMalloc((void **)&cm->sendbuf, std::max<size_t>(tot, 1) * 3 * sizeof(double)));
-   LGH_HIP_CHECK(hipMalloc((void **)&cm->recvbuf, std::max<size_t>(tot, 1) * 3 * sizeof(double)));
+   cm->bufsize = 3 * std::max(tot, 1) + kHaloSlack * n_nbr;
+   LGH_HIP_CHECK(hipMalloc((void **)&cm->sendbuf, (size_t)cm->bufsize * sizeof(double)));
+   LGH_HIP_CHECK(hipMalloc((void **)&cm->recvbuf, (size_t)cm->bufsize * sizeof(double)));
+   LGH_HIP_CHECK(hipMemset(cm->sendbuf, 0, (size_t)cm->bufsize * sizeof(double)));
+   LGH_HIP_CHECK(hipMemset(cm->recvbuf, 0, (size_t)cm->bufsize * sizeof(double)));
+   {
+      // per-neighbour tables and the rank -> neighbour map of the piggy-backed scalars
+      void *old[] = {cm->d_base, cm->d_cnt, cm->rank_src};
+      for (void *p : old) { if (p) { (void)hipFree(p); } }
+      std::vector<int> rs((size_t)std::max(c->nranks, 1), -2);
+      rs[c->rank] = -1;
+      for (int k = 0; k < n_nbr; k++)
+      {
+         if (nbr_rank[k] >= 0 && nbr_rank[k] < c->nranks) { rs[nbr_rank[k]] = k; }
+      }
+      cm->allpairs = (n_nbr > 0 && n_nbr == c->nranks - 1);
+      for (int r : rs) { if (r == -2) { cm->allpairs = false; } }
+      // the message sizes depend on it: every rank must come to the same decision
+      // (in a 3x1x1 partition only the middle rank sees all others)
+      if (c->multi != 0 && (cm->comm || cm->local))
+      {
+         double flag = cm->allpairs ? 1.0 : 0.0;
+         const int rc = lgh_allreduce(c, &flag, 1);
+         if (rc) { return rc; }
+         cm->allpairs = (flag > 0.5);
+      }
+      LGH_HIP_CHECK(hipMalloc((void **)&cm->d_base, std::max<size_t>(n_nbr, 1) * sizeof(int)));
+      LGH_HIP_CHECK(hipMalloc((void **)&cm->d_cnt, std::max<size_t>(n_nbr, 1) * sizeof(int)));
+      LGH_HIP_CHECK(hipMalloc((void **)&cm->rank_src, rs.size() * sizeof(int)));
+      if (n_nbr)
+      {
+         LGH_HIP_CHECK(hipMemcpy(cm->d_base, cm->nbr_base.data(), n_nbr * sizeof(int), hipMemcpyHostToDevice));
+         LGH_HIP_CHECK(hipMemcpy(cm->d_cnt, cm->nbr_count.data(), n_nbr * sizeof(int), hipMemcpyHostToDevice));
+      }
+      LGH_HIP_CHECK(hipMemcpy(cm->rank_src, rs.data(), rs.size() * sizeof(int), hipMemcpyHostToDevice));
+   }
    return LGH_OK;
 }
 
@@ -472,7 +570,7 @@ int lgh_test_halo_pack(lgh_ctx *c, const double *v, int ncomp, double *out)
    hipLaunchKernelGGL(halo_pack_k, dim3(ceil_div((long)cm->total * ncomp, 256)), dim3(256), 0, c->stream,
                       cm->total, ncomp, c->N, cm->nodes, cm->pos, cm->cnt, v, cm->sendbuf);
    LGH_HIP_CHECK(hipGetLastError());
-   LGH_HIP_CHECK(hipMemcpyAsync(out, cm->sendbuf, 3 * (size_t)cm->total * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+   LGH_HIP_CHECK(hipMemcpyAsync(out, cm->sendbuf, (size_t)cm->bufsize * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
    return LGH_OK;
 }
 int lgh_test_halo_combine(lgh_ctx *c, const double *in, double *v, int ncomp)
@@ -480,7 +578,7 @@ int lgh_test_halo_combine(lgh_ctx *c, const double *in, double *v, int ncomp)
    LGH_CHECK_ARG(c && v && in && c->comm && ncomp >= 1 && ncomp <= 3);
    Comm *cm = c->comm;
    if (cm->total == 0) { return LGH_OK; }
-   LGH_HIP_CHECK(hipMemcpyAsync(cm->recvbuf, in, 3 * (size_t)cm->total * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+   LGH_HIP_CHECK(hipMemcpyAsync(cm->recvbuf, in, (size_t)cm->bufsize * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
    hipLaunchKernelGGL(halo_combine_k, dim3(ceil_div((long)cm->n_shared * ncomp, 256)), dim3(256), 0, c->stream,
                       cm->n_shared, ncomp, c->N, cm->sh_node, cm->sh_off, cm->sh_src, cm->pos, cm->cnt,
                       cm->recvbuf, v);
@@ -491,7 +589,7 @@ int lgh_test_halo_combine(lgh_ctx *c, const double *in, double *v, int ncomp)
 int lgh_halo_sum(lgh_ctx *c, double *v_h1, int ncomp)
 {
    LGH_CHECK_ARG(c && v_h1 && ncomp >= 1 && ncomp <= 3);
-   return halo_sum(c, v_h1, ncomp);
+   return halo_sum(c, v_h1, ncomp, nullptr, 0);
 }
 
 int lgh_allreduce(lgh_ctx *c, double *value, int op)

@@ -337,7 +337,8 @@ int vec_axpby(lgh_ctx *c, double *z, double a, const double *x, double b, const 
 int vec_neg_inplace(lgh_ctx *c, double *y, long n);
 int vec_zero_list(lgh_ctx *c, double *y, const int *list, int n);
 int vec_dot(lgh_ctx *c, const double *x, const double *y, const double *w, long n, double *dev_out);
-int halo_sum(lgh_ctx *c, double *v, int ncomp);
+int halo_sum(lgh_ctx *c, double *v, int ncomp, double *extra = nullptr, int nextra = 0);
+bool halo_can_piggyback(const lgh_ctx *c);
 int allreduce_dev(lgh_ctx *c, double *dev, int count, int op);
 
 // bracket one launch of kernel `id` with an event pair when sampling is on

@@ -1106,10 +1106,20 @@ int vcg_solve(lgh_ctx *c, const double *B, double *X, double rel_tol, int max_it
             LGH_HIP_CHECK(hipGetLastError());
             if (multi)
             {
-               rc = halo_sum(c, a.yL, kVC);
-               if (rc) { return rc; }
-               rc = allreduce_dev(c, ds->den, kVC, 0);
-               if (rc) { return rc; }
+               // (d, A d): summed over the ranks by the halo messages themselves when every
+               // rank is a neighbour of every other, by an all-reduce otherwise
+               if (halo_can_piggyback(c))
+               {
+                  rc = halo_sum(c, a.yL, kVC, ds->den, kVC);
+                  if (rc) { return rc; }
+               }
+               else
+               {
+                  rc = halo_sum(c, a.yL, kVC);
+                  if (rc) { return rc; }
+                  rc = allreduce_dev(c, ds->den, kVC, 0);
+                  if (rc) { return rc; }
+               }
                hipLaunchKernelGGL(vcg_den_finish_k, dim3(1), dim3(1), 0, c->stream, ds);
             }
             if (mixed) { hipLaunchKernelGGL((vcg_update_k<true, 8>), dim3(nb), dim3(256), 0, c->stream, a); }
