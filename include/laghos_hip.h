@@ -152,6 +152,12 @@ int lgh_vec_axpby(lgh_ctx *ctx, double *z, double a, const double *x, double b,
 int lgh_vec_dot(lgh_ctx *ctx, const double *x, const double *y, long n, double *result); /* sync */
 
 /* ---- energies (laghos_solver.cpp:640-697); synchronous, all-reduced */
+/* 2D Taylor-Green energy source (SolveEnergy's source_type == 1 branch,
+ * laghos_solver.cpp:448-467 with TaylorCoefficient laghos_solver.hpp:208-218):
+ * e_source (L2 size, device) = DomainLFIntegrator(TaylorCoefficient) assembled on the
+ * mesh positions in S; pass it to lgh_solve_energy(_begin). */
+int lgh_tg_source_2d(lgh_ctx *ctx, const double *S, double *e_source);
+
 int lgh_internal_energy(lgh_ctx *ctx, const double *e_l2, double *result);
 int lgh_kinetic_energy(lgh_ctx *ctx, const double *v_h1, double *result);
 

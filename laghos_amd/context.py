@@ -187,6 +187,9 @@ class Context:
                                         rel_tol, max_iter, ctypes.byref(it)))
         return it.value
 
+    def tg_source_2d(self, S, out):
+        check(self.lib.lgh_tg_source_2d(self.h, _ptr(S), _ptr(out)))
+
     def solve_energy_begin(self, S, v, dS, e_rhs, rel_tol, max_iter, e_source=None):
         check(self.lib.lgh_solve_energy_begin(self.h, _ptr(S), _ptr(v), _ptr(dS), _ptr(e_rhs),
                                               _ptr(e_source) if e_source is not None else None,

@@ -596,6 +596,12 @@ int lgh_vec_dot(lgh_ctx *c, const double *x, const double *y, long n, double *re
    return LGH_OK;
 }
 
+int lgh_tg_source_2d(lgh_ctx *c, const double *S, double *e_source)
+{
+   LGH_CHECK_ARG(c && S && e_source);
+   return tg_source_2d(c, S, e_source);
+}
+
 int lgh_internal_energy(lgh_ctx *c, const double *e_l2, double *result)
 {
    LGH_CHECK_ARG(c && e_l2 && result);

@@ -330,6 +330,7 @@ int qupdate(lgh_ctx *c, const double *S);
 int setup_rho0detj0(lgh_ctx *c, const double *x0, const double *rho0_l2, const double *rho0_q,
                     double *volume);
 int interp_energy(lgh_ctx *c, int which, const double *vec, double *result);
+int tg_source_2d(lgh_ctx *c, const double *S, double *out);
 int test_eig(lgh_ctx *c, int dim, int n, const double *A, double *lambda, double *vec);
 int test_singular(lgh_ctx *c, int dim, int n, const double *A, double *sv);
 int vec_set(lgh_ctx *c, double *y, double a, long n);

@@ -591,6 +591,70 @@ int interp_energy(lgh_ctx *c, int which, const double *vec, double *result)
    return LGH_OK;
 }
 
+// ---- 2D Taylor-Green energy source (laghos_solver.cpp:448-467, TaylorCoefficient
+// laghos_solver.hpp:208-218): e_src_l = sum_q w_q detJ(x_q) f(x_q) phi_l(q) on the CURRENT
+// mesh, f = 3/8 pi (cos 3 pi x cos pi y - cos pi x cos 3 pi y).  One workgroup per element,
+// one thread per quadrature point; a set-up-grade kernel (2D problem 0 only).
+__global__ void __launch_bounds__(128)
+tg_source_2d_k(const int NE, const int N, const int D, const int Q, const int L, const int *__restrict__ map,
+               const double *__restrict__ B, const double *__restrict__ G, const double *__restrict__ Bl,
+               const double *__restrict__ W, const double *__restrict__ x, double *__restrict__ out)
+{
+   __shared__ double sx[2 * 36], ss[100];
+   const int e = blockIdx.x, t = threadIdx.x;
+   const int ND = D * D, NQ = Q * Q, NL = L * L;
+   for (int i = t; i < 2 * ND; i += blockDim.x)
+   {
+      const int c = i / ND, d = i - c * ND;
+      sx[i] = x[(size_t)c * N + map[(size_t)e * ND + d]];
+   }
+   __syncthreads();
+   if (t < NQ)
+   {
+      const int qx = t % Q, qy = t / Q;
+      double v[2] = {0.0, 0.0}, gx[2] = {0.0, 0.0}, gy[2] = {0.0, 0.0};
+      for (int dy = 0; dy < D; dy++)
+      {
+         for (int dx = 0; dx < D; dx++)
+         {
+            const double bb = B[qx + Q * dx] * B[qy + Q * dy];
+            const double gb = G[qx + Q * dx] * B[qy + Q * dy];
+            const double bg = B[qx + Q * dx] * G[qy + Q * dy];
+            for (int c = 0; c < 2; c++)
+            {
+               const double u = sx[c * ND + dx + D * dy];
+               v[c] += bb * u;
+               gx[c] += gb * u;
+               gy[c] += bg * u;
+            }
+         }
+      }
+      const double det = gx[0] * gy[1] - gx[1] * gy[0];
+      const double f = 3.0 / 8.0 * M_PI * (cos(3.0 * M_PI * v[0]) * cos(M_PI * v[1]) - cos(M_PI * v[0]) * cos(3.0 * M_PI * v[1]));
+      ss[t] = W[t] * det * f;
+   }
+   __syncthreads();
+   if (t < NL)
+   {
+      const int lx = t % L, ly = t / L;
+      double s = 0.0;
+      for (int qy = 0; qy < Q; qy++)
+      {
+         for (int qx = 0; qx < Q; qx++) { s += ss[qx + Q * qy] * Bl[qx + Q * lx] * Bl[qy + Q * ly]; }
+      }
+      out[t + (size_t)NL * e] = s;
+   }
+}
+int tg_source_2d(lgh_ctx *c, const double *S, double *out)
+{
+   if (c->dim != 2) { set_error("the Taylor-Green energy source is the 2D one (laghos_solver.cpp:448)"); return LGH_ERR_ARG; }
+   if (c->D1D > 6 || c->Q1D > 10 || c->NQ > 128) { return LGH_ERR_UNSUPPORTED; }
+   hipLaunchKernelGGL(tg_source_2d_k, dim3(c->NE), dim3(128), 0, c->stream, c->NE, c->N, c->D1D, c->Q1D, c->L1D,
+                      c->h1map, c->B, c->G, c->Bl, c->W, S, out);
+   LGH_HIP_CHECK(hipGetLastError());
+   return LGH_OK;
+}
+
 // ---- device probes for the small-matrix kernels (tests) ----------------------
 template <int DIM>
 __global__ void test_eig_k(int n, const double *A, double *lambda, double *vec)

@@ -111,6 +111,8 @@ LagrangianHydroOperator::LagrangianHydroOperator(const Discretization &d, const 
    LGH_VERIFY(lgh_vec_set(ctx, one.Write(), 1.0, L2Vsize)); // :170-171
    rhs.SetSize(H1Vsize);
    e_rhs.SetSize(L2Vsize);
+   source_type = (d.problem == 0 && dim == 2) ? 1 : 0; // laghos.cpp:636-647
+   if (source_type == 1) { e_source.SetSize(L2Vsize); }
    B.SetSize(d.N);
    LGH_VERIFY(lgh_sync(ctx));
 }
@@ -126,8 +128,9 @@ void LagrangianHydroOperator::Mult(const Vector &S, Vector &dS_dt) const
    // from S, not from SolveVelocity's result, so the library may overlap the two: the
    // energy solve is enqueued first (second stream) and completed after the velocity solve.
    UpdateQuadratureData(S); // :332 / :445
-   LGH_VERIFY(lgh_solve_energy_begin(ctx, S.Read(), S.Read() + H1Vsize, dS_dt.Write(), e_rhs.Write(), nullptr,
-                                     cg_rel_tol, cg_max_iter));
+   if (source_type == 1) { LGH_VERIFY(lgh_tg_source_2d(ctx, S.Read(), e_source.Write())); } // :448-467
+   LGH_VERIFY(lgh_solve_energy_begin(ctx, S.Read(), S.Read() + H1Vsize, dS_dt.Write(), e_rhs.Write(),
+                                     source_type == 1 ? e_source.Read() : nullptr, cg_rel_tol, cg_max_iter));
    SolveVelocity(S, dS_dt);
    int it = 0;
    LGH_VERIFY(lgh_solve_energy_end(ctx, &it));
@@ -148,7 +151,9 @@ void LagrangianHydroOperator::SolveEnergy(const Vector &S, const Vector &v, Vect
    UpdateQuadratureData(S); // :445
    int it = 0;
    // ForcePA->MultTranspose(v, e_rhs); CG_EMass.Mult(e_rhs, de) (:473-486)
-   LGH_VERIFY(lgh_solve_energy(ctx, S.Read(), v.Read(), dS_dt.Write(), e_rhs.Write(), nullptr,
+   if (source_type == 1) { LGH_VERIFY(lgh_tg_source_2d(ctx, S.Read(), e_source.Write())); } // :448-467
+   LGH_VERIFY(lgh_solve_energy(ctx, S.Read(), v.Read(), dS_dt.Write(), e_rhs.Write(),
+                               source_type == 1 ? e_source.Read() : nullptr,
                                cg_rel_tol, cg_max_iter, &it));
 }
 

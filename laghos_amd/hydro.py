@@ -45,6 +45,8 @@ class HydroOperator:
         self.rhs = ctx.zeros(prob.H1V)
         self.e_rhs = ctx.zeros(prob.L2V)
         self.work = ctx.zeros(prob.N)
+        # source_type 1 = 2D Taylor-Green (laghos.cpp:636-647, laghos_solver.cpp:448)
+        self.e_source = ctx.zeros(prob.L2V) if (prob.problem == 0 and prob.dim == 2) else None
         self.qdata_is_current = False
         torch.cuda.synchronize()
 
@@ -75,7 +77,10 @@ class HydroOperator:
         ctx.vec_copy(dS[:p.H1V], S[p.H1V:2 * p.H1V])             # dx_dt = v
         self.update_quadrature_data(S)
         # SolveEnergy takes v from S, not from SolveVelocity: the library overlaps the two
-        ctx.solve_energy_begin(S, S[p.H1V:2 * p.H1V], dS, self.e_rhs, self.cg_tol, self.cg_max_iter)
+        if self.e_source is not None:
+            ctx.tg_source_2d(S, self.e_source)
+        ctx.solve_energy_begin(S, S[p.H1V:2 * p.H1V], dS, self.e_rhs, self.cg_tol, self.cg_max_iter,
+                               e_source=self.e_source)
         ctx.solve_velocity(S, dS, self.one, self.rhs, self.work, self.cg_tol, self.cg_max_iter)
         ctx.solve_energy_end()
         self.qdata_is_current = False
@@ -122,7 +127,9 @@ def rk2avg_step(hydro, S, t, dt, work):
         hydro.update_quadrature_data(S)
         ctx.solve_velocity(S, dS, hydro.one, hydro.rhs, hydro.work, hydro.cg_tol, hydro.cg_max_iter)
         ctx.vec_axpby(V, 1.0, v0, 0.5 * dt, dv)                   # V = v0 + dt/2 dv_dt
-        ctx.solve_energy(S, V, dS, hydro.e_rhs, hydro.cg_tol, hydro.cg_max_iter)
+        if hydro.e_source is not None:
+            ctx.tg_source_2d(S, hydro.e_source)
+        ctx.solve_energy(S, V, dS, hydro.e_rhs, hydro.cg_tol, hydro.cg_max_iter, e_source=hydro.e_source)
         ctx.vec_copy(dS[:h1v], V)                                  # dx_dt = V
     ctx.vec_axpby(S, 1.0, S0, dt, dS)                              # S = S0 + dt dS_dt
     hydro.reset_quadrature_data()

@@ -252,3 +252,21 @@ def test_smallmat_device():
     s = np.linalg.svd(J, compute_uv=False)
     assert np.max(np.abs(sv.cpu().numpy() - s[:, 2]) / s[:, 0]) < 1e-10
     g.close()
+
+
+def test_tg_source_2d():
+    """2D Taylor-Green energy source (laghos_solver.cpp:448-467) on a distorted mesh vs the oracle"""
+    from oracle.fem import Problem
+    from oracle.driver import _dp
+    prob = Problem(mesh="square01_quad", rs=2, order_v=2, order_e=1, problem=0)
+    g, o = make_gpu(prob), make_oracle(prob)
+    S = deformed_state(prob, seed=5)
+    want = np.empty(prob.L2V)
+    o.L.lgo_qupdate(o.h, _dp(S))
+    o.L.lgo_tg_source_2d(o.h, _dp(S), _dp(want))
+    got = g.ctx.empty(prob.L2V)
+    g.ctx.tg_source_2d(g.ctx.to_dev(S), got)
+    g.ctx.sync()
+    assert rel_err(got.cpu().numpy(), want) < TOL
+    g.close()
+    o.close()

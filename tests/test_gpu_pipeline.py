@@ -9,7 +9,7 @@ from helpers import make_gpu, rel_err, seeded
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name", ["chk-3D-Sedov", "chk-2D-Sedov", "chk-3D-TG", "chk-3D-p3"])
+@pytest.mark.parametrize("name", ["chk-3D-Sedov", "chk-2D-Sedov", "chk-3D-TG", "chk-2D-TG", "chk-3D-p3", "chk-2D-p3"])
 def test_checks_table_on_gpu(golden, name):
     """`--checks` golden values (laghos.cpp:1441-1463) through the HIP path.
     -cgt 1e-14: the CG runs to round-off, so the GPU/CPU difference is the
@@ -54,12 +54,12 @@ def test_readme_run8_gresho_rk2avg(golden):
     assert abs(r["e_norm"] - g["e_norm"]) / g["e_norm"] < 5e-11, (r["e_norm"], g["e_norm"])
 
 
-@pytest.mark.parametrize("name", ["README-2", "README-3", "README-4", "README-6", "README-7"])
+@pytest.mark.parametrize("name", ["README-1", "README-2", "README-3", "README-4", "README-6", "README-7"])
 def test_readme_runs_on_gpu(golden, name):
     """The reference's published verification runs (README.md:214-235; run 3 is BASELINE
     configs[0]) from t = 0 to t_final through the HIP path, compared the way `make tests`
-    compares them: final step count, printed dt, |e|.  (Run 1 needs the 2D Taylor-Green
-    source term, which stays on the oracle side; run 8 has its own test below.)"""
+    compares them: final step count, printed dt, |e|.  (Run 8 has its own test below; runs 5
+    and 9 are 1D / problem 7 and outside the harness.)"""
     from laghos_amd.hydro import run
     from oracle.fem import Problem
     g = next(c for c in golden["readme"] if c["name"] == name)
@@ -169,7 +169,7 @@ def test_full_size_sedov_steps(full_size):
 
 # ---- the C++ host layer (laghos_amd/host): reference API mirror + driver --------------------
 @pytest.mark.parametrize("mesh,prob", [("data/cube01_hex.mesh", 1), ("data/square01_quad.mesh", 1),
-                                       ("data/cube01_hex.mesh", 0)])
+                                       ("data/cube01_hex.mesh", 0), ("data/square01_quad.mesh", 0)])
 def test_cpp_driver_checks(mesh, prob):
     """`laghos -chk` through the C++ driver: both probe points of the reference's
     --checks table must be hit and match (laghos.cpp:903-926)."""
