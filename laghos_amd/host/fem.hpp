@@ -88,7 +88,8 @@ struct Discretization
    // S = [x | v | e]; rho0 grid function (L2 dofs), gamma per element, rho0 at qpts
    void InitialState(std::vector<double> &S, std::vector<double> &rho0_l2,
                      std::vector<double> &gamma, std::vector<double> &rho0_q) const;
-   bool UseViscosity() const { return problem != 0 && problem != 4; } // laghos.cpp:636-647
+   bool impose_visc = false; // -iv (laghos.cpp:648)
+   bool UseViscosity() const { return impose_visc || (problem != 0 && problem != 4); } // laghos.cpp:636-648
    int SourceType() const { return (problem == 0 && dim == 2) ? 1 : 0; }
 
    // problem definitions (laghos.cpp:1094-1275)

@@ -38,7 +38,7 @@ struct Options
    int cg_max_iter = 300, max_tsteps = -1;
    bool p_assembly = true;
    int vis_steps = 5;
-   bool check = false, fom = false;
+   bool check = false, fom = false, impose_visc = false;
    int dev = 0;
    // multi-rank (set by the launcher, not the reference CLI)
    int nranks = 1, rank = 0;
@@ -77,6 +77,8 @@ bool ParseArgs(int argc, const char *const *argv, Options &o, std::string &err)
       if (a == "-fa" || a == "--full-assembly") { o.p_assembly = false; continue; }
       if (a == "-chk" || a == "--checks") { o.check = true; continue; }
       if (a == "-no-chk" || a == "--no-checks") { o.check = false; continue; }
+      if (a == "-iv" || a == "--impose-viscosity") { o.impose_visc = true; continue; }
+      if (a == "-niv" || a == "--no-impose-viscosity") { o.impose_visc = false; continue; }
       if (a == "-f" || a == "--fom") { o.fom = true; continue; }
       if (a == "-no-fom" || a == "--no-fom") { o.fom = false; continue; }
       if (a == "-q" || a == "--quiet") { o.quiet = true; continue; }
@@ -171,6 +173,7 @@ laghos_sim *laghos_sim_create(int argc, const char *const *argv, int nranks, int
       for (int l = 0; l < o.rs_levels + o.rp_levels; l++) { mesh.UniformRefinement(); } // laghos.cpp:391, :483
       o.dim = mesh.dim;
       s->disc.reset(new Discretization(mesh, o.order_v, o.order_e, o.problem, nranks, rank, o.order_q, o.blast_energy));
+      s->disc->impose_visc = o.impose_visc;
    }
    catch (const std::exception &e)
    {
