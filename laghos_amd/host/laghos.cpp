@@ -194,10 +194,13 @@ laghos_sim *laghos_sim_create(int argc, const char *const *argv, int nranks, int
                                                              o.cg_max_iter, o.dev, nccl_id));
    switch (o.ode_solver_type)
    {
+      case 1: s->ode.reset(new ForwardEulerSolver); break;
+      case 2: s->ode.reset(new RK2Solver(0.5)); break;
+      case 3: s->ode.reset(new RK3SSPSolver); break;
       case 4: s->ode.reset(new RK4Solver); break;
       case 7: s->ode.reset(new RK2AvgSolver); break;
       default:
-         std::fprintf(stderr, "Unknown / unsupported ODE solver type: %d (4 = RK4, 7 = RK2Avg)\n", o.ode_solver_type);
+         std::fprintf(stderr, "Unknown / unsupported ODE solver type: %d (1 = Forward Euler, 2 = RK2, 3 = RK3 SSP, 4 = RK4, 7 = RK2Avg)\n", o.ode_solver_type);
          return nullptr;
    }
    s->S.FromHost(S0);

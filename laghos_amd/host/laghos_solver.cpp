@@ -282,6 +282,59 @@ void LagrangianHydroOperator::PrintTimingData(bool IamRoot, int steps, bool fom)
 } // namespace hydrodynamics
 
 // ---- ODE solvers ------------------------------------------------------------------------------
+void ForwardEulerSolver::Init(hydrodynamics::LagrangianHydroOperator &op)
+{
+   ODESolver::Init(op);
+   k.SetSize(op.Size());
+}
+void ForwardEulerSolver::Step(Vector &S, double &t, double &dt)
+{
+   f->Mult(S, k);
+   f->Add(S, 1.0, S, dt, k); // x += dt f(x)
+   t += dt;
+}
+
+void RK2Solver::Init(hydrodynamics::LagrangianHydroOperator &op)
+{
+   ODESolver::Init(op);
+   k.SetSize(op.Size());
+   x1.SetSize(op.Size());
+}
+void RK2Solver::Step(Vector &S, double &t, double &dt)
+{
+   //  0 |
+   //  a |  a
+   // ---+--------
+   //    | 1-b  b      b = 1/(2a)
+   const double b = 0.5 / a;
+   f->Mult(S, k);
+   f->Add(x1, 1.0, S, (1. - b) * dt, k);
+   f->Add(S, 1.0, S, a * dt, k);
+   f->Mult(S, k);
+   f->Add(S, 1.0, x1, b * dt, k);
+   t += dt;
+}
+
+void RK3SSPSolver::Init(hydrodynamics::LagrangianHydroOperator &op)
+{
+   ODESolver::Init(op);
+   k.SetSize(op.Size());
+   y.SetSize(op.Size());
+}
+void RK3SSPSolver::Step(Vector &S, double &t, double &dt)
+{
+   // x1 = x + dt f(x); x2 = 3/4 x + 1/4 (x1 + dt f(x1)); x3 = 1/3 x + 2/3 (x2 + dt f(x2))
+   f->Mult(S, k);
+   f->Add(y, 1.0, S, dt, k);
+   f->Mult(y, k);
+   f->Add(y, 1.0, y, dt, k);
+   f->Add(y, 3. / 4, S, 1. / 4, y);
+   f->Mult(y, k);
+   f->Add(y, 1.0, y, dt, k);
+   f->Add(S, 1. / 3, S, 2. / 3, y);
+   t += dt;
+}
+
 void RK4Solver::Init(hydrodynamics::LagrangianHydroOperator &op)
 {
    ODESolver::Init(op);

@@ -107,6 +107,37 @@ public:
    virtual int Stages() const = 0;
 };
 
+// upstream ForwardEulerSolver, RK2Solver(0.5) (midpoint) and RK3SSPSolver (laghos.cpp:521-523)
+class ForwardEulerSolver : public ODESolver
+{
+   Vector k;
+
+public:
+   void Init(hydrodynamics::LagrangianHydroOperator &op) override;
+   void Step(Vector &S, double &t, double &dt) override;
+   int Stages() const override { return 1; }
+};
+class RK2Solver : public ODESolver
+{
+   Vector k, x1;
+   double a;
+
+public:
+   explicit RK2Solver(double a_ = 0.5) : a(a_) {}
+   void Init(hydrodynamics::LagrangianHydroOperator &op) override;
+   void Step(Vector &S, double &t, double &dt) override;
+   int Stages() const override { return 2; }
+};
+class RK3SSPSolver : public ODESolver
+{
+   Vector k, y;
+
+public:
+   void Init(hydrodynamics::LagrangianHydroOperator &op) override;
+   void Step(Vector &S, double &t, double &dt) override;
+   int Stages() const override { return 3; }
+};
+
 // classical RK4 (upstream RK4Solver; laghos.cpp:524)
 class RK4Solver : public ODESolver
 {

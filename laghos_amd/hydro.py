@@ -111,6 +111,42 @@ def rk4_step(hydro, S, t, dt, work):
     return t + dt
 
 
+def rk1_step(hydro, S, t, dt, work):
+    """upstream ForwardEulerSolver::Step"""
+    k = work[0]
+    hydro.mult(S, k)
+    hydro.ctx.vec_axpby(S, 1.0, S, dt, k)
+    return t + dt
+
+
+def rk2_step(hydro, S, t, dt, work, a=0.5):
+    """upstream RK2Solver(a)::Step; Laghos uses a = 0.5, the midpoint rule (laghos.cpp:522)"""
+    ctx = hydro.ctx
+    k, x1, _ = work
+    b = 0.5 / a
+    hydro.mult(S, k)
+    ctx.vec_axpby(x1, 1.0, S, (1.0 - b) * dt, k)
+    ctx.vec_axpby(S, 1.0, S, a * dt, k)
+    hydro.mult(S, k)
+    ctx.vec_axpby(S, 1.0, x1, b * dt, k)
+    return t + dt
+
+
+def rk3ssp_step(hydro, S, t, dt, work):
+    """upstream RK3SSPSolver::Step (laghos.cpp:523)"""
+    ctx = hydro.ctx
+    k, y, _ = work
+    hydro.mult(S, k)
+    ctx.vec_axpby(y, 1.0, S, dt, k)
+    hydro.mult(y, k)
+    ctx.vec_axpby(y, 1.0, y, dt, k)
+    ctx.vec_axpby(y, 3.0 / 4, S, 1.0 / 4, y)
+    hydro.mult(y, k)
+    ctx.vec_axpby(y, 1.0, y, dt, k)
+    ctx.vec_axpby(S, 1.0 / 3, S, 2.0 / 3, y)
+    return t + dt
+
+
 def rk2avg_step(hydro, S, t, dt, work):
     """RK2AvgSolver::Step (laghos_solver.cpp:1447-1487): two SolveVelocity /
     SolveEnergy sub-steps, the energy one with the half-step average velocity V."""
@@ -140,9 +176,10 @@ class TimeLoop:
     """laghos.cpp:706-778 as a resumable object (bench.py steps it K times)."""
 
     def __init__(self, hydro, t_final=0.6, max_steps=-1, ode_solver=4):
-        if ode_solver not in (4, 7):
-            raise ValueError("ode_solver: 4 (RK4) or 7 (RK2Avg)")
-        self.stepper = rk2avg_step if ode_solver == 7 else rk4_step
+        steppers = {1: rk1_step, 2: rk2_step, 3: rk3ssp_step, 4: rk4_step, 7: rk2avg_step}
+        if ode_solver not in steppers:
+            raise ValueError("ode_solver: 1 (Euler), 2 (RK2), 3 (RK3 SSP), 4 (RK4) or 7 (RK2Avg)")
+        self.stepper = steppers[ode_solver]
         self.h = hydro
         self.t_final, self.max_steps = t_final, max_steps
         self.S = hydro.S0.clone()

@@ -277,6 +277,40 @@ def rk4_step(hydro, S, t, dt, work):
     return t + dt
 
 
+def rk1_step(hydro, S, t, dt, work):
+    """upstream ForwardEulerSolver::Step"""
+    k = work[0]
+    hydro.mult(S, k)
+    S += dt * k
+    return t + dt
+
+
+def rk2_step(hydro, S, t, dt, work, a=0.5):
+    """upstream RK2Solver(a)::Step (laghos.cpp:522 uses a = 0.5)"""
+    k, x1, _ = work
+    b = 0.5 / a
+    hydro.mult(S, k)
+    np.add(S, ((1.0 - b) * dt) * k, out=x1)
+    S += (a * dt) * k
+    hydro.mult(S, k)
+    np.add(x1, (b * dt) * k, out=S)
+    return t + dt
+
+
+def rk3ssp_step(hydro, S, t, dt, work):
+    """upstream RK3SSPSolver::Step (laghos.cpp:523)"""
+    k, y, _ = work
+    hydro.mult(S, k)
+    np.add(S, dt * k, out=y)
+    hydro.mult(y, k)
+    y += dt * k
+    y[:] = (3.0 / 4) * S + (1.0 / 4) * y
+    hydro.mult(y, k)
+    y += dt * k
+    S[:] = (1.0 / 3) * S + (2.0 / 3) * y
+    return t + dt
+
+
 def rk2avg_step(hydro, S, t, dt, work):
     """RK2AvgSolver::Step (laghos_solver.cpp:1447-1487)."""
     dS, S0, _ = work
@@ -331,7 +365,7 @@ def run(prob: Problem, t_final=0.6, cfl=0.5, cg_tol=1e-8, cg_max_iter=300, max_s
         S_old[:] = S
         t_old = t
         hydro.reset_time_step_estimate()
-        t = (rk2avg_step if ode_solver == 7 else rk4_step)(hydro, S, t, dt, work)
+        t = {1: rk1_step, 2: rk2_step, 3: rk3ssp_step, 4: rk4_step, 7: rk2avg_step}[ode_solver](hydro, S, t, dt, work)
         steps += 1
         dt_est = hydro.get_time_step_estimate(S)
         if dt_est < dt:
