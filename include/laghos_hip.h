@@ -152,6 +152,12 @@ int lgh_vec_axpby(lgh_ctx *ctx, double *z, double a, const double *x, double b,
 int lgh_vec_dot(lgh_ctx *ctx, const double *x, const double *y, long n, double *result); /* sync */
 
 /* ---- energies (laghos_solver.cpp:640-697); synchronous, all-reduced */
+/* Acceleration source of SolveVelocity (source_type == 2, problem 7; laghos_solver.cpp:340-347,
+ * :371-380): accel_h1 = nodal projection of RTCoefficient on the H1 space (dim*N, byNODES, device;
+ * must stay valid), NULL switches it off.  lgh_solve_velocity then adds VMassPA->MultFull(accel_c)
+ * to the right-hand side of every component before EliminateRHS. */
+int lgh_set_velocity_source(lgh_ctx *ctx, const double *accel_h1);
+
 /* 2D Taylor-Green energy source (SolveEnergy's source_type == 1 branch,
  * laghos_solver.cpp:448-467 with TaylorCoefficient laghos_solver.hpp:208-218):
  * e_source (L2 size, device) = DomainLFIntegrator(TaylorCoefficient) assembled on the

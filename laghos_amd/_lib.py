@@ -65,6 +65,7 @@ SYMBOLS = {
     "lgh_solve_energy": (_I, [_P, _P, _P, _P, _P, _P, _D, _I, c_int_p]),
     "lgh_solve_energy_begin": (_I, [_P, _P, _P, _P, _P, _P, _D, _I]),
     "lgh_tg_source_2d": (_I, [_P, _P, _P]),
+    "lgh_set_velocity_source": (_I, [_P, _P]),
     "lgh_solve_energy_end": (_I, [_P, c_int_p]),
     "lgh_vec_set": (_I, [_P, _P, _D, _L]),
     "lgh_vec_copy": (_I, [_P, _P, _P, _L]),

@@ -187,6 +187,9 @@ class Context:
                                         rel_tol, max_iter, ctypes.byref(it)))
         return it.value
 
+    def set_velocity_source(self, accel):
+        check(self.lib.lgh_set_velocity_source(self.h, _ptr(accel) if accel is not None else None))
+
     def tg_source_2d(self, S, out):
         check(self.lib.lgh_tg_source_2d(self.h, _ptr(S), _ptr(out)))
 

@@ -438,6 +438,16 @@ int lgh_solve_velocity(lgh_ctx *c, const double *S, double *dS_dt, const double 
    if (rc) { return rc; }
    rc = vec_neg_inplace(c, rhs_h1, c->H1V); // :358
    if (rc) { return rc; }
+   if (c->accel_src) // source_type == 2: B_c += VMassPA->MultFull(accel_c) (:371-380), before EliminateRHS
+   {
+      for (int cc = 0; cc < dim; cc++)
+      {
+         rc = mass_apply_h1(c, c->accel_src + (size_t)cc * N, work_B, false);
+         if (rc) { return rc; }
+         rc = vec_axpby(c, rhs_h1 + (size_t)cc * N, 1.0, rhs_h1 + (size_t)cc * N, 1.0, work_B, N);
+         if (rc) { return rc; }
+      }
+   }
    // the dim component solves in lockstep (lgh_vcg.hip) when the kernel id has it
    {
       for (int cc = 0; cc < dim; cc++)
@@ -593,6 +603,13 @@ int lgh_vec_dot(lgh_ctx *c, const double *x, const double *y, long n, double *re
    LGH_HIP_CHECK(hipMemcpyAsync(c->host_pinned + 1, c->scal + 1, sizeof(double), hipMemcpyDeviceToHost, c->stream));
    LGH_HIP_CHECK(hipStreamSynchronize(c->stream));
    *result = c->host_pinned[1];
+   return LGH_OK;
+}
+
+int lgh_set_velocity_source(lgh_ctx *c, const double *accel_h1)
+{
+   LGH_CHECK_ARG(c);
+   c->accel_src = accel_h1;
    return LGH_OK;
 }
 

@@ -86,6 +86,7 @@ struct lgh_ctx
    hipStream_t stream2;
    hipEvent_t ev_fork, ev_join;
    void *l2run;          // state of a split L2 solve (lgh_mass.hip)
+   const double *accel_src; // dim*N acceleration source of SolveVelocity (source_type 2) or nullptr
    int e_async;          // 1: lgh_solve_energy_begin enqueued the solve, 2: deferred to _end
    struct { const double *S, *v; double *dS, *e_rhs; const double *src; double tol; int maxit; } e_args;
    bool own_stream;

@@ -169,6 +169,12 @@ CartMesh CartMesh::Named(const std::string &name_in)
       m.brk[0] = {0., 1., 2., 3., 4., 5., 6., 7.};
       m.brk[1] = {0., 1., 2., 3.};
    }
+   else if (name == "rt2D")
+   {
+      m.dim = 2;
+      m.brk[0] = {0.0, 0.5};
+      m.brk[1] = {-1.0, -0.5, 0.0, 0.5, 1.0};
+   }
    else if (name == "square_gresho")
    {
       m.dim = 2;
@@ -179,7 +185,7 @@ CartMesh CartMesh::Named(const std::string &name_in)
    {
       throw std::runtime_error("mesh '" + name_in + "' is not one of the structured meshes this "
                                "harness supports (square01_quad, cube01_hex, box01_hex, rectangle01_quad, "
-                               "square_gresho)");
+                               "square_gresho, rt2D)");
    }
    return m;
 }
@@ -375,6 +381,7 @@ double Discretization::rho0(const double *x) const
          return (dim == 2) ? ((x[0] > 1.0 && x[1] > 1.5) ? 0.125 : 1.0)
                            : ((x[0] > 1.0 && ((x[1] < 1.5 && x[2] < 1.5) || (x[1] > 1.5 && x[2] > 1.5))) ? 0.125 : 1.0);
       case 4: return 1.0;
+      case 7: return x[1] >= 0.0 ? 2.0 : 1.0; // laghos.cpp:1117
       default: throw std::runtime_error("Bad number given for problem id!");
    }
 }
@@ -387,6 +394,7 @@ double Discretization::gamma_func(const double *x) const
       case 2: return 1.4;
       case 3: return (x[0] > 1.0 && x[1] <= 1.5) ? 1.4 : 1.5;
       case 4: return 5.0 / 3.0;
+      case 7: return 5.0 / 3.0;
       default: throw std::runtime_error("Bad number given for problem id!");
    }
 }
@@ -403,6 +411,10 @@ void Discretization::v0(const double *x, double *v) const
          v[1] *= std::cos(M_PI * x[2]);
          v[2] = 0.0;
       }
+   }
+   else if (problem == 7) // laghos.cpp:1198-1203
+   {
+      v[1] = 0.02 * std::exp(-2 * M_PI * x[1] * x[1]) * std::cos(2 * M_PI * x[0]);
    }
    else if (problem == 4) // Gresho vortex, laghos.cpp:1161-1177
    {
@@ -436,6 +448,11 @@ double Discretization::e0(const double *x) const
       }
       case 1: return 0.0;
       case 3: return ((x[0] > 1.0) ? 0.1 : 1.0) / rho0(x) / (gamma_func(x) - 1.0);
+      case 7: // laghos.cpp:1268-1272
+      {
+         const double rho = rho0(x), gamma = gamma_func(x);
+         return (6.0 - rho * x[1]) / (gamma - 1.0) / rho;
+      }
       case 4: // laghos.cpp:1232-1247
       {
          const double rsq = x[0] * x[0] + x[1] * x[1], r = std::sqrt(rsq);

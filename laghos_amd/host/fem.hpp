@@ -90,7 +90,8 @@ struct Discretization
                      std::vector<double> &gamma, std::vector<double> &rho0_q) const;
    bool impose_visc = false; // -iv (laghos.cpp:648)
    bool UseViscosity() const { return impose_visc || (problem != 0 && problem != 4); } // laghos.cpp:636-648
-   int SourceType() const { return (problem == 0 && dim == 2) ? 1 : 0; }
+   int SourceType() const { return problem == 7 ? 2 : ((problem == 0 && dim == 2) ? 1 : 0); } // laghos.cpp:636-647
+   bool UseVorticity() const { return problem == 7; }
 
    // problem definitions (laghos.cpp:1094-1275)
    double rho0(const double *x) const;

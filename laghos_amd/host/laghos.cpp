@@ -2,7 +2,7 @@
 //
 // Mirrors the command line, time loop and output format of the reference driver
 // (/root/reference/laghos.cpp:119-1092) for the subset this repository supports:
-// PA mode (-pa), dim 2/3, problems 0, 1, 3, 4 on the structured meshes of data/,
+// PA mode (-pa), dim 2/3, problems 0, 1, 3, 4, 7 on the structured meshes of data/,
 // -s 1, 2, 3, 4 (Euler, RK2, RK3 SSP, RK4) and 7 (RK2Avg).  Everything else the reference driver does
 // (visualisation, VisIt, -fa, AMR, METIS, Umpire, Caliper) is out of scope
 // (SURVEY §2).  Exposed both as the `laghos` executable and as C entry points

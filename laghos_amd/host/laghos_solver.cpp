@@ -59,7 +59,7 @@ LagrangianHydroOperator::LagrangianHydroOperator(const Discretization &d, const 
    const bool multi = d.part.nranks > 1 || force_multi;
    cfg.owner = multi ? d.owner.data() : nullptr;
    cfg.use_viscosity = d.UseViscosity();
-   cfg.use_vorticity = 0;
+   cfg.use_vorticity = d.UseVorticity() ? 1 : 0;
    cfg.cfl = cfl;
    cfg.order_v = d.tab.order_v;
    cfg.device = device;
@@ -111,8 +111,16 @@ LagrangianHydroOperator::LagrangianHydroOperator(const Discretization &d, const 
    LGH_VERIFY(lgh_vec_set(ctx, one.Write(), 1.0, L2Vsize)); // :170-171
    rhs.SetSize(H1Vsize);
    e_rhs.SetSize(L2Vsize);
-   source_type = (d.problem == 0 && dim == 2) ? 1 : 0; // laghos.cpp:636-647
+   source_type = d.SourceType(); // laghos.cpp:636-647
    if (source_type == 1) { e_source.SetSize(L2Vsize); }
+   if (source_type == 2)
+   {
+      // accel_src_gf.ProjectCoefficient(RTCoefficient) (:340-347): (0, -1) at every node
+      std::vector<double> acc((size_t)H1Vsize, 0.0);
+      for (long i = H1Vsize / dim; i < 2 * (H1Vsize / dim); i++) { acc[i] = -1.0; }
+      accel_src.FromHost(acc);
+      LGH_VERIFY(lgh_set_velocity_source(ctx, accel_src.Read()));
+   }
    B.SetSize(d.N);
    LGH_VERIFY(lgh_sync(ctx));
 }

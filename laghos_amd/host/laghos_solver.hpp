@@ -47,6 +47,7 @@ protected:
    std::unique_ptr<MassPAOperator> VMassPA, EMassPA;
    std::unique_ptr<QUpdate> qupdate;
    mutable Vector one, rhs, e_rhs, B;
+   Vector accel_src;        // source_type == 2 (problem 7 gravity, laghos_solver.cpp:340-347)
    mutable Vector e_source; // source_type == 1 (2D Taylor-Green, laghos_solver.cpp:448-467), else empty
    int source_type = 0;
    mutable TimingData timer;

@@ -24,7 +24,9 @@ class HydroOperator:
         self.ctx = ctx = Context(prob.dim, prob.NE, prob.D1D, prob.Q1D, prob.L1D, prob.N, prob.h1map,
                                  prob.B, prob.G, prob.Bl, prob.W, gamma, prob.ess,
                                  owner=prob.owner if multi else None,
-                                 use_viscosity=prob.use_viscosity(), cfl=cfl, order_v=prob.order_v,
+                                 use_viscosity=prob.use_viscosity(),
+                                 use_vorticity=getattr(prob, "use_vorticity", lambda: False)(),
+                                 cfl=cfl, order_v=prob.order_v,
                                  device=device)
         self.multi = multi
         if multi:
@@ -47,6 +49,10 @@ class HydroOperator:
         self.work = ctx.zeros(prob.N)
         # source_type 1 = 2D Taylor-Green (laghos.cpp:636-647, laghos_solver.cpp:448)
         self.e_source = ctx.zeros(prob.L2V) if (prob.problem == 0 and prob.dim == 2) else None
+        # source_type 2 = gravity of problem 7 (laghos.cpp:645, laghos_solver.cpp:340-347)
+        self.accel = ctx.to_dev(prob.accel_source()) if prob.problem == 7 else None
+        if self.accel is not None:
+            ctx.set_velocity_source(self.accel)
         self.qdata_is_current = False
         torch.cuda.synchronize()
 

@@ -98,7 +98,7 @@ class Hydro:
             prob.dim, prob.NE, prob.D1D, prob.Q1D, prob.L1D, prob.N, _ip(k["h1map"]),
             _dp(k["B"]), _dp(k["G"]), _dp(k["Bl"]), _dp(k["W"]), _dp(k["gamma"]), _ip(k["essc"]),
             _ip(ess[0]), _ip(ess[1]), _ip(ess[2]), _dp(k["owner"]),
-            int(prob.use_viscosity()), 0, ctypes.c_double(cfl), prob.order_v))
+            int(prob.use_viscosity()), int(prob.use_vorticity()), ctypes.c_double(cfl), prob.order_v))
         if comm is not None:
             self._install_comm(comm)
         # Rho0DetJ0Vol + h0 (laghos_solver.cpp:223-262)
@@ -114,6 +114,7 @@ class Hydro:
         L.lgo_set_h0(self.h, ctypes.c_double(h0))
         L.lgo_mass_assemble_diag(self.h)  # OperatorJacobiSmoother (laghos_solver.cpp:266-270)
         self.source_type = prob.source_type()
+        self._accel = np.ascontiguousarray(prob.accel_source()) if self.source_type == 2 else None
         self.qdata_is_current = False
 
     def _install_comm(self, comm):
@@ -188,6 +189,13 @@ class Hydro:
     def mult(self, S, dS):
         # SolveVelocity's UpdateQuadratureData (:332) honours qdata_is_current (:809)
         self.update_quadrature_data(S)
+        if self.source_type == 2:  # gravity: the split calls carry the acceleration source
+            h1v = self.p.H1V
+            dS[:h1v] = S[h1v:2 * h1v]
+            self.solve_velocity(S, dS)
+            self.solve_energy(S, S[h1v:2 * h1v], dS)
+            self.qdata_is_current = False
+            return
         src = None
         if self.source_type == 1:
             src = np.empty(self.p.L2V)
@@ -198,6 +206,10 @@ class Hydro:
 
     def solve_velocity(self, S, dS):
         self.update_quadrature_data(S)
+        if self.source_type == 2:
+            self.L.lgo_solve_velocity_src(self.h, _dp(S), _dp(dS), ctypes.c_double(self.cg_tol), self.cg_max_iter, 1,
+                                          _dp(self._accel))
+            return
         self.L.lgo_solve_velocity(self.h, _dp(S), _dp(dS), ctypes.c_double(self.cg_tol), self.cg_max_iter, 1)
 
     def solve_energy(self, S, V, dS):

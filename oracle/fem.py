@@ -90,6 +90,7 @@ MESHES = {
     "box01_hex": [[0.0, 1.0, 3.0, 5.0, 7.0], [0.0, 1.5, 3.0], [0.0, 1.5, 3.0]],
     "rectangle01_quad": [[float(i) for i in range(8)], [0.0, 1.0, 2.0, 3.0]],
     "square_gresho": [[-0.5, 0.0, 0.5], [-0.5, 0.0, 0.5]],
+    "rt2D": [[0.0, 0.5], [-1.0, -0.5, 0.0, 0.5, 1.0]],
 }
 
 
@@ -304,6 +305,8 @@ class Problem:
         p, dim = self.problem, self.dim
         if p in (0, 1, 4):
             return np.ones(x.shape[:-1])
+        if p == 7:  # Rayleigh-Taylor, laghos.cpp:1117
+            return np.where(x[..., 1] >= 0.0, 2.0, 1.0)
         if p == 2:
             return np.where(x[..., 0] < 0.5, 1.0, 0.1)
         if p == 3:
@@ -316,7 +319,7 @@ class Problem:
 
     def gamma_func(self, x):
         p = self.problem
-        if p in (0, 4):
+        if p in (0, 4, 7):
             return np.full(x.shape[:-1], 5.0 / 3.0)
         if p in (1, 2):
             return np.full(x.shape[:-1], 1.4)
@@ -333,6 +336,8 @@ class Problem:
             if dim == 3:
                 v[..., 0] *= np.cos(np.pi * x[..., 2])
                 v[..., 1] *= np.cos(np.pi * x[..., 2])
+        if p == 7:  # laghos.cpp:1198-1203
+            v[..., 1] = 0.02 * np.exp(-2 * np.pi * x[..., 1] * x[..., 1]) * np.cos(2 * np.pi * x[..., 0])
         if p == 4:  # Gresho vortex, laghos.cpp:1161-1177
             x0, x1 = x[..., 0], x[..., 1]
             r = np.sqrt(x0 * x0 + x1 * x1)
@@ -356,6 +361,9 @@ class Problem:
             return np.zeros(x.shape[:-1])
         if p == 3:
             return np.where(x[..., 0] > 1.0, 0.1, 1.0) / self.rho0(x) / (self.gamma_func(x) - 1.0)
+        if p == 7:  # laghos.cpp:1268-1272
+            rho, gamma = self.rho0(x), self.gamma_func(x)
+            return (6.0 - rho * x[..., 1]) / (gamma - 1.0) / rho
         if p == 4:  # laghos.cpp:1232-1247
             x0, x1 = x[..., 0], x[..., 1]
             rsq = x0 * x0 + x1 * x1
@@ -371,10 +379,21 @@ class Problem:
         raise ValueError
 
     def source_type(self):
+        if self.problem == 7:
+            return 2  # gravity (laghos.cpp:645)
         return 1 if (self.problem == 0 and self.dim == 2) else 0
 
     def use_viscosity(self):
         return self.problem not in (0, 4)
+
+    def use_vorticity(self):
+        return self.problem == 7  # laghos.cpp:645
+
+    def accel_source(self):
+        """nodal projection of RTCoefficient (laghos_solver.hpp:221-231): (0, -1) at every node"""
+        a = np.zeros((self.dim, self.N))
+        a[1, :] = -1.0
+        return a.reshape(-1)
 
     # ---- nodal L2 (Gauss-Legendre) -> Bernstein, exact change of basis --------
     def _nodal_to_bernstein(self, vals):

@@ -1417,6 +1417,7 @@ done:
 // S = [x|v|e], dS = [dx|dv|de].  The caller owns the qdata_is_current flag
 // (laghos_solver.cpp:809-812, :326): when set, UpdateQuadratureData is skipped.
 // SolveVelocity (laghos_solver.cpp:328-398): dv_dt block of dS
+static const double *g_accel_src = nullptr; // set per call by lgo_solve_velocity_src
 void lgo_solve_velocity(void *h, const double *S, double *dS, double cg_tol, int cg_max_iter,
                         int qdata_is_current /* :809 early return */)
 {
@@ -1433,11 +1434,27 @@ void lgo_solve_velocity(void *h, const double *S, double *dS, double cg_tol, int
    for (int cc = 0; cc < dim; cc++)
    {
       std::memcpy(Bv.data(), rhs.data() + (size_t)cc * N, sizeof(double) * N); // :368-369
+      if (g_accel_src) // source_type == 2: B += VMassPA->MultFull(accel_c) (:371-380)
+      {
+         std::vector<double> BA(N);
+         lgo_mass_mult(h, 0, 1, g_accel_src + (size_t)cc * N, BA.data());
+         for (int i = 0; i < N; i++) { Bv[i] += BA[i]; }
+      }
       double *X = dv + (size_t)cc * N;                                           // :382 (dv = 0)
       lgo_mass_set_ess(h, cc);                                                   // :383
       lgo_mass_eliminate_rhs(h, Bv.data());                                      // :384
       lgo_cg(h, 0, Bv.data(), X, cg_tol, cg_max_iter);                           // :388
    }
+}
+
+// SolveVelocity with the acceleration source of problem 7 (source_type 2, :340-347:
+// accel = nodal projection of RTCoefficient = (0, -1))
+void lgo_solve_velocity_src(void *h, const double *S, double *dS, double cg_tol, int cg_max_iter,
+                            int qdata_is_current, const double *accel_h1)
+{
+   g_accel_src = accel_h1;
+   lgo_solve_velocity(h, S, dS, cg_tol, cg_max_iter, qdata_is_current);
+   g_accel_src = nullptr;
 }
 
 // SolveEnergy (laghos_solver.cpp:400-493) with the velocity v (RK2Avg passes the
@@ -1466,7 +1483,7 @@ void lgo_hydro_mult(void *h, const double *S, double *dS, double cg_tol, int cg_
    const int H1V = c->H1V;
    const double *v = S + H1V;
    std::memcpy(dS, v, sizeof(double) * H1V); // :323
-   lgo_solve_velocity(h, S, dS, cg_tol, cg_max_iter, qdata_is_current);
+   lgo_solve_velocity(h, S, dS, cg_tol, cg_max_iter, qdata_is_current); // g_accel_src: see lgo_hydro_mult_src
    lgo_solve_energy(h, v, dS, cg_tol, cg_max_iter, e_source);
 }
 

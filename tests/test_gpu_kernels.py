@@ -270,3 +270,35 @@ def test_tg_source_2d():
     assert rel_err(got.cpu().numpy(), want) < TOL
     g.close()
     o.close()
+
+
+def test_problem7_vorticity_and_gravity():
+    """Problem 7 (Rayleigh-Taylor): the vorticity-scaled viscosity of QUpdateBody
+    (laghos_solver.cpp:1097-1103) and the acceleration source of SolveVelocity (:371-380),
+    one QUpdate and one RHS evaluation on a distorted state vs the oracle."""
+    import torch
+    from oracle.fem import Problem
+    prob = Problem(mesh="rt2D", rs=1, order_v=3, order_e=2, problem=7)
+    g, o = make_gpu(prob), make_oracle(prob)
+    S = deformed_state(prob, seed=3)
+    o.reset_time_step_estimate()
+    o.qdata_is_current = False
+    o.update_quadrature_data(S)
+    g.reset_time_step_estimate()
+    g.reset_quadrature_data()
+    Sd = g.ctx.to_dev(S)
+    torch.cuda.synchronize()
+    g.update_quadrature_data(Sd)
+    assert rel_err(g.ctx.stressJinvT, o.stressJinvT) < 1e-12
+    assert abs(g.ctx.get_dt_est() - o.L.lgo_get_dt_est(o.h)) / o.L.lgo_get_dt_est(o.h) < 1e-12
+    o.cg_tol, g.cg_tol = 1e-14, 1e-14
+    dS_o = np.empty_like(S)
+    o.qdata_is_current = False
+    o.mult(S, dS_o)
+    dS = g.ctx.zeros(S.size)
+    g.reset_quadrature_data()
+    g.mult(Sd, dS)
+    g.ctx.sync()
+    assert rel_err(dS.cpu().numpy(), dS_o) < 1e-9
+    g.close()
+    o.close()

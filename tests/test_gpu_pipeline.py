@@ -239,6 +239,29 @@ def test_cpp_driver_readme_run8(golden):
     assert abs(e - g["e_norm"]) / g["e_norm"] < 5e-11, (e, g["e_norm"])
 
 
+def test_readme_run9_rayleigh_taylor(golden):
+    """README run 9 (README.md:223, :235): -p 7 -m rt2D -rs 1 -ok 4 -ot 3 -tf 4: vorticity-scaled
+    viscosity, gravity source in SolveVelocity, 2D Q4Q3 (0x258), 2462 RK4 steps - through the
+    python driver and the C++ driver.  Unstable flow: |e| within the fixture's e_rel_tol."""
+    from laghos_amd import host_lib
+    from laghos_amd.hydro import run
+    from oracle.fem import Problem
+    g = next(c for c in golden["readme"] if c["name"] == "README-9")
+    r = run(Problem(mesh=g["mesh"], rs=g["rs"], problem=g["problem"], order_v=g["order_v"], order_e=g["order_e"]),
+            t_final=g["tf"])
+    assert r["ti"] == g["step"]
+    assert f"{r['dt']:.6f}" == g["dt"]
+    assert abs(r["e_norm"] - g["e_norm"]) / g["e_norm"] < g["e_rel_tol"], (r["e_norm"], g["e_norm"])
+    sim = host_lib.Sim(["-p", 7, "-m", "data/rt2D.mesh", "-rs", 1, "-ok", 4, "-ot", 3, "-tf", 4, "-pa", "-q"])
+    while sim.step() == 1:
+        pass
+    e, ti, dt = sim.e_norm(), sim.ti, sim.dt
+    sim.close()
+    assert ti == g["step"]
+    assert f"{dt:.6f}" == g["dt"]
+    assert abs(e - g["e_norm"]) / g["e_norm"] < g["e_rel_tol"], (e, g["e_norm"])
+
+
 def test_cpp_driver_unknown_kernel():
     """(dim, D1D, Q1D) without a kernel must fail loudly like the reference's
     'Unknown kernel' abort (laghos_assembly.cpp:549-553): -ok 6 -ot 5 has no table entry."""
