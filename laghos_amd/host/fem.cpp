@@ -381,6 +381,14 @@ double Discretization::rho0(const double *x) const
          return (dim == 2) ? ((x[0] > 1.0 && x[1] > 1.5) ? 0.125 : 1.0)
                            : ((x[0] > 1.0 && ((x[1] < 1.5 && x[2] < 1.5) || (x[1] > 1.5 && x[2] > 1.5))) ? 0.125 : 1.0);
       case 4: return 1.0;
+      case 5: // laghos.cpp:1105-1110
+         if (x[0] >= 0.5 && x[1] >= 0.5) { return 0.5313; }
+         if (x[0] < 0.5 && x[1] < 0.5) { return 0.8; }
+         return 1.0;
+      case 6: // laghos.cpp:1111-1116
+         if (x[0] < 0.5 && x[1] >= 0.5) { return 2.0; }
+         if (x[0] >= 0.5 && x[1] < 0.5) { return 3.0; }
+         return 1.0;
       case 7: return x[1] >= 0.0 ? 2.0 : 1.0; // laghos.cpp:1117
       default: throw std::runtime_error("Bad number given for problem id!");
    }
@@ -394,6 +402,8 @@ double Discretization::gamma_func(const double *x) const
       case 2: return 1.4;
       case 3: return (x[0] > 1.0 && x[1] <= 1.5) ? 1.4 : 1.5;
       case 4: return 5.0 / 3.0;
+      case 5: return 1.4;
+      case 6: return 1.4;
       case 7: return 5.0 / 3.0;
       default: throw std::runtime_error("Bad number given for problem id!");
    }
@@ -410,6 +420,21 @@ void Discretization::v0(const double *x, double *v) const
          v[0] *= std::cos(M_PI * x[2]);
          v[1] *= std::cos(M_PI * x[2]);
          v[2] = 0.0;
+      }
+   }
+   else if (problem == 5 || problem == 6) // laghos.cpp:1144-1145, :1178-1197
+   {
+      const double atn = std::pow(x[0] * (1.0 - x[0]) * 4 * x[1] * (1.0 - x[1]) * 4.0, 0.4);
+      const bool hx = x[0] >= 0.5, hy = x[1] >= 0.5;
+      if (problem == 5)
+      {
+         v[0] = (!hx && hy) ? 0.7276 * atn : 0.0 * atn;
+         v[1] = (hx && !hy) ? 0.7276 * atn : 0.0 * atn;
+      }
+      else
+      {
+         v[0] = hy ? 0.75 * atn : -0.75 * atn;
+         v[1] = hx ? -0.5 * atn : 0.5 * atn;
       }
    }
    else if (problem == 7) // laghos.cpp:1198-1203
@@ -448,6 +473,13 @@ double Discretization::e0(const double *x) const
       }
       case 1: return 0.0;
       case 3: return ((x[0] > 1.0) ? 0.1 : 1.0) / rho0(x) / (gamma_func(x) - 1.0);
+      case 2: return ((x[0] < 0.5) ? 1.0 : 0.1) / rho0(x) / (gamma_func(x) - 1.0); // :1228-1229
+      case 5: // :1248-1257
+      {
+         const double irg = 1.0 / rho0(x) / (gamma_func(x) - 1.0);
+         return ((x[0] >= 0.5 && x[1] >= 0.5) ? 0.4 : 1.0) * irg;
+      }
+      case 6: return 1.0 / rho0(x) / (gamma_func(x) - 1.0); // :1258-1267
       case 7: // laghos.cpp:1268-1272
       {
          const double rho = rho0(x), gamma = gamma_func(x);

@@ -307,6 +307,11 @@ class Problem:
             return np.ones(x.shape[:-1])
         if p == 7:  # Rayleigh-Taylor, laghos.cpp:1117
             return np.where(x[..., 1] >= 0.0, 2.0, 1.0)
+        if p in (5, 6):  # 2D Riemann problems, laghos.cpp:1105-1116
+            hx, hy = x[..., 0] >= 0.5, x[..., 1] >= 0.5
+            if p == 5:
+                return np.where(hx & hy, 0.5313, np.where(~hx & ~hy, 0.8, 1.0))
+            return np.where(~hx & hy, 2.0, np.where(hx & ~hy, 3.0, 1.0))
         if p == 2:
             return np.where(x[..., 0] < 0.5, 1.0, 0.1)
         if p == 3:
@@ -321,7 +326,7 @@ class Problem:
         p = self.problem
         if p in (0, 4, 7):
             return np.full(x.shape[:-1], 5.0 / 3.0)
-        if p in (1, 2):
+        if p in (1, 2, 5, 6):
             return np.full(x.shape[:-1], 1.4)
         if p == 3:
             return np.where((x[..., 0] > 1.0) & (x[..., 1] <= 1.5), 1.4, 1.5)
@@ -336,6 +341,16 @@ class Problem:
             if dim == 3:
                 v[..., 0] *= np.cos(np.pi * x[..., 2])
                 v[..., 1] *= np.cos(np.pi * x[..., 2])
+        if p in (5, 6):  # laghos.cpp:1144-1145, :1178-1197
+            x0, x1 = x[..., 0], x[..., 1]
+            atn = np.power(x0 * (1.0 - x0) * 4 * x1 * (1.0 - x1) * 4.0, 0.4)
+            hx, hy = x0 >= 0.5, x1 >= 0.5
+            if p == 5:
+                v[..., 0] = np.where(~hx & hy, 0.7276 * atn, 0.0 * atn)
+                v[..., 1] = np.where(hx & ~hy, 0.7276 * atn, 0.0 * atn)
+            else:
+                v[..., 0] = np.where(hy, 0.75 * atn, -0.75 * atn)
+                v[..., 1] = np.where(hx, -0.5 * atn, 0.5 * atn)
         if p == 7:  # laghos.cpp:1198-1203
             v[..., 1] = 0.02 * np.exp(-2 * np.pi * x[..., 1] * x[..., 1]) * np.cos(2 * np.pi * x[..., 0])
         if p == 4:  # Gresho vortex, laghos.cpp:1161-1177
@@ -361,6 +376,13 @@ class Problem:
             return np.zeros(x.shape[:-1])
         if p == 3:
             return np.where(x[..., 0] > 1.0, 0.1, 1.0) / self.rho0(x) / (self.gamma_func(x) - 1.0)
+        if p == 2:  # laghos.cpp:1228-1229
+            return np.where(x[..., 0] < 0.5, 1.0, 0.1) / self.rho0(x) / (self.gamma_func(x) - 1.0)
+        if p in (5, 6):  # laghos.cpp:1248-1267
+            irg = 1.0 / self.rho0(x) / (self.gamma_func(x) - 1.0)
+            if p == 5:
+                return np.where((x[..., 0] >= 0.5) & (x[..., 1] >= 0.5), 0.4, 1.0) * irg
+            return irg
         if p == 7:  # laghos.cpp:1268-1272
             rho, gamma = self.rho0(x), self.gamma_func(x)
             return (6.0 - rho * x[..., 1]) / (gamma - 1.0) / rho

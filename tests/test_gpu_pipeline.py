@@ -9,7 +9,8 @@ from helpers import make_gpu, rel_err, seeded
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name", ["chk-3D-Sedov", "chk-2D-Sedov", "chk-3D-TG", "chk-2D-TG", "chk-3D-p3", "chk-2D-p3"])
+@pytest.mark.parametrize("name", ["chk-3D-Sedov", "chk-2D-Sedov", "chk-3D-TG", "chk-2D-TG", "chk-3D-p3", "chk-2D-p3"] +
+                         [f"chk-{d}D-p{p}" for p in (2, 4, 5, 6, 7) for d in (3, 2)])
 def test_checks_table_on_gpu(golden, name):
     """`--checks` golden values (laghos.cpp:1441-1463) through the HIP path.
     -cgt 1e-14: the CG runs to round-off, so the GPU/CPU difference is the
@@ -191,8 +192,7 @@ def test_full_size_sedov_steps(full_size):
 
 
 # ---- the C++ host layer (laghos_amd/host): reference API mirror + driver --------------------
-@pytest.mark.parametrize("mesh,prob", [("data/cube01_hex.mesh", 1), ("data/square01_quad.mesh", 1),
-                                       ("data/cube01_hex.mesh", 0), ("data/square01_quad.mesh", 0)])
+@pytest.mark.parametrize("mesh,prob", [(m, p) for p in range(8) for m in ("data/cube01_hex.mesh", "data/square01_quad.mesh")])
 def test_cpp_driver_checks(mesh, prob):
     """`laghos -chk` through the C++ driver: both probe points of the reference's
     --checks table must be hit and match (laghos.cpp:903-926)."""

@@ -23,7 +23,8 @@ def test_tables(ok, ot):
 
 CASES = [("cube01_hex", 1, 2, 1, 1), ("cube01_hex", 1, 3, 2, 0), ("square01_quad", 2, 2, 1, 1),
          ("box01_hex", 1, 2, 1, 3), ("rectangle01_quad", 1, 3, 2, 3), ("square01_quad", 1, 2, 1, 0),
-         ("square_gresho", 2, 3, 2, 4), ("rt2D", 1, 4, 3, 7)]
+         ("square_gresho", 2, 3, 2, 4), ("rt2D", 1, 4, 3, 7), ("cube01_hex", 1, 2, 1, 2),
+         ("square01_quad", 2, 2, 1, 5), ("cube01_hex", 1, 2, 1, 6), ("cube01_hex", 1, 2, 1, 7)]
 
 
 @pytest.mark.parametrize("mesh,rs,ok,ot,prob", CASES)

@@ -6,7 +6,8 @@ import pytest
 from oracle.driver import run
 from oracle.fem import Problem
 
-CHECK_NAMES = ["chk-3D-Sedov", "chk-2D-Sedov", "chk-3D-TG", "chk-2D-TG", "chk-3D-p3", "chk-2D-p3"]
+CHECK_NAMES = ["chk-3D-Sedov", "chk-2D-Sedov", "chk-3D-TG", "chk-2D-TG", "chk-3D-p3", "chk-2D-p3"] + \
+              [f"chk-{d}D-p{p}" for p in (2, 4, 5, 6, 7) for d in (3, 2)]  # = `make checks`: problems 0-7 x {2D, 3D}
 
 
 @pytest.mark.parametrize("name", CHECK_NAMES)
