@@ -4,7 +4,7 @@
 // uniform refinement and block partitioning, the H1 (Gauss-Lobatto) and L2
 // (Bernstein) tensor bases with their 1-D DofToQuad tables, lexicographic
 // element restrictions, boundary-attribute essential dofs, and the initial
-// conditions of problems 0, 1 and 3.  Host-only, no GPU code.
+// conditions of problems 0-7 (laghos.cpp:1094-1275).  Host-only, no GPU code.
 //
 // This is deliberately not a general FE library: just enough to
 // drive and verify the partial-assembly path.

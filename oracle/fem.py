@@ -13,7 +13,7 @@ reference's golden |e| values:
     axis-aligned structured grids with element axes = global axes)
   * H1 numbering / lexicographic element maps, byNODES vectors
   * essential dofs from boundary attributes 1/2/3 (laghos.cpp:499-515)
-  * initial conditions for problems 0, 1, 3 incl. the Sedov delta function and
+  * initial conditions for problems 0-7 incl. the Sedov delta function and
     the nodal-L2 -> Bernstein projection (laghos.cpp:568-632, :1094-1275; A11, A12)
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this.
