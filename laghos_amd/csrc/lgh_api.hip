@@ -124,6 +124,9 @@ template <typename T> static int dev_alloc_zero(T **dst, size_t n)
 {
    LGH_HIP_CHECK(hipMalloc((void **)dst, std::max<size_t>(n, 1) * sizeof(T)));
    LGH_HIP_CHECK(hipMemset(*dst, 0, std::max<size_t>(n, 1) * sizeof(T)));
+   // hipMemset of device memory returns before the fill has run (null stream) and the
+   // context's stream does not synchronise with the null stream
+   LGH_HIP_CHECK(hipStreamSynchronize(nullptr));
    return LGH_OK;
 }
 

@@ -316,9 +316,12 @@ int allreduce_dev(lgh_ctx *c, double *dev, int count, int op)
    {
       LocalGroup *g = cm->local.get();
       if (count > 8) { set_error("local communicator: count > 8"); return LGH_ERR_ARG; }
+      // `mine` / `res` are pageable: an async copy to or from pageable memory is not
+      // ordered with the kernels of the stream (observed: stale sums, run-to-run different
+      // results), so drain the stream first and copy synchronously
       double mine[8];
-      LGH_HIP_CHECK(hipMemcpyAsync(mine, dev, count * sizeof(double), hipMemcpyDeviceToHost, c->stream));
       LGH_HIP_CHECK(hipStreamSynchronize(c->stream));
+      LGH_HIP_CHECK(hipMemcpy(mine, dev, count * sizeof(double), hipMemcpyDeviceToHost));
       for (int i = 0; i < count; i++) { g->slots[(size_t)c->rank * 8 + i] = mine[i]; }
       if (!g->barrier()) { set_error("local communicator: barrier timed out (all-reduce)"); return LGH_ERR_COMM; }
       double res[8];
@@ -333,8 +336,7 @@ int allreduce_dev(lgh_ctx *c, double *dev, int count, int op)
          res[i] = r;
       }
       if (!g->barrier()) { set_error("local communicator: barrier timed out (all-reduce)"); return LGH_ERR_COMM; }
-      LGH_HIP_CHECK(hipMemcpyAsync(dev, res, count * sizeof(double), hipMemcpyHostToDevice, c->stream));
-      LGH_HIP_CHECK(hipStreamSynchronize(c->stream));
+      LGH_HIP_CHECK(hipMemcpy(dev, res, count * sizeof(double), hipMemcpyHostToDevice));
       return LGH_OK;
    }
    if (!cm || !cm->comm) { return LGH_OK; }
@@ -521,6 +523,7 @@ int lgh_comm_set_neighbors(lgh_ctx *c, int n_nbr, const int *nbr_rank, const int
    LGH_HIP_CHECK(hipMalloc((void **)&cm->recvbuf, (size_t)cm->bufsize * sizeof(double)));
    LGH_HIP_CHECK(hipMemset(cm->sendbuf, 0, (size_t)cm->bufsize * sizeof(double)));
    LGH_HIP_CHECK(hipMemset(cm->recvbuf, 0, (size_t)cm->bufsize * sizeof(double)));
+   LGH_HIP_CHECK(hipStreamSynchronize(nullptr)); // the fills run asynchronously on the null stream
    {
       // per-neighbour tables and the rank -> neighbour map of the piggy-backed scalars
       void *old[] = {cm->d_base, cm->d_cnt, cm->rank_src};
@@ -596,7 +599,10 @@ int lgh_allreduce(lgh_ctx *c, double *value, int op)
 {
    LGH_CHECK_ARG(c && value);
    if (!c->multi || !c->comm) { return LGH_OK; }
-   LGH_HIP_CHECK(hipMemcpyAsync(c->scal + 2, value, sizeof(double), hipMemcpyHostToDevice, c->stream));
+   // through the pinned staging area: an async copy from pageable memory is not ordered
+   // with the stream
+   c->host_pinned[3] = *value;
+   LGH_HIP_CHECK(hipMemcpyAsync(c->scal + 2, c->host_pinned + 3, sizeof(double), hipMemcpyHostToDevice, c->stream));
    int rc = allreduce_dev(c, c->scal + 2, 1, op);
    if (rc) { return rc; }
    LGH_HIP_CHECK(hipMemcpyAsync(c->host_pinned + 2, c->scal + 2, sizeof(double), hipMemcpyDeviceToHost, c->stream));

@@ -997,6 +997,7 @@ int vcg_solve(lgh_ctx *c, const double *B, double *X, double rel_tol, int max_it
       LGH_HIP_CHECK(hipMemset(c->vcg_partials, 0, 2 * kVC * (size_t)c->vcg_stride * sizeof(double)));
       LGH_HIP_CHECK(hipMalloc((void **)&c->vcg_tickets, 2 * kTicketSlot * sizeof(unsigned int)));
       LGH_HIP_CHECK(hipMemset(c->vcg_tickets, 0, 2 * kTicketSlot * sizeof(unsigned int)));
+      LGH_HIP_CHECK(hipStreamSynchronize(nullptr)); // the fills run asynchronously on the null stream
    }
    VcgScalars *ds = (VcgScalars *)c->vcg_s;
    hipLaunchKernelGGL(vcg_set_tol_k, dim3(1), dim3(1), 0, c->stream, ds, rel_tol * rel_tol);

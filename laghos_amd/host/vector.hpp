@@ -49,6 +49,8 @@ public:
       own_ = true;
       LAGHOS_HIP(hipMalloc((void **)&d_, (n > 0 ? n : 1) * sizeof(double)));
       LAGHOS_HIP(hipMemset(d_, 0, (n > 0 ? n : 1) * sizeof(double)));
+      // the fill runs asynchronously on the null stream; the library's stream is non-blocking
+      LAGHOS_HIP(hipStreamSynchronize(nullptr));
    }
    // non-owning view of a sub-range (ParGridFunction::MakeRef, laghos_solver.cpp:319)
    void MakeRef(Vector &base, long offset, long n)

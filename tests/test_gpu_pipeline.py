@@ -385,8 +385,9 @@ def test_halo_logic_emulated_ranks(pgrid):
         c.close()
 
 
-@pytest.mark.parametrize("nranks,nel", [(2, (8, 8, 8)), (8, (8, 8, 8)), (3, (9, 6, 6))])
-def test_multi_rank_run_on_one_gpu(nranks, nel):
+@pytest.mark.parametrize("nranks,nel,problem", [(2, (8, 8, 8), 1), (8, (8, 8, 8), 1), (3, (9, 6, 6), 1),
+                                                (4, (8, 8, 4), 7)])
+def test_multi_rank_run_on_one_gpu(nranks, nel, problem):
     """The complete multi-rank algorithm (block partition, owner-weighted dot products,
     halo pack / canonical combine, separate-gather CG sequencing with its finish
     kernels, dt / |e| reductions) on ONE GPU: the ranks are contexts driven by one host
@@ -396,11 +397,12 @@ def test_multi_rank_run_on_one_gpu(nranks, nel):
     |e| to round-off (the ranks sum shared-node contributions in a different order).
     2 and 2x2x2 ranks are all-pairs neighbours: (d, A d) rides on the halo messages; in the
     3x1x1 partition only the middle rank sees all others, so the (collective) decision
-    must fall back to the all-reduce on every rank."""
+    must fall back to the all-reduce on every rank.  The 4-rank case runs problem 7
+    (vorticity-scaled viscosity, gravity source through the halo-summed MultFull)."""
     import os
     import threading
     from laghos_amd import host_lib
-    args = ["-p", 1, "-dim", 3, "-nx", nel[0], "-ny", nel[1], "-nz", nel[2], "-Sx", 1, "-Sy", 1, "-Sz", 1, "-rs", 0,
+    args = ["-p", problem, "-dim", 3, "-nx", nel[0], "-ny", nel[1], "-nz", nel[2], "-Sx", 1, "-Sy", 1, "-Sz", 1, "-rs", 0,
             "-ok", 3, "-ot", 2, "-pa", "-tf", 0.6, "-ms", 6, "-q"]
     ref = host_lib.Sim(args)
     while ref.step() == 1:
