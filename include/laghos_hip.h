@@ -167,6 +167,33 @@ int lgh_tg_source_2d(lgh_ctx *ctx, const double *S, double *e_source);
 int lgh_internal_energy(lgh_ctx *ctx, const double *e_l2, double *result);
 int lgh_kinetic_energy(lgh_ctx *ctx, const double *v_h1, double *result);
 
+/* ---- `-err`: density against the exact Sedov blast wave (laghos.cpp:1007-1086) ---------
+ * Replaces the host-side SedovSol class (sedov/sedov_sol.hpp:21-76, sedov_sol.cpp),
+ * LagrangianHydroOperator::ComputeDensity (laghos_solver.cpp:542-563) and the error loop
+ * of the driver.  The solution's parameter block `par` is 21 host doubles:
+ *   dim gamma rho0 E omega | a b c d e | alpha0..alpha5 | V0 Vv V2 Vs | alpha
+ * (the members of SedovSol, sedov_sol.hpp:24-55). */
+/* SedovSol::SedovSol (sedov_sol.cpp:27-117): constants and the energy integral alpha
+ * (adaptive 21-point Gauss-Kronrod, host).  omega must be 0 (uniform initial density). */
+int lgh_sedov_setup(int dim, double gamma, double rho0, double blast_energy, double omega, double par[21]);
+/* SedovSol::SetTime (sedov_sol.cpp:119-130): shock[6] = r2 U rho1 rho2 v2 p2 at time t. */
+int lgh_sedov_shock(const double par[21], double t, double shock[6]);
+/* SedovSol::EvalSol (sedov_sol.cpp:132-198) at one radius, on the host (scalar API of the class). */
+int lgh_sedov_eval_point(const double par[21], double t, double r, double *rho, double *v, double *P);
+/* The same for n radii on the GPU: r, rho, v, P are device arrays; asynchronous on the context's stream. */
+int lgh_sedov_eval(lgh_ctx *ctx, const double par[21], double t, long n, const double *r, double *rho, double *v,
+                   double *P);
+/* ComputeDensity (laghos_solver.cpp:542-563): zone-local L2 projection of the density on the
+ * mesh positions x_h1 (= S, device) into rho_l2 (L2 size, device).  Needs lgh_setup_rho0detj0. */
+int lgh_compute_density(lgh_ctx *ctx, const double *x_h1, double *rho_l2);
+/* laghos.cpp:1027-1080: err2 = integral over the current mesh of (rho_exact(|x - origin|, t) - rho_h)^2
+ * with the n1d^dim tensor Gauss-Legendre rule given by HOST tables on [0,1]: weights[n1d],
+ * B_h1/G_h1 [p + n1d*d] (H1 basis values / derivatives), B_l2 [p + n1d*l] (L2 basis).
+ * Summed over the ranks; synchronous. */
+int lgh_sedov_density_error(lgh_ctx *ctx, const double *x_h1, const double *rho_l2, const double par[21], double t,
+                            const double origin[3], int n1d, const double *weights, const double *B_h1,
+                            const double *G_h1, const double *B_l2, double *err2);
+
 /* ---- timing data (TimingData, laghos_solver.hpp:39-56): seconds measured with
  * HIP events around the same regions as the reference stopwatches.
  * t[0..3] = cgH1, cgL2, force, qdata; c[0..2] = H1iter, L2iter, quad_tstep */

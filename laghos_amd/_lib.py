@@ -73,6 +73,12 @@ SYMBOLS = {
     "lgh_vec_dot": (_I, [_P, _P, _P, _L, c_dbl_p]),
     "lgh_internal_energy": (_I, [_P, _P, c_dbl_p]),
     "lgh_kinetic_energy": (_I, [_P, _P, c_dbl_p]),
+    "lgh_sedov_setup": (_I, [_I, _D, _D, _D, _D, c_dbl_p]),
+    "lgh_sedov_shock": (_I, [c_dbl_p, _D, c_dbl_p]),
+    "lgh_sedov_eval_point": (_I, [c_dbl_p, _D, _D, c_dbl_p, c_dbl_p, c_dbl_p]),
+    "lgh_sedov_eval": (_I, [_P, c_dbl_p, _D, _L, _P, _P, _P, _P]),
+    "lgh_compute_density": (_I, [_P, _P, _P]),
+    "lgh_sedov_density_error": (_I, [_P, _P, _P, c_dbl_p, _D, c_dbl_p, _I, c_dbl_p, c_dbl_p, c_dbl_p, c_dbl_p, c_dbl_p]),
     "lgh_get_timers": (_I, [_P, c_dbl_p, ctypes.POINTER(ctypes.c_long)]),
     "lgh_reset_timers": (_I, [_P]),
     "lgh_enable_timers": (_I, [_P, _I]),

@@ -27,6 +27,34 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
+def _dbl(a):
+    """host pointer of a contiguous float64 numpy array (kept alive by the caller)"""
+    assert isinstance(a, np.ndarray) and a.dtype == np.float64 and a.flags.c_contiguous
+    return a.ctypes.data_as(_lib.c_dbl_p)
+
+
+def sedov_setup(dim, gamma, rho0, blast_energy, omega=0.0):
+    """SedovSol::SedovSol (sedov/sedov_sol.cpp:27-117): the 21-entry parameter block."""
+    par = np.zeros(21)
+    check(_lib.load().lgh_sedov_setup(int(dim), float(gamma), float(rho0), float(blast_energy), float(omega), _dbl(par)))
+    return par
+
+
+def sedov_shock(par, t):
+    """SedovSol::SetTime: (r2, U, rho1, rho2, v2, p2)."""
+    out = np.zeros(6)
+    check(_lib.load().lgh_sedov_shock(_dbl(par), float(t), _dbl(out)))
+    return out
+
+
+def sedov_eval_point(par, t, r):
+    """SedovSol::EvalSol at one radius (host)."""
+    rho, v, p = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+    check(_lib.load().lgh_sedov_eval_point(_dbl(par), float(t), float(r), ctypes.byref(rho), ctypes.byref(v),
+                                           ctypes.byref(p)))
+    return rho.value, v.value, p.value
+
+
 class Context:
     """lgh_ctx owner.  Arguments follow struct lgh_config: tables are (Q,D)
     arrays B[q,d]; h1_map is (NE, ND); ess is a list of dim int arrays."""
@@ -192,6 +220,29 @@ class Context:
 
     def tg_source_2d(self, S, out):
         check(self.lib.lgh_tg_source_2d(self.h, _ptr(S), _ptr(out)))
+
+    # ---- `-err`: density against the exact Sedov solution (include/laghos_hip.h) ----
+    def compute_density(self, x, rho_l2):
+        """ComputeDensity (laghos_solver.cpp:542-563); x = S (positions first)."""
+        check(self.lib.lgh_compute_density(self.h, _ptr(x), _ptr(rho_l2)))
+
+    def sedov_eval(self, par, t, r, rho, v, P):
+        """SedovSol::EvalSol for a device array of radii."""
+        check(self.lib.lgh_sedov_eval(self.h, _dbl(par), float(t), r.numel(), _ptr(r), _ptr(rho), _ptr(v), _ptr(P)))
+
+    def sedov_density_error(self, x, rho_l2, par, t, origin, weights, B_h1, G_h1, B_l2):
+        """Integral of (rho_exact - rho_h)^2 over the current mesh (laghos.cpp:1027-1080);
+        the tables are host arrays of the error rule: weights[n], B/G [p + n*d], B_l2 [p + n*l]."""
+        import numpy as np
+        w = np.ascontiguousarray(weights, dtype=np.float64)
+        tabs = [np.ascontiguousarray(a, dtype=np.float64).ravel() for a in (B_h1, G_h1, B_l2)]
+        org = np.zeros(3)
+        org[:len(origin)] = origin
+        out = ctypes.c_double()
+        check(self.lib.lgh_sedov_density_error(self.h, _ptr(x), _ptr(rho_l2), _dbl(par), float(t), _dbl(org),
+                                               int(w.size), _dbl(w), _dbl(tabs[0]), _dbl(tabs[1]), _dbl(tabs[2]),
+                                               ctypes.byref(out)))
+        return out.value
 
     def solve_energy_begin(self, S, v, dS, e_rhs, rel_tol, max_iter, e_source=None):
         check(self.lib.lgh_solve_energy_begin(self.h, _ptr(S), _ptr(v), _ptr(dS), _ptr(e_rhs),

@@ -7,6 +7,7 @@
 // (visualisation, VisIt, -fa, AMR, METIS, Umpire, Caliper) is out of scope
 // (SURVEY §2).  Exposed both as the `laghos` executable and as C entry points
 // (laghos_sim_*) that bench.py drives through ctypes.
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <iomanip>
@@ -17,6 +18,7 @@
 #include <string>
 
 #include "laghos_solver.hpp"
+#include "sedov_exact.hpp"
 
 using namespace laghos;
 
@@ -39,6 +41,7 @@ struct Options
    bool p_assembly = true;
    int vis_steps = 5;
    bool check = false, fom = false, impose_visc = false;
+   bool check_exact_sedov = false; // -err (laghos.cpp:262)
    int dev = 0;
    // multi-rank (set by the launcher, not the reference CLI)
    int nranks = 1, rank = 0;
@@ -80,6 +83,8 @@ bool ParseArgs(int argc, const char *const *argv, Options &o, std::string &err)
       if (a == "-iv" || a == "--impose-viscosity") { o.impose_visc = true; continue; }
       if (a == "-niv" || a == "--no-impose-viscosity") { o.impose_visc = false; continue; }
       if (a == "-f" || a == "--fom") { o.fom = true; continue; }
+      if (a == "-err" || a == "--exact-error") { o.check_exact_sedov = true; continue; }
+      if (a == "-no-err" || a == "--no-exact-error") { o.check_exact_sedov = false; continue; }
       if (a == "-no-fom" || a == "--no-fom") { o.fom = false; continue; }
       if (a == "-q" || a == "--quiet") { o.quiet = true; continue; }
       if (a == "-d" || a == "--device") { if (!need(i)) { return false; } continue; } // always the HIP path
@@ -169,6 +174,19 @@ laghos_sim *laghos_sim_create(int argc, const char *const *argv, int nranks, int
    {
       std::fprintf(stderr, "laghos: %s\n", err.c_str());
       return nullptr;
+   }
+   if (o.check_exact_sedov) // laghos.cpp:303-309
+   {
+      if (o.problem != 1)
+      {
+         std::fprintf(stderr, "Can only compare problem 1 (Sedov) against the exact solution\n");
+         return nullptr;
+      }
+      if (o.mesh_file.compare(0, 7, "default") != 0)
+      {
+         std::fprintf(stderr, "check: mesh_file\n");
+         return nullptr;
+      }
    }
    if (!o.p_assembly)
    {
@@ -288,6 +306,29 @@ int laghos_sim_step(laghos_sim *s)
       s->ti++;
       return 1;
    }
+}
+
+// `-err` (laghos.cpp:1007-1086): L2 error of the density against the exact Sedov solution at
+// t_final.  Returns a negative value (and sets the error string) when the exact shock has
+// reached the boundary of the default mesh.
+double laghos_sim_sedov_error(laghos_sim *s)
+{
+   const Options &o = s->opt;
+   const double gamma = 1.4, rho0 = 1, omega = 0;
+   SedovSol asol(o.dim, gamma, rho0, o.blast_energy, omega);
+   asol.SetTime(o.t_final);
+   const double min_r = std::min(std::min(o.Sx, o.Sy), o.Sz);
+   if (!(asol.r2 <= min_r))
+   {
+      s->error = "Solution reflections off boundaries detected, cannot compare against exact solution.";
+      std::fprintf(stderr, "%s\n", s->error.c_str());
+      return -1.0;
+   }
+   const int err_order = std::max((std::max(o.order_v, o.order_e) + 1) * 2, o.order_q) * 2;
+   const double blast_position[3] = {0.0, 0.0, 0.0};
+   Vector rho;
+   s->hydro->ComputeDensity(s->S, rho);
+   return s->hydro->SedovDensityError(s->S, rho, asol.par, o.t_final, blast_position, err_order);
 }
 
 // state / metrics access for bench.py
@@ -419,6 +460,13 @@ int laghos_main(int argc, const char *const *argv)
    std::cout << "Energy  diff: " << std::scientific << std::setprecision(2)
              << std::fabs(s->energy_init - energy_final) << std::endl;
    int ret = 0;
+   if (o.check_exact_sedov)
+   {
+      const double err = laghos_sim_sedov_error(s);
+      if (err < 0) { laghos_sim_destroy(s); return 1; }
+      // the reference prints this with the stream state left by "Energy diff" (scientific, 2 digits)
+      std::cout << "Density L2 error: " << std::scientific << std::setprecision(6) << err << std::endl;
+   }
    if (o.check && !(s->checks == 2 && s->checks_ok))
    {
       std::cout << "Check error!" << std::endl; // MFEM_VERIFY(!check || checks == 2) (laghos.cpp:926)

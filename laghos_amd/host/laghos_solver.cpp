@@ -207,6 +207,27 @@ double LagrangianHydroOperator::ENorm(const Vector &S) const
    return std::sqrt(n2);
 }
 
+void LagrangianHydroOperator::ComputeDensity(const Vector &S, Vector &rho) const
+{
+   if (rho.Size() != L2Vsize) { rho.SetSize(L2Vsize); }
+   LGH_VERIFY(lgh_compute_density(ctx, S.Read(), rho.Write()));
+}
+
+double LagrangianHydroOperator::SedovDensityError(const Vector &S, const Vector &rho, const double par[21], double t,
+                                                  const double origin[3], int err_order) const
+{
+   // IntRules.Get(cube, err_order): tensor Gauss-Legendre with err_order/2+1 points per direction
+   const int n1 = err_order / 2 + 1;
+   std::vector<double> pts, wts, Bh, Gh, Bl;
+   GaussLegendre(n1, pts, wts);
+   LagrangeTables(disc.tab.gll, pts, Bh, Gh);
+   BernsteinTable(disc.tab.order_e, pts, Bl);
+   double err2 = 0;
+   LGH_VERIFY(lgh_sedov_density_error(ctx, S.Read(), rho.Read(), par, t, origin, n1, wts.data(), Bh.data(), Gh.data(),
+                                      Bl.data(), &err2));
+   return std::sqrt(err2);
+}
+
 double LagrangianHydroOperator::AllReduce(double v, int op) const
 {
    if (disc.part.nranks > 1) { LGH_VERIFY(lgh_allreduce(ctx, &v, op)); }

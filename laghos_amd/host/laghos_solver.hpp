@@ -77,6 +77,12 @@ public:
    double InternalEnergy(const Vector &S) const;
    double KineticEnergy(const Vector &S) const;
    double ENorm(const Vector &S) const; // ||e||_2, all-reduced (laghos.cpp:794-795)
+   // zone-local L2 projection of the density on the current mesh (laghos_solver.cpp:542-563)
+   void ComputeDensity(const Vector &S, Vector &rho) const;
+   // sqrt of the integral of (rho_exact - rho)^2 against the exact Sedov solution `par` at time t,
+   // error rule of order err_order (laghos.cpp:1007-1086); all-reduced
+   double SedovDensityError(const Vector &S, const Vector &rho, const double par[21], double t,
+                            const double origin[3], int err_order) const;
    void PrintTimingData(bool IamRoot, int steps, bool fom) const;
    const TimingData &Timing() const;
    void ResetTiming();

@@ -35,7 +35,7 @@ def load():
         L.laghos_sim_destroy.argtypes = [P]
         L.laghos_sim_step.restype = I
         L.laghos_sim_step.argtypes = [P]
-        for n in ("laghos_sim_time", "laghos_sim_dt", "laghos_sim_enorm", "laghos_sim_energy"):
+        for n in ("laghos_sim_time", "laghos_sim_dt", "laghos_sim_enorm", "laghos_sim_energy", "laghos_sim_sedov_error"):
             getattr(L, n).restype = D
             getattr(L, n).argtypes = [P]
         for n in ("laghos_sim_steps", "laghos_sim_ti"):
@@ -112,6 +112,10 @@ class Sim:
 
     def energy(self):
         return self.L.laghos_sim_energy(self.h)
+
+    def sedov_error(self):
+        """`-err`: L2 error of the density against the exact Sedov solution at t_final."""
+        return self.L.laghos_sim_sedov_error(self.h)
 
     def enable_timers(self, on):
         self.L.laghos_sim_enable_timers(self.h, int(on))

@@ -59,6 +59,22 @@ class HydroOperator:
     def close(self):
         self.ctx.close()
 
+    # ---- `-err` post-processing (laghos.cpp:1007-1086) ----
+    def compute_density(self, S):
+        """LagrangianHydroOperator::ComputeDensity (laghos_solver.cpp:542-563)"""
+        rho = self.ctx.zeros(self.p.L2V)
+        self.ctx.compute_density(S, rho)
+        return rho
+
+    def sedov_density_error(self, S, rho, par, t, origin, weights, B_h1, G_h1, B_l2):
+        """sqrt of the integrated squared density error against the exact Sedov solution `par`
+        (context.sedov_setup); the error rule comes as host tables [p, d] (transposed here to the
+        library's [p + n*d] layout)."""
+        import numpy as np
+        err2 = self.ctx.sedov_density_error(S, rho, par, t, origin, weights, np.asarray(B_h1).T.copy(),
+                                            np.asarray(G_h1).T.copy(), np.asarray(B_l2).T.copy())
+        return float(np.sqrt(err2))
+
     def reset_time_step_estimate(self):
         self.ctx.set_dt_est(float("inf"))
 
