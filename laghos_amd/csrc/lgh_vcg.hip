@@ -795,7 +795,7 @@ vcg_update_k(const VcgArgs a)
    __shared__ double red[16];
    if (a.s->all_done) { return; }
    const bool it1 = (a.iter == 1);
-   const int n = blockIdx.x * blockDim.x + threadIdx.x;
+   const int n = xcd_swizzle(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
    const bool ok = n < a.N;
    const int nn = ok ? n : a.N - 1;
    double part[kVC] = {0.0, 0.0, 0.0};
