@@ -178,6 +178,30 @@ LGH_HD double hypot_scaled(const double a, const double b) { return sqrt(a * a +
 // every branch (measured: 4300 VALU instructions per wave).
 #define LGH_SM_QTINY 3.2e-30
 
+// cos(acos(t)/3) for t in [-0.9, 1], i.e. the largest root c of 4c^3 - 3c = t (c in [0.62, 1]):
+// Newton's method from a quadratic fit (error <= 0.023; the cubic is convex for c > 0 and its
+// slope is >= 1.6 on the range, so the fourth step is at round-off: <= 2 ulp against the
+// library pair, checked over the range on the host).  The characteristic-cubic roots of the
+// eigenvalue / singular-value routines need nothing else, and an acos plus a cos call are
+// 93 + 148 VALU instructions against ~25 here.
+LGH_HD double cos_third_acos(const double t)
+{
+   double c = fma(t, fma(t, -0.0709, 0.2049), 0.8660254037844386);
+#pragma unroll
+   for (int i = 0; i < 4; i++)
+   {
+      const double c2 = c * c;
+      const double p = fma(c, fma(4.0, c2, -3.0), -t);
+      const double dp = fma(12.0, c2, -3.0);
+#if defined(__HIP_DEVICE_COMPILE__)
+      c = fma(-p, __builtin_amdgcn_rcp(dp), c); // Newton corrects the reciprocal's last bits
+#else
+      c -= p / dp;
+#endif
+   }
+   return c;
+}
+
 // Jacobi rotation (c,s) for [d1 d12; d12 d2]; d1,d2 become the eigenvalues.
 LGH_HD void eigensystem2s(const double d12, double &d1, double &d2, double &c, double &s)
 {
@@ -537,9 +561,9 @@ LGH_HD void min_eigenpair3(const double *data, double &lambda, double *vec)
       else
       {
          R = R / sqrtQ3;
-         // one acos / cos call site for both signs: (acos(R) + 0.0) / 3 is exactly the
-         // reference's acos(R) / 3, and a wave with both signs runs the pair once
-         r = -2 * sqrtQ * cos((acos(R) + ((R < 0.) ? 2.0 * M_PI : 0.0)) / 3);
+         // reference: cos(acos(R)/3) for R >= 0, cos((acos(R) + 2 pi)/3) for R < 0; the second
+         // is -cos(acos(-R)/3), so both are the isolated root +-cos_third_acos(|R|)
+         r = -2 * sqrtQ * copysign(cos_third_acos(fabs(R)), R);
       }
       aa += r;
       c1 = d11 - aa;
@@ -671,9 +695,11 @@ LGH_HD double min_singular3(const double *data)
       else
       {
          R = R / sqrtQ3;
-         // the three cases share one acos / cos call site (see min_eigenpair3)
          const bool mid = (fabs(R) <= 0.9), neg = (R < 0.);
-         const double cs = cos((acos(R) + ((!mid && neg) ? 2.0 * M_PI : 0.0)) / 3);
+         // mid: cos(acos(R)/3); else the isolated root, cos((acos(R) + 2 pi)/3) = -cos(acos(-R)/3)
+         // for R < 0 and cos(acos(R)/3) for R > 0
+         const double cta = cos_third_acos(mid ? R : fabs(R));
+         const double cs = (!mid && neg) ? -cta : cta;
          if (mid)
          {
             aa -= 2 * sqrtQ * cs; // min root directly
