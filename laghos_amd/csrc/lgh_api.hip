@@ -433,7 +433,28 @@ int lgh_solve_velocity(lgh_ctx *c, const double *S, double *dS_dt, const double 
    (void)S;
    const int dim = c->dim, N = c->N;
    double *dv = dS_dt + c->H1V;
-   int rc = vec_set(c, dv, 0.0, c->H1V); // dv = 0.0 (:338)
+   int rc;
+   // One rank, region timers off, no acceleration source: the E->L sum of F.1, the negation,
+   // EliminateRHS, dv = 0 and the CG initialisation are one kernel (vcg_init_force_k), with
+   // bit-identical results.  With the timers on the reference's regions are kept apart.
+   if (!c->timers.enabled && !c->accel_src && vcg_fused_init_ok(c))
+   {
+      kt_begin(c, LGH_KERNEL_FORCE_MULT);
+      rc = force_mult_E(c, c->stressJinvT, one_l2, c->YE); // :354 up to the E-vector (K1 reuses c->YE after the init)
+      kt_end(c, LGH_KERNEL_FORCE_MULT);
+      if (rc) { return rc; }
+      int its[3] = {0, 0, 0};
+      rc = vcg_solve(c, rhs_h1, dv, rel_tol, max_iter, its, c->YE); // :358-388
+      if (rc) { return rc; }
+      for (int cc = 0; cc < dim; cc++)
+      {
+         c->timers.c[0] += its[cc]; // :392
+         if (h1_iters) { *h1_iters += its[cc]; }
+      }
+      c->cur_ess = dim - 1;
+      return LGH_OK;
+   }
+   rc = vec_set(c, dv, 0.0, c->H1V); // dv = 0.0 (:338)
    if (rc) { return rc; }
    timer_start(c);
    rc = lgh_force_mult(c, one_l2, rhs_h1); // :354

@@ -318,7 +318,9 @@ int mass_apply_h1(lgh_ctx *c, const double *x, double *y, bool eliminate);
 int mass_apply_l2(lgh_ctx *c, const double *x, double *y);
 int mass_apply_E(lgh_ctx *c, int space, const double *xE, double *yE);
 int mass_assemble_diag(lgh_ctx *c);
-int vcg_solve(lgh_ctx *c, const double *B, double *X, double rel_tol, int max_iter, int iters[3]);
+int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, int iters[3],
+              const double *force_E = nullptr);
+bool vcg_fused_init_ok(const lgh_ctx *c);
 bool vcg_available(const lgh_ctx *c);
 // multi-rank: flags / list of the nodes shared with other ranks (nullptr / 0 without neighbours)
 void comm_shared_nodes(const lgh_ctx *c, const uint8_t **hmask, const int **sh_node, int *n_shared);

@@ -743,6 +743,70 @@ vcg_init_k(const VcgArgs a)
       }
    }
 }
+// ---- init fused with the tail of ForcePA->Mult(one) (SolveVelocity, laghos_solver.cpp:354-384):
+// b = -(H1R^T Y_E) with the essential rows of every component zeroed, x = 0, r = b, nom.  FE is
+// the force E-vector in the reference layout (D1D^3, dim, NE) (laghos_assembly.cpp:312); the sum
+// runs in the order of h1_transpose_gather_k, so b has the bits of the separate
+// gather / negate / EliminateRHS kernels it replaces (four passes over the vectors less).
+template <int DEG>
+__global__ void __launch_bounds__(256)
+vcg_init_force_k(const VcgArgs a, const double *__restrict__ FE, const int ND, double *__restrict__ bout)
+{
+   __shared__ double red[16];
+   const int n = blockIdx.x * blockDim.x + threadIdx.x; // block order of vcg_init_k: same partial sums
+   double part[kVC] = {0.0, 0.0, 0.0};
+   if (n < a.N)
+   {
+      long pos[DEG];
+#pragma unroll
+      for (int j = 0; j < DEG; j++)
+      {
+         const int p = (j < a.deg) ? a.ell[(size_t)j * a.N + n] : -1; // e*ND + d
+         const int e = p / ND;
+         pos[j] = (p >= 0) ? (long)kVC * ND * e + (p - e * ND) : -1;
+      }
+      const double di = a.dinv[n];
+#pragma unroll
+      for (int c = 0; c < kVC; c++)
+      {
+         double s = 0.0;
+#pragma unroll
+         for (int j = 0; j < DEG; j++) { if (pos[j] >= 0) { s += FE[pos[j] + (long)ND * c]; } }
+         double bv = -s;
+         if (a.ess[c] && a.ess[c][n]) { bv = 0.0; }
+         const size_t i = (size_t)c * a.N + n;
+         bout[i] = bv;
+         a.r[i] = bv;
+         a.x[i] = 0.0;
+         part[c] = __dmul_rn(bv, di) * bv;
+      }
+   }
+   double bp[kVC], total[kVC];
+#pragma unroll
+   for (int c = 0; c < kVC; c++)
+   {
+      bp[c] = block_sum(part[c], red);
+      __syncthreads();
+   }
+   if (grid_sum3_last_block(bp, a.partials, a.stride, a.ticket, red, total))
+   {
+      if (threadIdx.x == 0)
+      {
+         VcgScalars *s = a.s;
+         int all = 1;
+         for (int c = 0; c < kVC; c++)
+         {
+            s->rz[c] = s->rz_prev[c] = total[c];
+            s->iters[c] = 0;
+            s->r0[c] = fmax(total[c] * s->rel_tol2, 0.0);
+            s->done[c] = (total[c] < 0.0 || total[c] <= s->r0[c]) ? 1 : 0;
+            all = all && s->done[c];
+         }
+         s->first = 1;
+         s->all_done = all;
+      }
+   }
+}
 __global__ void vcg_init_finish_k(VcgScalars *s)
 {
    int all = 1;
@@ -977,10 +1041,18 @@ template <int D, int Q> static void launch_vcg_apply(lgh_ctx *c, const VcgArgs &
    } while (0)
 
 bool vcg_available(const lgh_ctx *c) { return vcg_supported(c); }
+bool vcg_fused_init_ok(const lgh_ctx *c)
+{
+   static const char *env = getenv("LGH_FUSED_INIT"); // A/B switch
+   if (env && env[0] == '0') { return false; }
+   return vcg_supported(c) && c->multi == 0 && c->t_deg <= 8;
+}
 
 // B, X: dim*N (byNODES).  X must be zero on entry (dv = 0, laghos_solver.cpp:338, :382).
+// force_E != nullptr: B and X are outputs - the init kernel forms B = -(H1R^T force_E) with the
+// essential rows zeroed and X = 0 itself (single rank only; see vcg_init_force_k).
 // iters[c] = GetNumIterations() of component c.
-int vcg_solve(lgh_ctx *c, const double *B, double *X, double rel_tol, int max_iter, int iters[3])
+int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, int iters[3], const double *force_E)
 {
    if (!vcg_supported(c)) { return LGH_ERR_UNSUPPORTED; }
    const bool multi = c->multi != 0;
@@ -1037,7 +1109,12 @@ int vcg_solve(lgh_ctx *c, const double *B, double *X, double rel_tol, int max_it
    // init (vector kernels use reduction slot 0, the element kernel slot 1)
    a.partials = c->vcg_partials;
    a.ticket = c->vcg_tickets;
-   hipLaunchKernelGGL(vcg_init_k, dim3(nb), dim3(256), 0, c->stream, a);
+   if (force_E)
+   {
+      if (multi || c->t_deg > 8) { set_error("vcg_solve: fused init is single-rank, degree <= 8"); return LGH_ERR_ARG; }
+      hipLaunchKernelGGL(vcg_init_force_k<8>, dim3(nb), dim3(256), 0, c->stream, a, force_E, c->ND, B);
+   }
+   else { hipLaunchKernelGGL(vcg_init_k, dim3(nb), dim3(256), 0, c->stream, a); }
    LGH_HIP_CHECK(hipGetLastError());
    if (multi)
    {
