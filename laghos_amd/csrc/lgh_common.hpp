@@ -119,7 +119,7 @@ struct lgh_ctx
    unsigned int *tickets;// 4 reduction slots of lgh::kTicketSlot counters (sharded tickets)
    lgh::CgScalars *cgs;  // device
    double *scal;         // small device scalar pool (16 doubles)
-   double *host_pinned;  // pinned host staging (16 doubles)
+   double *host_pinned;  // pinned host staging, 64 doubles: [0..7] scalar CG / misc, [8] dt, [32..] lockstep CG scalars
 
    // lockstep velocity CG (lgh_vcg.hip), allocated on first use
    void *vcg_s;
