@@ -148,3 +148,40 @@ def test_cpp_driver_err_option_guards():
     p = subprocess.run([exe, "-p", "1", "-pa", "-err", "-dim", "2", "-nx", "4", "-ny", "4", "-rs", "0", "-ms", "2", "-tf", "5.0"],
                        capture_output=True, text=True, timeout=300)
     assert p.returncode != 0 and "reflections" in (p.stdout + p.stderr)
+
+
+@pytest.mark.parametrize("nranks", [2, 8])
+def test_err_option_on_emulated_ranks(nranks):
+    """-err on several ranks (loopback communicator, see test_multi_rank_run_on_one_gpu): every rank
+    integrates its own zones, the squared error is all-reduced; must match the single-rank value."""
+    import threading
+    from laghos_amd import host_lib
+    args = ["-p", 1, "-dim", 3, "-nx", 8, "-ny", 8, "-nz", 8, "-rs", 0, "-ok", 2, "-ot", 1, "-pa", "-E0", 0.25, "-tf", 0.05, "-q"]
+    ref = host_lib.Sim(args)
+    while ref.step() == 1:
+        pass
+    want = ref.sedov_error()
+    ref.close()
+    assert want > 0
+    cid = (b"LGHLOCAL" + os.urandom(16).hex().encode()).ljust(128, b"\0")
+    out, err = {}, {}
+
+    def rank_main(rank):
+        try:
+            sim = host_lib.Sim(args, nranks=nranks, rank=rank, nccl_id=cid)
+            while sim.step() == 1:
+                pass
+            out[rank] = sim.sedov_error()
+            sim.close()
+        except Exception as ex:  # noqa: BLE001 - reported below
+            err[rank] = repr(ex)
+
+    threads = [threading.Thread(target=rank_main, args=(r,), daemon=True) for r in range(nranks)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=240)
+    assert not any(t.is_alive() for t in threads), "a rank did not finish (collective mismatch?)"
+    assert not err, err
+    for r in range(nranks):
+        assert abs(out[r] - want) <= 1e-9 * want, (r, out[r], want)
