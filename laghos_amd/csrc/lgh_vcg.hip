@@ -699,7 +699,7 @@ __global__ void __launch_bounds__(256)
 vcg_init_k(const VcgArgs a)
 {
    __shared__ double red[16];
-   const int n = blockIdx.x * blockDim.x + threadIdx.x;
+   const int n = xcd_swizzle(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x; // as K2 and vcg_init_force_k
    double part[kVC] = {0.0, 0.0, 0.0};
    if (n < a.N)
    {
@@ -753,7 +753,7 @@ __global__ void __launch_bounds__(256)
 vcg_init_force_k(const VcgArgs a, const double *__restrict__ FE, const int ND, double *__restrict__ bout)
 {
    __shared__ double red[16];
-   const int n = blockIdx.x * blockDim.x + threadIdx.x; // block order of vcg_init_k: same partial sums
+   const int n = xcd_swizzle(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x; // node ranges of vcg_init_k: same partial sums
    double part[kVC] = {0.0, 0.0, 0.0};
    if (n < a.N)
    {

@@ -107,13 +107,20 @@ def test_q3q2_sedov_vs_oracle():
     assert r["steps"] == o["steps"]
 
 
-def test_overlapped_energy_solve_is_bit_identical():
-    """lgh_solve_energy_begin/_end (energy solve on a second stream while the velocity
-    solve runs; active when the region timers are off) must give exactly the state of
-    the sequential SolveVelocity -> SolveEnergy order: same kernels, same reductions."""
+@pytest.mark.parametrize("kw", [dict(mesh="cube01_hex", rs=2, order_v=3, order_e=2, problem=1),
+                                dict(mesh="cube01_hex", rs=2, order_v=2, order_e=1, problem=0),
+                                dict(mesh="box01_hex", rs=1, order_v=2, order_e=1, problem=3),
+                                dict(mesh="cube01_hex", rs=1, order_v=1, order_e=0, problem=1),
+                                dict(mesh="cube01_hex", rs=1, order_v=4, order_e=3, problem=1)],
+                         ids=["sedov-q3q2", "tg-q2q1", "triple-q2q1", "sedov-q1q0", "sedov-q4q3"])
+def test_overlapped_energy_solve_is_bit_identical(kw):
+    """With the region timers off the hot path takes its fused / overlapped forms: the energy
+    solve on a second stream while the velocity solve runs (lgh_solve_energy_begin/_end) and the
+    E->L sum of F.1, negation, EliminateRHS, dv = 0 and CG initialisation in one kernel
+    (vcg_init_force_k).  Both must give exactly the state of the sequential
+    SolveVelocity -> SolveEnergy order with separate kernels: same sums in the same order."""
     from laghos_amd.hydro import run
     from oracle.fem import Problem
-    kw = dict(mesh="cube01_hex", rs=2, order_v=3, order_e=2, problem=1)
     seq = run(Problem(**kw), t_final=0.6, max_steps=12, timers=True)
     ovl = run(Problem(**kw), t_final=0.6, max_steps=12, timers=False)
     assert (seq["steps"], seq["ti"]) == (ovl["steps"], ovl["ti"])
