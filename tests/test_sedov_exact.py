@@ -108,3 +108,31 @@ def test_density_projection_and_error_integral_oracle():
     sol.set_time(1e-12)
     assert se.density_error(prob, S0, rho, sol, [0, 0, 0], se.err_order(2, 1)) < 1e-6
     h.close()
+
+
+@pytest.mark.parametrize("case", CASES, ids=[f"dim{c['dim']}-g{c['gamma']:.3f}-t{c['t']}" for c in CASES])
+def test_library_host_entries_reproduce_reference_values(case):
+    """lgh_sedov_setup / _shock / _eval_point are the host-side scalar API of the reference's SedovSol
+    class (constructor, SetTime, EvalSol): pure host code in liblaghos_hip.so, so they are checked
+    here without a GPU (the array evaluation on the GPU and the error integral: test_gpu_sedov.py)."""
+    from laghos_amd import context as C
+    par = C.sedov_setup(case["dim"], case["gamma"], case["rho0"], case["blast_energy"])
+    assert close_to(par, case["par"], 2e-15)
+    assert close_to(C.sedov_shock(par, case["t"]), case["shock"], 2e-15)
+    got = np.array([C.sedov_eval_point(par, case["t"], r) for r in case["r"]])
+    for i, key in enumerate(("rho", "v", "P")):
+        assert close_to(got[:, i], case[key], 1e-12, shock_r=case["shock"][0], r=case["r"]), key
+
+
+def test_library_rejects_what_the_reference_cannot_do():
+    """omega != 0: the reference's own set-up returns NaN or does not terminate (its header says
+    "currently only supports uniform initial density"); the library refuses it."""
+    from laghos_amd import _lib
+    L = _lib.load()
+    par = np.zeros(21)
+    p = par.ctypes.data_as(_lib.c_dbl_p)
+    assert L.lgh_sedov_setup(3, 1.4, 1.0, 1.0, 0.5, p) == 2          # LGH_ERR_UNSUPPORTED
+    assert b"omega" in L.lgh_last_error()
+    assert L.lgh_sedov_setup(4, 1.4, 1.0, 1.0, 0.0, p) == 1          # LGH_ERR_ARG
+    assert L.lgh_sedov_setup(3, 1.0, 1.0, 1.0, 0.0, p) == 1
+    assert L.lgh_sedov_setup(3, 1.4, 1.0, 1.0, 0.0, p) == 0 and par[20] > 0
