@@ -164,54 +164,50 @@ constexpr int kHaloSlack = 4; // doubles of room behind every neighbour's block 
 // piggy-backed scalars - so every neighbour is ONE send and ONE recv.
 // pos[j] = base_k + i for entry j = off_k + i of the concatenated node lists;
 // cnt[j] = cnt_k.
+// nextra > 0: the first n_nbr*nextra threads also put the piggy-backed scalars behind every
+// neighbour's node block.
 __global__ void __launch_bounds__(256)
 halo_pack_k(const int total, const int ncomp, const int N, const int *__restrict__ nodes,
             const int *__restrict__ pos, const int *__restrict__ cnt, const double *__restrict__ v,
-            double *__restrict__ buf)
+            double *__restrict__ buf, const int n_nbr, const int nextra, const int *__restrict__ base,
+            const int *__restrict__ ncnt, const double *__restrict__ extra)
 {
    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+   if (i < n_nbr * nextra)
+   {
+      const int k = i / nextra, e = i - k * nextra;
+      buf[(size_t)base[k] + (size_t)ncomp * ncnt[k] + e] = extra[e];
+   }
    if (i >= total * ncomp) { return; }
    const int c = i / total, j = i - c * total;
    buf[(size_t)pos[j] + (size_t)c * cnt[j]] = v[(size_t)c * N + nodes[j]];
-}
-__global__ void halo_pack_extra_k(const int n_nbr, const int nextra, const int ncomp, const int *__restrict__ base,
-                                  const int *__restrict__ ncnt, const double *__restrict__ extra,
-                                  double *__restrict__ buf)
-{
-   const int i = threadIdx.x;
-   if (i >= n_nbr * nextra) { return; }
-   const int k = i / nextra, e = i - k * nextra;
-   buf[(size_t)base[k] + (size_t)ncomp * ncnt[k] + e] = extra[e];
-}
-// sum of the piggy-backed scalars over all ranks in ascending rank order (own value at
-// its rank's position): bit-identical on every rank
-__global__ void halo_reduce_extra_k(const int nranks, const int nextra, const int ncomp,
-                                    const int *__restrict__ rank_src, const int *__restrict__ base,
-                                    const int *__restrict__ ncnt, const double *__restrict__ buf,
-                                    double *__restrict__ extra)
-{
-   const int e = threadIdx.x;
-   if (e >= nextra) { return; }
-   double s = 0.0;
-   for (int r = 0; r < nranks; r++)
-   {
-      const int k = rank_src[r];
-      const double val = (k < 0) ? extra[e] : buf[(size_t)base[k] + (size_t)ncomp * ncnt[k] + e];
-      s = (r == 0) ? val : s + val;
-   }
-   extra[e] = s;
 }
 // Canonical sum of a shared node: contributions are added in ascending rank
 // order (own value at its rank's position), so every rank holding the node
 // computes bit-identical results, as MFEM's GroupCommunicator does.  CSR over the
 // unique shared nodes; src >= 0: entry j of the concatenated lists, -1: own value.
+// nextra > 0: threads e < nextra of the launch also sum the piggy-backed scalars over all ranks in
+// ascending rank order (own value at its rank's position): bit-identical on every rank.
 __global__ void __launch_bounds__(256)
 halo_combine_k(const int n_shared, const int ncomp, const int N, const int *__restrict__ sh_node,
                const int *__restrict__ sh_off, const int *__restrict__ sh_src,
                const int *__restrict__ pos, const int *__restrict__ cnt,
-               const double *__restrict__ buf, double *__restrict__ v)
+               const double *__restrict__ buf, double *__restrict__ v, const int nranks, const int nextra,
+               const int *__restrict__ rank_src, const int *__restrict__ base, const int *__restrict__ ncnt,
+               double *__restrict__ extra)
 {
    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+   if (i < nextra)
+   {
+      double s = 0.0;
+      for (int r = 0; r < nranks; r++)
+      {
+         const int k = rank_src[r];
+         const double val = (k < 0) ? extra[i] : buf[(size_t)base[k] + (size_t)ncomp * ncnt[k] + i];
+         s = (r == 0) ? val : s + val;
+      }
+      extra[i] = s;
+   }
    if (i >= n_shared * ncomp) { return; }
    const int c = i / n_shared, u = i - c * n_shared;
    const int node = sh_node[u];
@@ -242,20 +238,13 @@ int halo_sum(lgh_ctx *c, double *v, int ncomp, double *extra, int nextra)
    const int nx = extra ? nextra : 0;
    const int tot = cm->total;
    hipLaunchKernelGGL(halo_pack_k, dim3(ceil_div((long)tot * ncomp, 256)), dim3(256), 0, c->stream, tot,
-                      ncomp, c->N, cm->nodes, cm->pos, cm->cnt, v, cm->sendbuf);
+                      ncomp, c->N, cm->nodes, cm->pos, cm->cnt, v, cm->sendbuf, cm->n_nbr, nx, cm->d_base, cm->d_cnt,
+                      extra);
    LGH_HIP_CHECK(hipGetLastError());
-   if (nx)
-   {
-      hipLaunchKernelGGL(halo_pack_extra_k, dim3(1), dim3(128), 0, c->stream, cm->n_nbr, nx, ncomp, cm->d_base,
-                         cm->d_cnt, extra, cm->sendbuf);
-      LGH_HIP_CHECK(hipGetLastError());
-   }
-   auto reduce_extra = [&]() {
-      if (nx)
-      {
-         hipLaunchKernelGGL(halo_reduce_extra_k, dim3(1), dim3(64), 0, c->stream, c->nranks, nx, ncomp, cm->rank_src,
-                            cm->d_base, cm->d_cnt, cm->recvbuf, extra);
-      }
+   auto combine = [&]() {
+      hipLaunchKernelGGL(halo_combine_k, dim3(ceil_div((long)cm->n_shared * ncomp, 256)), dim3(256), 0,
+                         c->stream, cm->n_shared, ncomp, c->N, cm->sh_node, cm->sh_off, cm->sh_src, cm->pos,
+                         cm->cnt, cm->recvbuf, v, c->nranks, nx, cm->rank_src, cm->d_base, cm->d_cnt, extra);
    };
    if (cm->local)
    {
@@ -277,10 +266,7 @@ int halo_sum(lgh_ctx *c, double *v, int ncomp, double *extra, int nextra)
       }
       LGH_HIP_CHECK(hipStreamSynchronize(c->stream));
       if (!g->barrier()) { set_error("local communicator: barrier timed out (halo)"); return LGH_ERR_COMM; } // peers may repack
-      hipLaunchKernelGGL(halo_combine_k, dim3(ceil_div((long)cm->n_shared * ncomp, 256)), dim3(256), 0,
-                         c->stream, cm->n_shared, ncomp, c->N, cm->sh_node, cm->sh_off, cm->sh_src, cm->pos,
-                         cm->cnt, cm->recvbuf, v);
-      reduce_extra();
+      combine();
       LGH_HIP_CHECK(hipGetLastError());
       return LGH_OK;
    }
@@ -293,10 +279,7 @@ int halo_sum(lgh_ctx *c, double *v, int ncomp, double *extra, int nextra)
       LGH_NCCL_CHECK(g_nccl.Recv(cm->recvbuf + o, n, ncclFloat64, cm->nbr_rank[k], cm->comm, c->stream));
    }
    LGH_NCCL_CHECK(g_nccl.GroupEnd());
-   hipLaunchKernelGGL(halo_combine_k, dim3(ceil_div((long)cm->n_shared * ncomp, 256)), dim3(256), 0,
-                      c->stream, cm->n_shared, ncomp, c->N, cm->sh_node, cm->sh_off, cm->sh_src, cm->pos,
-                      cm->cnt, cm->recvbuf, v);
-   reduce_extra();
+   combine();
    LGH_HIP_CHECK(hipGetLastError());
    return LGH_OK;
 }
@@ -571,7 +554,7 @@ int lgh_test_halo_pack(lgh_ctx *c, const double *v, int ncomp, double *out)
    Comm *cm = c->comm;
    if (cm->total == 0) { return LGH_OK; }
    hipLaunchKernelGGL(halo_pack_k, dim3(ceil_div((long)cm->total * ncomp, 256)), dim3(256), 0, c->stream,
-                      cm->total, ncomp, c->N, cm->nodes, cm->pos, cm->cnt, v, cm->sendbuf);
+                      cm->total, ncomp, c->N, cm->nodes, cm->pos, cm->cnt, v, cm->sendbuf, 0, 0, nullptr, nullptr, nullptr);
    LGH_HIP_CHECK(hipGetLastError());
    LGH_HIP_CHECK(hipMemcpyAsync(out, cm->sendbuf, (size_t)cm->bufsize * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
    return LGH_OK;
@@ -584,7 +567,7 @@ int lgh_test_halo_combine(lgh_ctx *c, const double *in, double *v, int ncomp)
    LGH_HIP_CHECK(hipMemcpyAsync(cm->recvbuf, in, (size_t)cm->bufsize * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
    hipLaunchKernelGGL(halo_combine_k, dim3(ceil_div((long)cm->n_shared * ncomp, 256)), dim3(256), 0, c->stream,
                       cm->n_shared, ncomp, c->N, cm->sh_node, cm->sh_off, cm->sh_src, cm->pos, cm->cnt,
-                      cm->recvbuf, v);
+                      cm->recvbuf, v, c->nranks, 0, nullptr, nullptr, nullptr, nullptr);
    LGH_HIP_CHECK(hipGetLastError());
    return LGH_OK;
 }
