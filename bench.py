@@ -167,7 +167,7 @@ def main():
     value = 1e-6 * dofs * 4 * rk_steps / wall
 
     out = {
-        "metric": "Mdofs*steps/s on 3D Sedov -pa (Q3/Q2)", "value": value, "unit": "Mdofs*steps/s",
+        "metric": "Mdofs\u00d7steps/s on 3D Sedov -pa (Q3/Q2)", "value": value, "unit": "Mdofs*steps/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * wall / a.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
         "data": "synthetic",
