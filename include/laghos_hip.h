@@ -239,6 +239,9 @@ int lgh_mass_apply_E(lgh_ctx *ctx, int space, const double *x_E, double *y_E);
 int lgh_test_set_rank(lgh_ctx *ctx, int nranks, int rank);
 int lgh_test_halo_pack(lgh_ctx *ctx, const double *v_h1, int ncomp, double *sendbuf_out);
 int lgh_test_halo_combine(lgh_ctx *ctx, const double *recvbuf_in, double *v_h1, int ncomp);
+/* grouped ncclSend / ncclRecv of n doubles from this rank to itself on the RCCL communicator (what
+ * halo_sum does with its neighbours); *max_abs_diff = max |received - sent| */
+int lgh_test_rccl_self_sendrecv(lgh_ctx *ctx, int n, double *max_abs_diff);
 /* device small-matrix probes: n matrices (column-major, 9 or 4 doubles each) */
 int lgh_test_eig(lgh_ctx *ctx, int dim, int n, const double *A, double *lambda, double *vec);
 int lgh_test_singular(lgh_ctx *ctx, int dim, int n, const double *A, double *sv_min);

@@ -95,6 +95,7 @@ SYMBOLS = {
     "lgh_test_set_rank": (_I, [_P, _I, _I]),
     "lgh_test_halo_pack": (_I, [_P, _P, _I, _P]),
     "lgh_test_halo_combine": (_I, [_P, _P, _P, _I]),
+    "lgh_test_rccl_self_sendrecv": (_I, [_P, _I, c_dbl_p]),
     "lgh_test_eig": (_I, [_P, _I, _I, _P, _P, _P]),
     "lgh_test_singular": (_I, [_P, _I, _I, _P, _P]),
 }

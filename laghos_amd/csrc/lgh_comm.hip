@@ -15,6 +15,7 @@
 // loads on a host without RCCL (and reuses torch's copy when already loaded).
 #include <dlfcn.h>
 #include <cstdlib>
+#include <cmath>
 
 #include <algorithm>
 #include <chrono>
@@ -569,6 +570,35 @@ int lgh_test_halo_combine(lgh_ctx *c, const double *in, double *v, int ncomp)
                       cm->n_shared, ncomp, c->N, cm->sh_node, cm->sh_off, cm->sh_src, cm->pos, cm->cnt,
                       cm->recvbuf, v, c->nranks, 0, nullptr, nullptr, nullptr, nullptr);
    LGH_HIP_CHECK(hipGetLastError());
+   return LGH_OK;
+}
+
+// Probe of the transport used by halo_sum on the REAL communicator (not the loopback one):
+// a grouped ncclSend / ncclRecv of n doubles from this rank to itself, the only
+// peer a one-GPU box offers.  *max_abs_diff = max |received - sent|.
+int lgh_test_rccl_self_sendrecv(lgh_ctx *c, int n, double *max_abs_diff)
+{
+   LGH_CHECK_ARG(c && c->comm && c->comm->comm && !c->comm->local && n > 0 && max_abs_diff);
+   double *buf = nullptr;
+   LGH_HIP_CHECK(hipMalloc((void **)&buf, 2 * (size_t)n * sizeof(double)));
+   std::vector<double> h(2 * (size_t)n, 0.0);
+   for (int i = 0; i < n; i++) { h[i] = 1.0 + 0.5 * i; }
+   LGH_HIP_CHECK(hipMemcpy(buf, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
+   int rc = LGH_OK;
+   if (g_nccl.GroupStart() != ncclSuccess || g_nccl.Send(buf, (size_t)n, ncclFloat64, c->rank, c->comm->comm, c->stream) != ncclSuccess ||
+       g_nccl.Recv(buf + n, (size_t)n, ncclFloat64, c->rank, c->comm->comm, c->stream) != ncclSuccess ||
+       g_nccl.GroupEnd() != ncclSuccess)
+   {
+      set_error("RCCL self send/recv failed");
+      rc = LGH_ERR_COMM;
+   }
+   if (rc == LGH_OK && hipStreamSynchronize(c->stream) != hipSuccess) { rc = LGH_ERR_HIP; }
+   if (rc == LGH_OK && hipMemcpy(h.data(), buf, h.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) { rc = LGH_ERR_HIP; }
+   (void)hipFree(buf);
+   if (rc) { return rc; }
+   double d = 0.0;
+   for (int i = 0; i < n; i++) { d = std::max(d, std::fabs(h[(size_t)n + i] - h[i])); }
+   *max_abs_diff = d;
    return LGH_OK;
 }
 

@@ -308,6 +308,25 @@ def test_multi_rank_code_path_on_one_gpu():
     assert abs(a["t"] - b["t"]) / a["t"] < 1e-10
 
 
+def test_rccl_grouped_send_recv_on_this_gpu():
+    """The halo transport on real RCCL: grouped ncclSend / ncclRecv on the communicator the
+    library creates (size 1 under LGH_FORCE_MULTI=1 - the only peer a one-GPU box has is the
+    rank itself).  The pack / combine logic around it is covered with emulated ranks below."""
+    import os
+    import subprocess
+    import sys
+    code = ("import ctypes; from laghos_amd import host_lib, _lib; "
+            "s=host_lib.Sim(['-p',1,'-m','data/cube01_hex.mesh','-rs',1,'-ok',2,'-ot',1,'-ms',1,'-q']); "
+            "d=ctypes.c_double(-1.0); "
+            "rc=_lib.load().lgh_test_rccl_self_sendrecv(ctypes.c_void_p(s.L.laghos_sim_context(s.h)), 4097, ctypes.byref(d)); "
+            "print('RESULT', rc, d.value)")
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, LGH_FORCE_MULTI="1"),
+                       cwd=".", timeout=300)
+    assert p.returncode == 0, (p.stdout[-800:], p.stderr[-1500:])
+    line = next(l for l in p.stdout.splitlines() if l.startswith("RESULT"))
+    assert line.split()[1:] == ["0", "0.0"], line
+
+
 @pytest.mark.parametrize("pgrid", [[2, 1, 1], [2, 2, 2]])
 def test_halo_logic_emulated_ranks(pgrid):
     """The shared-node sum of the element-sharded path, with the RCCL transport
