@@ -153,7 +153,7 @@ struct VcgArgs
    const double *dinv, *owner;
    const double *b;       // kVC*N right-hand sides (byNODES)
    double *x;             // kVC*N solutions
-   double *r, *z, *d;     // kVC*N each
+   double *r, *d;         // kVC*N each (z = r/diag is recomputed where it is used)
    double *YE;            // kVC * NE*ND
    size_t ye_stride;      // NE*ND
    double *yL;            // kVC*N (unfused path)
@@ -1062,8 +1062,8 @@ int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
    {
       LGH_HIP_CHECK(hipMalloc((void **)&c->vcg_s, sizeof(VcgScalars)));
       LGH_HIP_CHECK(hipMemset(c->vcg_s, 0, sizeof(VcgScalars)));
-      LGH_HIP_CHECK(hipMalloc((void **)&c->vcg_vec, 4 * kVC * N * sizeof(double))); // r, z, d, yL
-      LGH_HIP_CHECK(hipMemset(c->vcg_vec, 0, 4 * kVC * N * sizeof(double)));
+      LGH_HIP_CHECK(hipMalloc((void **)&c->vcg_vec, 3 * kVC * N * sizeof(double))); // r, d, yL (z = r/diag is never stored)
+      LGH_HIP_CHECK(hipMemset(c->vcg_vec, 0, 3 * kVC * N * sizeof(double)));
       c->vcg_stride = (unsigned)(std::max<size_t>((size_t)c->NE, (N + 255) / 256) + kShards);
       LGH_HIP_CHECK(hipMalloc((void **)&c->vcg_partials, 2 * kVC * (size_t)c->vcg_stride * sizeof(double)));
       LGH_HIP_CHECK(hipMemset(c->vcg_partials, 0, 2 * kVC * (size_t)c->vcg_stride * sizeof(double)));
@@ -1089,9 +1089,8 @@ int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
    a.b = B;
    a.x = X;
    a.r = c->vcg_vec;
-   a.z = c->vcg_vec + kVC * N;
-   a.d = c->vcg_vec + 2 * kVC * N;
-   a.yL = c->vcg_vec + 3 * kVC * N;
+   a.d = c->vcg_vec + kVC * N;
+   a.yL = c->vcg_vec + 2 * kVC * N;
    a.YE = c->YE;
    a.ye_stride = (size_t)c->NE * c->ND;
    a.s = ds;
