@@ -234,16 +234,20 @@ int halo_sum(lgh_ctx *c, double *v, int ncomp, double *extra, int nextra)
 {
    Comm *cm = c->comm;
    if (!cm || cm->n_nbr == 0) { return LGH_OK; }
-   if (ncomp > 3) { set_error("halo_sum: ncomp > 3"); return LGH_ERR_ARG; }
+   if (ncomp > 3 || ncomp < 0 || (ncomp == 0 && !extra)) { set_error("halo_sum: bad ncomp"); return LGH_ERR_ARG; }
    if (extra && (!cm->allpairs || nextra < 1 || nextra > 3)) { set_error("halo_sum: cannot piggy-back"); return LGH_ERR_ARG; }
    const int nx = extra ? nextra : 0;
    const int tot = cm->total;
-   hipLaunchKernelGGL(halo_pack_k, dim3(ceil_div((long)tot * ncomp, 256)), dim3(256), 0, c->stream, tot,
+   // ncomp == 0 (v unused): the messages carry the scalars only - a sum over the ranks as one
+   // exchange with every peer (allreduce_dev uses it in all-pairs partitions)
+   const long npack = std::max((long)tot * ncomp, (long)cm->n_nbr * nx);
+   hipLaunchKernelGGL(halo_pack_k, dim3(ceil_div(npack, 256)), dim3(256), 0, c->stream, tot,
                       ncomp, c->N, cm->nodes, cm->pos, cm->cnt, v, cm->sendbuf, cm->n_nbr, nx, cm->d_base, cm->d_cnt,
                       extra);
    LGH_HIP_CHECK(hipGetLastError());
    auto combine = [&]() {
-      hipLaunchKernelGGL(halo_combine_k, dim3(ceil_div((long)cm->n_shared * ncomp, 256)), dim3(256), 0,
+      const long ncomb = std::max((long)cm->n_shared * ncomp, (long)nx);
+      hipLaunchKernelGGL(halo_combine_k, dim3(ceil_div(ncomb, 256)), dim3(256), 0,
                          c->stream, cm->n_shared, ncomp, c->N, cm->sh_node, cm->sh_off, cm->sh_src, cm->pos,
                          cm->cnt, cm->recvbuf, v, c->nranks, nx, cm->rank_src, cm->d_base, cm->d_cnt, extra);
    };
@@ -296,6 +300,13 @@ void comm_shared_nodes(const lgh_ctx *c, const uint8_t **hmask, const int **sh_n
 int allreduce_dev(lgh_ctx *c, double *dev, int count, int op)
 {
    Comm *cm = c->comm;
+   // Sums of up to three scalars in an all-pairs partition (the CG dot products on <= 2x2x2 ranks):
+   // one grouped exchange with every peer and a sum in rank order, the transport of the halo
+   // messages, instead of a ring / tree all-reduce - one hop, bit-identical on every rank.
+   if (op == 0 && count >= 1 && count <= 3 && cm && cm->n_nbr > 0 && halo_can_piggyback(c))
+   {
+      return halo_sum(c, nullptr, 0, dev, count);
+   }
    if (cm && cm->local)
    {
       LocalGroup *g = cm->local.get();
