@@ -30,6 +30,15 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def flush_c_stdio():
+    """RCCL writes its version banner through C stdio; push it out so that it cannot land behind
+    the JSON line when stdout is a pipe."""
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+
+
 def block_grid(n):
     """ranks -> (px,py,pz) of 32^3-element blocks (same rule as laghos::Partition)"""
     p = [1, 1, 1]
@@ -139,6 +148,7 @@ def main():
     args += ["-p", 1, "-ok", 3, "-ot", 2, "-pa", "-tf", 1e9, "-ms", a.warmup + a.steps + 64, "-vs", 10 ** 9,
              "-dev", local_rank, "-q"]
     sim = host_lib.Sim(args, nranks=world, rank=rank, nccl_id=nccl_id)
+    flush_c_stdio()  # RCCL's banner (C stdio) out now, on every rank, not at process exit after the JSON line
     sim.enable_timers(False)  # region stopwatches synchronise; keep them out of the timed loop
     sz = sim.sizes()
 
@@ -251,11 +261,16 @@ def main():
         except Exception as e:  # the checker is optional for the measurement
             out["cpu_baseline"] = {"error": repr(e)}
     sim.close()
+    flush_c_stdio()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out))
+        # RCCL writes its version banner through C stdio: flush that first so that the JSON line is
+        # the last line of stdout
+        flush_c_stdio()
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
