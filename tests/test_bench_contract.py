@@ -50,3 +50,17 @@ def test_profiled_run_agrees_with_the_plain_run():
     a, b = _line("r1_bench.json"), _line("r1_bench_under_rocprofv3.json")
     assert a["config"]["workload"] == b["config"]["workload"]
     assert 0.8 * a["value"] < b["value"] <= 1.05 * a["value"]
+
+
+def test_weak_scaling_layout_of_the_bench():
+    """N ranks keep 32^3 elements each in a block grid whose ranks are all neighbours of each other
+    up to N = 8 (the partitions for which the CG sums ride on the halo exchange)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert [tuple(bench.block_grid(n)) for n in (1, 2, 4, 8)] == [(1, 1, 1), (2, 1, 1), (2, 2, 1), (2, 2, 2)]
+    for n in (1, 2, 3, 4, 6, 8):
+        px, py, pz = bench.block_grid(n)
+        assert px * py * pz == n
+    assert bench.usable_cpus() >= 1
