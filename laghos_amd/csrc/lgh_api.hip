@@ -305,6 +305,7 @@ int lgh_destroy(lgh_ctx *c)
       delete c->ktime;
    }
    cg_l2_free(c);
+   pcg_free(c);
    if (c->stream2)
    {
       (void)hipStreamSynchronize(c->stream2);
@@ -555,7 +556,9 @@ int lgh_solve_energy(lgh_ctx *c, const double *S, const double *v_h1, double *dS
 static bool energy_overlap_ok(const lgh_ctx *c)
 {
    static const bool on = !(getenv("LGH_OVERLAP") && getenv("LGH_OVERLAP")[0] == '0');
-   return on && c->multi == 0 && !c->timers.enabled && !(c->ktime && c->ktime->which >= 0) && vcg_available(c);
+   // the persistent solve kernel (lgh_pcg.hip) needs all its workgroups resident: nothing runs beside it
+   return on && c->multi == 0 && !c->timers.enabled && !(c->ktime && c->ktime->which >= 0) && vcg_available(c) &&
+          !pcg_available(c);
 }
 int lgh_solve_energy_begin(lgh_ctx *c, const double *S, const double *v_h1, double *dS_dt, double *e_rhs,
                            const double *e_source, double rel_tol, int max_iter)
@@ -706,6 +709,14 @@ int lgh_ktime_end(lgh_ctx *c, int *launches, double *mean_seconds)
    *launches = k->n;
    *mean_seconds = k->n ? tot / k->n : 0.0;
    k->which = -1;
+   return LGH_OK;
+}
+
+int lgh_pcg_iterations(lgh_ctx *c, long *iterations)
+{
+   LGH_CHECK_ARG(c && iterations);
+   *iterations = c->pcg_iterations;
+   c->pcg_iterations = 0;
    return LGH_OK;
 }
 

@@ -129,6 +129,8 @@ struct lgh_ctx
    int vcg_last;
    int vcg_grid;         // persistent grid size of the K1 kernel (one resident wave)
    int vcg_variant;      // LGH_VCG_VARIANT: which K1 form vcg_solve launches (lgh_vcg.hip)
+   void *pcg;            // state of the persistent solve kernel (lgh_pcg.hip), allocated on first use
+   long pcg_iterations;  // loop trips of the persistent solve kernel since lgh_pcg_iterations()
 
    lgh::Timers timers;
    lgh::KTime *ktime;
@@ -321,6 +323,10 @@ int mass_assemble_diag(lgh_ctx *c);
 int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, int iters[3],
               const double *force_E = nullptr);
 bool vcg_fused_init_ok(const lgh_ctx *c);
+bool pcg_available(const lgh_ctx *c);
+int pcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, int iters[3],
+              const double *force_E);
+void pcg_free(lgh_ctx *c);
 bool vcg_available(const lgh_ctx *c);
 // multi-rank: flags / list of the nodes shared with other ranks (nullptr / 0 without neighbours)
 void comm_shared_nodes(const lgh_ctx *c, const uint8_t **hmask, const int **sh_node, int *n_shared);

@@ -466,7 +466,8 @@ vcg_apply_plane(const VcgArgs a, const int nbatch)
 
    const int tid = threadIdx.x;
    unsigned long long t_start = 0, t_loop = 0;
-   if (a.trace) { t_start = wall_clock64(); }
+   unsigned long long c_start = 0;
+   if (a.trace) { t_start = wall_clock64(); c_start = clock64(); }
    const int eb = tid / TE, lt = tid - eb * TE;
    const int c = lt / Q, qx = lt - c * Q;
    const int G = gridDim.x;
@@ -690,7 +691,7 @@ vcg_apply_plane(const VcgArgs a, const int nbatch)
       a.trace[4 * blockIdx.x + 0] = t_start;
       a.trace[4 * blockIdx.x + 1] = t_loop;
       a.trace[4 * blockIdx.x + 2] = wall_clock64();
-      a.trace[4 * blockIdx.x + 3] = ((unsigned long long)xcc << 32) | hwid;
+      a.trace[4 * blockIdx.x + 3] = clock64() - c_start; // shader cycles between the two wall-clock stamps 0 and 2
    }
 }
 
@@ -1055,6 +1056,8 @@ bool vcg_fused_init_ok(const lgh_ctx *c)
 int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, int iters[3], const double *force_E)
 {
    if (!vcg_supported(c)) { return LGH_ERR_UNSUPPORTED; }
+   // one rank: the whole solve is one persistent kernel (lgh_pcg.hip)
+   if (pcg_available(c)) { return pcg_solve(c, B, X, rel_tol, max_iter, iters, force_E); }
    const bool multi = c->multi != 0;
    const size_t N = (size_t)c->N;
    int rc;
@@ -1062,8 +1065,11 @@ int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
    {
       LGH_HIP_CHECK(hipMalloc((void **)&c->vcg_s, sizeof(VcgScalars)));
       LGH_HIP_CHECK(hipMemset(c->vcg_s, 0, sizeof(VcgScalars)));
-      LGH_HIP_CHECK(hipMalloc((void **)&c->vcg_vec, 3 * kVC * N * sizeof(double))); // r, d, yL (z = r/diag is never stored)
-      LGH_HIP_CHECK(hipMemset(c->vcg_vec, 0, 3 * kVC * N * sizeof(double)));
+      if (!c->vcg_vec)
+      {
+         LGH_HIP_CHECK(hipMalloc((void **)&c->vcg_vec, 3 * kVC * N * sizeof(double))); // r, d, yL (z = r/diag is never stored)
+         LGH_HIP_CHECK(hipMemset(c->vcg_vec, 0, 3 * kVC * N * sizeof(double)));
+      }
       c->vcg_stride = (unsigned)(std::max<size_t>((size_t)c->NE, (N + 255) / 256) + kShards);
       LGH_HIP_CHECK(hipMalloc((void **)&c->vcg_partials, 2 * kVC * (size_t)c->vcg_stride * sizeof(double)));
       LGH_HIP_CHECK(hipMemset(c->vcg_partials, 0, 2 * kVC * (size_t)c->vcg_stride * sizeof(double)));
