@@ -114,11 +114,27 @@ class Context:
     def empty(self, n):
         return torch.empty(int(n), dtype=torch.float64, device=self.device)
 
+    # The library works on its own (non-blocking) HIP stream; torch fills tensors on torch's current
+    # stream.  A tensor handed to the library must be complete first, so the helpers that WRITE device
+    # memory through torch wait for torch's stream before they return (empty() writes nothing).
+    def _torch_done(self):
+        torch.cuda.current_stream(self.device).synchronize()
+
     def zeros(self, n):
-        return torch.zeros(int(n), dtype=torch.float64, device=self.device)
+        t = torch.zeros(int(n), dtype=torch.float64, device=self.device)
+        self._torch_done()
+        return t
 
     def to_dev(self, a):
-        return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64)).to(self.device)
+        t = torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64)).to(self.device)
+        self._torch_done()
+        return t
+
+    def clone(self, t):
+        """torch clone of a device tensor, complete before the library may touch it"""
+        c = t.clone()
+        self._torch_done()
+        return c
 
     def sync(self):
         check(self.lib.lgh_sync(self.h))

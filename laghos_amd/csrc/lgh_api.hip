@@ -151,6 +151,8 @@ extern "C"
 const char *lgh_last_error(void) { return g_err; }
 const char *lgh_version(void) { return "laghos_hip 0.1 (gfx950)"; }
 
+static int create_impl(const lgh_config *cfg, lgh_ctx *c, const int kid);
+
 int lgh_create(const lgh_config *cfg, lgh_ctx **out)
 {
    LGH_CHECK_ARG(cfg && out);
@@ -176,10 +178,37 @@ int lgh_create(const lgh_config *cfg, lgh_ctx **out)
       return LGH_ERR_HIP;
    }
    LGH_HIP_CHECK(hipSetDevice(cfg->device));
+   // argument errors a caller can trigger are found before anything is allocated
+   for (size_t i = 0, n = (size_t)cfg->NE * (cfg->dim == 2 ? cfg->D1D * cfg->D1D : cfg->D1D * cfg->D1D * cfg->D1D); i < n; i++)
+   {
+      if (cfg->h1_map[i] < 0 || cfg->h1_map[i] >= cfg->N) { set_error("h1_map entry out of range"); return LGH_ERR_ARG; }
+   }
+   for (int k = 0; k < cfg->dim; k++)
+   {
+      LGH_CHECK_ARG(cfg->ess_count[k] >= 0 && (cfg->ess_count[k] == 0 || cfg->ess[k]));
+      for (int i = 0; i < cfg->ess_count[k]; i++)
+      {
+         if (cfg->ess[k][i] < 0 || cfg->ess[k][i] >= cfg->N) { set_error("essential dof out of range"); return LGH_ERR_ARG; }
+      }
+   }
 
    lgh_ctx *c = new lgh_ctx();
    memset((void *)c, 0, sizeof(lgh_ctx));
    new (&c->timers) Timers();
+   c->device = cfg->device;
+   // every failure below (HIP errors, out of memory) releases what was built so far
+   const int rc_create = create_impl(cfg, c, kid);
+   if (rc_create != LGH_OK)
+   {
+      lgh_destroy(c);
+      return rc_create;
+   }
+   *out = c;
+   return LGH_OK;
+}
+
+static int create_impl(const lgh_config *cfg, lgh_ctx *c, const int kid)
+{
    c->dim = cfg->dim; c->NE = cfg->NE; c->D1D = cfg->D1D; c->Q1D = cfg->Q1D; c->L1D = cfg->L1D;
    const int dim = c->dim;
    c->ND = dim == 2 ? c->D1D * c->D1D : c->D1D * c->D1D * c->D1D;
@@ -280,7 +309,6 @@ int lgh_create(const lgh_config *cfg, lgh_ctx **out)
    const double inf = std::numeric_limits<double>::infinity();
    LGH_HIP_CHECK(hipMemcpy(c->dt_est_dev, &inf, sizeof(double), hipMemcpyHostToDevice));
 #undef LGH_TRY
-   *out = c;
    return LGH_OK;
 }
 

@@ -435,6 +435,19 @@ int lgh_comm_set_neighbors(lgh_ctx *c, int n_nbr, const int *nbr_rank, const int
    LGH_CHECK_ARG(c && n_nbr >= 0);
    if (!c->comm) { c->comm = new Comm(); }
    Comm *cm = c->comm;
+   std::vector<int> rs((size_t)std::max(c->nranks, 1), -2);
+   // Everything that can fail locally (argument checks, allocations) runs first and its status is folded
+   // into the collective below: a rank that fails must not leave its peers blocked in the all-reduce.
+   const int rc_local = [&]() -> int {
+   LGH_CHECK_ARG(n_nbr == 0 || (nbr_rank && nbr_count && nbr_nodes));
+   for (int k = 0; k < n_nbr; k++)
+   {
+      LGH_CHECK_ARG(nbr_count[k] >= 0 && (nbr_count[k] == 0 || nbr_nodes[k]));
+      for (int i = 0; i < nbr_count[k]; i++)
+      {
+         if (nbr_nodes[k][i] < 0 || nbr_nodes[k][i] >= c->N) { set_error("neighbour node out of range"); return LGH_ERR_ARG; }
+      }
+   }
    cm->n_nbr = n_nbr;
    cm->nbr_rank.assign(nbr_rank, nbr_rank + n_nbr);
    cm->nbr_count.assign(nbr_count, nbr_count + n_nbr);
@@ -523,7 +536,7 @@ int lgh_comm_set_neighbors(lgh_ctx *c, int n_nbr, const int *nbr_rank, const int
       // per-neighbour tables and the rank -> neighbour map of the piggy-backed scalars
       void *old[] = {cm->d_base, cm->d_cnt, cm->rank_src};
       for (void *p : old) { if (p) { (void)hipFree(p); } }
-      std::vector<int> rs((size_t)std::max(c->nranks, 1), -2);
+      cm->d_base = cm->d_cnt = cm->rank_src = nullptr;
       rs[c->rank] = -1;
       for (int k = 0; k < n_nbr; k++)
       {
@@ -531,15 +544,25 @@ int lgh_comm_set_neighbors(lgh_ctx *c, int n_nbr, const int *nbr_rank, const int
       }
       cm->allpairs = (n_nbr > 0 && n_nbr == c->nranks - 1);
       for (int r : rs) { if (r == -2) { cm->allpairs = false; } }
-      // the message sizes depend on it: every rank must come to the same decision
-      // (in a 3x1x1 partition only the middle rank sees all others)
-      if (c->multi != 0 && (cm->comm || cm->local))
+   }
+   return LGH_OK;
+   }();
+   // the message sizes depend on it: every rank must come to the same decision (in a 3x1x1 partition
+   // only the middle rank sees all others); a local failure travels in the same MIN-reduction
+   if (c->multi != 0 && (cm->comm || cm->local))
+   {
+      double flag = rc_local ? -1.0 : (cm->allpairs ? 1.0 : 0.0);
+      const int rc = lgh_allreduce(c, &flag, 1);
+      if (rc) { return rc; }
+      if (flag < 0.0)
       {
-         double flag = cm->allpairs ? 1.0 : 0.0;
-         const int rc = lgh_allreduce(c, &flag, 1);
-         if (rc) { return rc; }
-         cm->allpairs = (flag > 0.5);
+         if (!rc_local) { set_error("lgh_comm_set_neighbors failed on another rank"); }
+         return rc_local ? rc_local : LGH_ERR_COMM;
       }
+      cm->allpairs = (flag > 0.5);
+   }
+   else if (rc_local) { return rc_local; }
+   {
       LGH_HIP_CHECK(hipMalloc((void **)&cm->d_base, std::max<size_t>(n_nbr, 1) * sizeof(int)));
       LGH_HIP_CHECK(hipMalloc((void **)&cm->d_cnt, std::max<size_t>(n_nbr, 1) * sizeof(int)));
       LGH_HIP_CHECK(hipMalloc((void **)&cm->rank_src, rs.size() * sizeof(int)));

@@ -219,6 +219,21 @@ __device__ __forceinline__ double block_min(double v, double *red)
 // a shard arrives on the top counter; the last of those owns the final fold.
 // Counters are reset by their last arrivers, so a slot is reusable by the next
 // launch on the stream.
+//
+// Memory ordering.  The partial is published with a relaxed agent-scope 8-byte atomic store (sc1:
+// write-through, nothing left in this XCD's L2), then `s_waitcnt vmcnt(0)` completes it before the ticket
+// is taken; the last arriver reads the partials with relaxed agent-scope 8-byte atomic loads (sc1: served
+// past the L1, and never stale in an L2 - the L2s snoop write-through traffic).  That is the "8-byte agent
+// atomics on both sides" form of MI355X_MICROARCH.md / cdna_hip_programming.md Guideline 16; it holds by
+// the behaviour of gfx9-family vmcnt (which counts stores) and sc1, not by the C++ memory model.  The
+// model-conforming form - a RELEASE fetch_add by the producers and an ACQUIRE one by the last block - costs
+// an L2 write-back (buffer_wbl2) per workgroup on gfx950, microseconds for each of the thousands of blocks
+// of the node kernels whose vector stores are still dirty in the L2; it is not used.  The guard below keeps
+// this file from being built for a target where the argument does not hold (vmcnt does not count stores from
+// gfx10 on).
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__) && !defined(__gfx90a__)
+#error "lgh_common.hpp: the grid reductions rely on gfx9-family vmcnt / sc1 semantics (see comment)"
+#endif
 constexpr unsigned kShards = 64;
 constexpr unsigned kTicketStride = 32;                               // uints: 128 B apart
 constexpr unsigned kTicketSlot = (kShards + 1) * kTicketStride;      // uints per reduction slot

@@ -720,18 +720,20 @@ cg_update_k(const CgVecArgs a)
       }
    }
 }
+// (several ranks) a finished solve leaves rz = den = 0: the exchanges of the launches the host enqueued past
+// convergence then sum zeros instead of multiplying the global values by the number of ranks each time
 __global__ void cg_update_finish_k(CgScalars *s, int iter)
 {
-   if (s->done) { return; }
+   if (s->done) { s->rz = 0.0; s->den = 0.0; return; }
    s->iters = iter;
-   if (s->rz < 0.0 || s->rz <= s->r0) { s->done = 1; }
+   if (s->rz < 0.0 || s->rz <= s->r0) { s->done = 1; s->rz = 0.0; s->den = 0.0; }
 }
 
 // In multi-GPU runs a rank-local `done` can only be set from all-reduced values,
 // so every rank takes identical decisions.
 __global__ void cg_den_finish_k(CgScalars *s)
 {
-   if (s->done) { return; }
+   if (s->done) { s->den = 0.0; return; }
    if (s->den == 0.0) { s->done = 1; }
 }
 

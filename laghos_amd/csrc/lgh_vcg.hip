@@ -827,11 +827,18 @@ __global__ void vcg_set_tol_k(VcgScalars *s, double rel_tol2)
    s->first = 1;
    for (int c = 0; c < kVC; c++) { s->done[c] = 0; s->iters[c] = 0; }
 }
+// Several ranks: the host enqueues the iteration count of the previous solve without looking at the flags,
+// so a few launches may follow convergence.  Their kernels return at once, but the exchanges between them
+// still run and would re-sum the (already global) den / rz of a finished component once per surplus
+// iteration - growing by the number of ranks each time, to inf after a long solve.  The finish kernels
+// therefore zero the scalars of finished components: sums of zeros stay zero.  den[c] and rz[c] are
+// undefined (0) once done[c] is set; nothing reads them after that.
 __global__ void vcg_den_finish_k(VcgScalars *s)
 {
    for (int c = 0; c < kVC; c++)
    {
       if (!s->done[c] && s->den[c] == 0.0) { s->done[c] = 1; }
+      if (s->done[c]) { s->den[c] = 0.0; }
    }
 }
 __global__ void vcg_update_finish_k(VcgScalars *s, int iter)
@@ -844,6 +851,7 @@ __global__ void vcg_update_finish_k(VcgScalars *s, int iter)
          s->iters[c] = iter;
          if (s->rz[c] < 0.0 || s->rz[c] <= s->r0[c]) { s->done[c] = 1; }
       }
+      if (s->done[c]) { s->rz[c] = 0.0; s->den[c] = 0.0; } // see vcg_den_finish_k
       all = all && s->done[c];
    }
    s->all_done = all;

@@ -9,7 +9,10 @@
 // (laghos_sim_*) that bench.py drives through ctypes.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
+#include <fstream>
+#include <sys/stat.h>
 #include <iomanip>
 #include <iostream>
 #include <limits>
@@ -42,6 +45,8 @@ struct Options
    int vis_steps = 5;
    bool check = false, fom = false, impose_visc = false;
    bool check_exact_sedov = false; // -err (laghos.cpp:262)
+   bool gfprint = false;           // -print (laghos.cpp:283-285)
+   std::string basename = "results/Laghos"; // -k (laghos.cpp:286-287)
    int dev = 0;
    // multi-rank (set by the launcher, not the reference CLI)
    int nranks = 1, rank = 0;
@@ -87,6 +92,8 @@ bool ParseArgs(int argc, const char *const *argv, Options &o, std::string &err)
       if (a == "-no-err" || a == "--no-exact-error") { o.check_exact_sedov = false; continue; }
       if (a == "-no-fom" || a == "--no-fom") { o.fom = false; continue; }
       if (a == "-q" || a == "--quiet") { o.quiet = true; continue; }
+      if (a == "-print" || a == "--print") { o.gfprint = true; continue; }
+      if (a == "-k" || a == "--outputfilename") { if (!(v = need(i))) { return false; } o.basename = v; continue; }
       if (a == "-d" || a == "--device") { if (!need(i)) { return false; } continue; } // always the HIP path
       if (a == "-no-vis" || a == "--no-visualization" || a == "-no-visit" || a == "-no-print") { continue; }
       err = "unsupported option: " + a;
@@ -136,6 +143,78 @@ bool CheckNorm(int dim, int problem, int ti, double nrm, int &chk)
 }
 
 } // namespace
+
+// `-print` (laghos.cpp:873-900): basename_<ti>_{mesh,rho,v,e}, 8 significant digits as the
+// reference's ofs.precision(8).  The reference writes MFEM's mesh / grid-function text formats in MFEM's
+// global dof numbering (PrintAsOne / SaveAsOne); MFEM is not part of this repo, so the files carry the
+// same header structure and the same fields but THIS library's numbering: H1 nodes lexicographic over
+// the Cartesian node grid (x fastest), vector fields byNODES (Ordering: 0), L2 dofs zone by zone in
+// lexicographic Bernstein order.  On several ranks every rank writes its block to <name>.<rank>.
+bool WriteFields(const std::string &basename, int ti, const Discretization &d, int nranks, int rank,
+                 const std::vector<double> &S, const std::vector<double> &rho)
+{
+   const size_t slash = basename.find_last_of('/');
+   if (slash != std::string::npos)
+   {
+      // create the directory chain of the base name (the reference leaves that to the user)
+      const std::string dir = basename.substr(0, slash);
+      for (size_t p = 1; p <= dir.size(); p++)
+      {
+         if (p == dir.size() || dir[p] == '/') { (void)::mkdir(dir.substr(0, p).c_str(), 0777); }
+      }
+   }
+   auto name = [&](const char *what) {
+      std::ostringstream os;
+      os << basename << "_" << ti << "_" << what;
+      if (nranks > 1) { os << "." << rank; }
+      return os.str();
+   };
+   const int dim = d.dim, ok = d.tab.D1D - 1, ot = d.tab.L1D - 1;
+   const long H1V = (long)dim * d.N;
+   auto header = [&](std::ofstream &f, const char *fec, int order, int vdim) {
+      f << "FiniteElementSpace\nFiniteElementCollection: " << fec << "_" << dim << "D_P" << order << "\nVDim: " << vdim
+        << "\nOrdering: 0\n\n";
+   };
+   {
+      std::ofstream f(name("mesh").c_str());
+      if (!f) { return false; }
+      f.precision(8);
+      f << "LGH mesh v1.0\n\n# structured " << (dim == 3 ? "hexahedral" : "quadrilateral")
+        << " zones; node ids of a zone in lexicographic order of its (order+1)^dim H1 nodes\n\ndimension\n" << dim
+        << "\n\nelements\n" << d.NE << "\n";
+      for (int e = 0; e < d.NE; e++)
+      {
+         f << 1 << " " << (dim == 3 ? 5 : 3);
+         for (int k = 0; k < d.ND; k++) { f << " " << d.h1map[(size_t)e * d.ND + k]; }
+         f << "\n";
+      }
+      f << "\nnodes\n";
+      header(f, "H1", ok, dim);
+      for (long i = 0; i < H1V; i++) { f << S[i] << "\n"; }
+   }
+   {
+      std::ofstream f(name("rho").c_str());
+      if (!f) { return false; }
+      f.precision(8);
+      header(f, "L2_T2", ot, 1); // positive (Bernstein) basis, as the reference's l2_fec
+      for (double v : rho) { f << v << "\n"; }
+   }
+   {
+      std::ofstream f(name("v").c_str());
+      if (!f) { return false; }
+      f.precision(8);
+      header(f, "H1", ok, dim);
+      for (long i = 0; i < H1V; i++) { f << S[H1V + i] << "\n"; }
+   }
+   {
+      std::ofstream f(name("e").c_str());
+      if (!f) { return false; }
+      f.precision(8);
+      header(f, "L2_T2", ot, 1);
+      for (size_t i = 2 * H1V; i < S.size(); i++) { f << S[i] << "\n"; }
+   }
+   return true;
+}
 
 // ---- simulation object driven by main() and by bench.py ------------------------------------
 struct laghos_sim
@@ -226,9 +305,10 @@ laghos_sim *laghos_sim_create(int argc, const char *const *argv, int nranks, int
       case 2: s->ode.reset(new RK2Solver(0.5)); break;
       case 3: s->ode.reset(new RK3SSPSolver); break;
       case 4: s->ode.reset(new RK4Solver); break;
+      case 6: s->ode.reset(new RK6Solver); break;
       case 7: s->ode.reset(new RK2AvgSolver); break;
       default:
-         std::fprintf(stderr, "Unknown / unsupported ODE solver type: %d (1 = Forward Euler, 2 = RK2, 3 = RK3 SSP, 4 = RK4, 7 = RK2Avg)\n", o.ode_solver_type);
+         std::fprintf(stderr, "Unknown ODE solver type: %d\n", o.ode_solver_type); // laghos.cpp:527-531
          return nullptr;
    }
    s->S.FromHost(S0);
@@ -297,6 +377,21 @@ int laghos_sim_step(laghos_sim *s)
                       << ",\t|e| = " << std::setprecision(10) << std::scientific << sqrt_norm;
             std::cout << std::fixed << std::endl;
          }
+         if (o.gfprint) // laghos.cpp:873-900
+         {
+            std::vector<double> Sh, rhoh;
+            Vector rho;
+            hydro.ComputeDensity(s->S, rho); // laghos.cpp:827-830 (rho_gf is refreshed before the output)
+            hydro.Sync();
+            s->S.ToHost(Sh);
+            rho.ToHost(rhoh);
+            if (!WriteFields(o.basename, s->ti, *s->disc, o.nranks, o.rank, Sh, rhoh))
+            {
+               s->error = "cannot write the -print files under " + o.basename;
+               std::fprintf(stderr, "%s\n", s->error.c_str());
+               return -1;
+            }
+         }
       }
       if (o.check)
       {
@@ -355,6 +450,27 @@ void laghos_sim_sizes(laghos_sim *s, long *out)
    out[0] = d.dim; out[1] = d.NE; out[2] = d.global_NE; out[3] = d.N;
    out[4] = s->hydro->GlobalH1Size(); out[5] = s->hydro->GlobalL2Size();
    out[6] = d.NQ; out[7] = d.tab.D1D; out[8] = d.tab.Q1D; out[9] = d.tab.L1D;
+   for (int a = 0; a < 3; a++)
+   {
+      out[10 + a] = d.part.pgrid[a];               // process grid
+      out[13 + a] = a < d.dim ? d.part.ne[a] : 1;  // local zones per axis
+   }
+}
+// host-only: the process grid Partition picks for an nx x ny x nz zone grid on nranks ranks
+// (bench.py derives its weak-scaling mesh from it); returns 0, or -1 if the grid cannot be split evenly
+int laghos_host_partition(int dim, int nx, int ny, int nz, int nranks, int *pgrid)
+{
+   try
+   {
+      CartMesh m = CartMesh::Cartesian(dim, nx, ny, nz, 1.0, 1.0, 1.0);
+      Partition p(m, nranks, 0);
+      for (int a = 0; a < 3; a++) { pgrid[a] = p.pgrid[a]; }
+      return 0;
+   }
+   catch (const std::exception &)
+   {
+      return -1;
+   }
 }
 void *laghos_sim_context(laghos_sim *s) { return s->hydro->Context(); }
 long laghos_sim_state_size(laghos_sim *s) { return s->S.Size(); }

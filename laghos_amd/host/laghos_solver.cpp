@@ -394,6 +394,81 @@ void RK4Solver::Step(Vector &S, double &t, double &dt)
    t += dt;
 }
 
+void ExplicitRKSolver::Init(hydrodynamics::LagrangianHydroOperator &op)
+{
+   ODESolver::Init(op);
+   y.SetSize(op.Size());
+   k.resize(s);
+   for (int i = 0; i < s; i++) { k[i].SetSize(op.Size()); }
+}
+void ExplicitRKSolver::Step(Vector &S, double &t, double &dt)
+{
+   //   0     |
+   //  c[0]   | a[0]
+   //  c[1]   | a[1] a[2]
+   //  ...    |    ...
+   //  c[s-2] | ...   a[s(s-1)/2-1]
+   // --------+---------------------
+   //         | b[0] b[1] ... b[s-1]          (same order of operations as upstream's Step)
+   f->Mult(S, k[0]);
+   for (int l = 0, i = 1; i < s; i++)
+   {
+      f->Add(y, 1.0, S, a[l++] * dt, k[0]);
+      for (int j = 1; j < i; j++) { f->Add(y, 1.0, y, a[l++] * dt, k[j]); }
+      f->Mult(y, k[i]); // the operator has no explicit time dependence (c unused, as f->SetTime upstream)
+   }
+   for (int i = 0; i < s; i++) { f->Add(S, 1.0, S, b[i] * dt, k[i]); }
+   t += dt;
+}
+// upstream RK6Solver (Verner); the coefficients satisfy the order conditions through order 6 to 1e-30
+// (checked in tests/test_host_setup.py)
+const double RK6Solver::a[] = {
+   .6e-1,
+   .1923996296296296296296296296296296296296e-1,
+   .7669337037037037037037037037037037037037e-1,
+   .35975e-1,
+   0.,
+   .107925,
+   1.318683415233148260919747276431735612861,
+   0.,
+   -5.042058063628562225427761634715637693344,
+   4.220674648395413964508014358284402080483,
+   -41.87259166432751461803757780644346812905,
+   0.,
+   159.4325621631374917700365669070346830453,
+   -122.1192135650100309202516203389242140663,
+   5.531743066200053768252631238332999150076,
+   -54.43015693531650433250642051294142461271,
+   0.,
+   207.0672513650184644273657173866509835987,
+   -158.6108137845899991828742424365058599469,
+   6.991816585950242321992597280791793907096,
+   -.1859723106220323397765171799549294623692e-1,
+   -54.66374178728197680241215648050386959351,
+   0.,
+   207.9528062553893734515824816699834244238,
+   -159.2889574744995071508959805871426654216,
+   7.018743740796944434698170760964252490817,
+   -.1833878590504572306472782005141738268361e-1,
+   -.5119484997882099077875432497245168395840e-3};
+const double RK6Solver::b[] = {
+   .3438957868357036009278820124728322386520e-1,
+   0.,
+   0.,
+   .2582624555633503404659558098586120858767,
+   .4209371189673537150642551514069801967032,
+   4.405396469669310170148836816197095664891,
+   -176.4831190242986576151740942499002125029,
+   172.3641334014150730294022582711902413315};
+const double RK6Solver::c[] = {
+   .6e-1,
+   .9593333333333333333333333333333333333333e-1,
+   .1439,
+   .4973,
+   .9725,
+   .9995,
+   1.};
+
 void RK2AvgSolver::Init(hydrodynamics::LagrangianHydroOperator &op)
 {
    ODESolver::Init(op);

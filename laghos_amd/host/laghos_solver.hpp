@@ -156,6 +156,29 @@ public:
    int Stages() const override { return 4; }
 };
 
+// upstream ExplicitRKSolver: s stages, Butcher tableau (a strictly lower triangular by rows, b, c),
+// and RK6Solver (laghos.cpp:525): Verner's 8-stage 6th-order method with upstream's coefficients
+class ExplicitRKSolver : public ODESolver
+{
+   int s;
+   const double *a, *b, *c;
+   Vector y;
+   std::vector<Vector> k;
+
+public:
+   ExplicitRKSolver(int s_, const double *a_, const double *b_, const double *c_) : s(s_), a(a_), b(b_), c(c_) {}
+   void Init(hydrodynamics::LagrangianHydroOperator &op) override;
+   void Step(Vector &S, double &t, double &dt) override;
+   int Stages() const override { return s; }
+};
+class RK6Solver : public ExplicitRKSolver
+{
+   static const double a[28], b[8], c[7];
+
+public:
+   RK6Solver() : ExplicitRKSolver(8, a, b, c) {}
+};
+
 // energy-conserving midpoint scheme (laghos_solver.cpp:1436-1487)
 class RK2AvgSolver : public ODESolver
 {

@@ -53,6 +53,8 @@ def load():
         L.laghos_sim_get_state.argtypes = [P, P]
         L.laghos_main.restype = I
         L.laghos_main.argtypes = [I, ctypes.POINTER(ctypes.c_char_p)]
+        L.laghos_host_partition.restype = I
+        L.laghos_host_partition.argtypes = [I, I, I, I, I, ctypes.POINTER(I)]
         L.laghos_host_tables.restype = I
         L.laghos_host_tables.argtypes = [I, I, P, P, P, P, P, P]
         L.laghos_host_disc_create.restype = P
@@ -130,16 +132,28 @@ class Sim:
         return dict(cgH1=t[0], cgL2=t[1], force=t[2], qdata=t[3], H1iter=c[0], L2iter=c[1], quad_tstep=c[2])
 
     def sizes(self):
-        s = (ctypes.c_long * 10)()
+        s = (ctypes.c_long * 16)()
         self.L.laghos_sim_sizes(self.h, s)
         keys = ["dim", "NE", "global_NE", "N", "H1GTV", "L2GTV", "NQ", "D1D", "Q1D", "L1D"]
-        return dict(zip(keys, list(s)))
+        out = dict(zip(keys, list(s)[:10]))
+        out["pgrid"] = tuple(s[10:13])      # process grid of laghos::Partition
+        out["local_ne"] = tuple(s[13:16])   # zones of this rank per axis
+        return out
 
     def state(self):
         n = self.L.laghos_sim_state_size(self.h)
         out = np.empty(n)
         self.L.laghos_sim_get_state(self.h, out.ctypes.data)
         return out
+
+
+def host_partition(dim, nx, ny, nz, nranks):
+    """Process grid laghos::Partition picks for an nx x ny x nz zone grid (None: not evenly divisible)."""
+    L = load()
+    pg = (ctypes.c_int * 3)()
+    if L.laghos_host_partition(dim, nx, ny, nz, nranks, pg) != 0:
+        return None
+    return tuple(pg)
 
 
 def host_tables(order_v, order_e):

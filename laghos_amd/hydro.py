@@ -33,7 +33,7 @@ class HydroOperator:
             ctx.comm_init(comm["nranks"], comm["rank"], comm["unique_id"])
             ctx.comm_set_neighbors(comm["nbr_rank"], comm["nbr_nodes"])
         self.S0 = ctx.to_dev(S)
-        x0 = self.S0[:prob.H1V].clone()
+        x0 = ctx.clone(self.S0[:prob.H1V])
         vol = ctx.setup_rho0detj0(x0, ctx.to_dev(rho_l2), ctx.to_dev(rho0_q))
         ne = float(prob.NE)
         if multi:
@@ -44,6 +44,7 @@ class HydroOperator:
         ctx.set_h0(self.h0)
         # scratch (laghos_solver.cpp:158-164): one, rhs, e_rhs, B
         self.one = torch.ones(prob.L2V, dtype=torch.float64, device=ctx.device)
+        torch.cuda.current_stream(ctx.device).synchronize()  # torch-stream fill complete before the library reads it
         self.rhs = ctx.zeros(prob.H1V)
         self.e_rhs = ctx.zeros(prob.L2V)
         self.work = ctx.zeros(prob.N)
@@ -169,6 +170,50 @@ def rk3ssp_step(hydro, S, t, dt, work):
     return t + dt
 
 
+
+# upstream RK6Solver (laghos.cpp:525): Verner's 8-stage 6th-order method, upstream's coefficients; the
+# order conditions through order 6 hold to 1e-30 (tests/test_host_setup.py)
+RK6_A = [
+    .6e-1,
+    .1923996296296296296296296296296296296296e-1, .7669337037037037037037037037037037037037e-1,
+    .35975e-1, 0., .107925,
+    1.318683415233148260919747276431735612861, 0., -5.042058063628562225427761634715637693344,
+    4.220674648395413964508014358284402080483,
+    -41.87259166432751461803757780644346812905, 0., 159.4325621631374917700365669070346830453,
+    -122.1192135650100309202516203389242140663, 5.531743066200053768252631238332999150076,
+    -54.43015693531650433250642051294142461271, 0., 207.0672513650184644273657173866509835987,
+    -158.6108137845899991828742424365058599469, 6.991816585950242321992597280791793907096,
+    -.1859723106220323397765171799549294623692e-1,
+    -54.66374178728197680241215648050386959351, 0., 207.9528062553893734515824816699834244238,
+    -159.2889574744995071508959805871426654216, 7.018743740796944434698170760964252490817,
+    -.1833878590504572306472782005141738268361e-1, -.5119484997882099077875432497245168395840e-3]
+RK6_B = [
+    .3438957868357036009278820124728322386520e-1, 0., 0., .2582624555633503404659558098586120858767,
+    .4209371189673537150642551514069801967032, 4.405396469669310170148836816197095664891,
+    -176.4831190242986576151740942499002125029, 172.3641334014150730294022582711902413315]
+
+
+def rk6_step(hydro, S, t, dt, work):
+    """upstream ExplicitRKSolver::Step with the RK6Solver tableau (same order of operations)"""
+    ctx = hydro.ctx
+    if getattr(hydro, "_rk6_k", None) is None or hydro._rk6_k[0].numel() != S.numel():
+        hydro._rk6_k = [torch.empty_like(S) for _ in range(8)]
+        torch.cuda.synchronize()
+    k, y = hydro._rk6_k, work[1]
+    hydro.mult(S, k[0])
+    l = 0
+    for i in range(1, 8):
+        ctx.vec_axpby(y, 1.0, S, RK6_A[l] * dt, k[0])
+        l += 1
+        for j in range(1, i):
+            ctx.vec_axpby(y, 1.0, y, RK6_A[l] * dt, k[j])
+            l += 1
+        hydro.mult(y, k[i])
+    for i in range(8):
+        ctx.vec_axpby(S, 1.0, S, RK6_B[i] * dt, k[i])
+    return t + dt
+
+
 def rk2avg_step(hydro, S, t, dt, work):
     """RK2AvgSolver::Step (laghos_solver.cpp:1447-1487): two SolveVelocity /
     SolveEnergy sub-steps, the energy one with the half-step average velocity V."""
@@ -198,9 +243,9 @@ class TimeLoop:
     """laghos.cpp:706-778 as a resumable object (bench.py steps it K times)."""
 
     def __init__(self, hydro, t_final=0.6, max_steps=-1, ode_solver=4):
-        steppers = {1: rk1_step, 2: rk2_step, 3: rk3ssp_step, 4: rk4_step, 7: rk2avg_step}
+        steppers = {1: rk1_step, 2: rk2_step, 3: rk3ssp_step, 4: rk4_step, 6: rk6_step, 7: rk2avg_step}
         if ode_solver not in steppers:
-            raise ValueError("ode_solver: 1 (Euler), 2 (RK2), 3 (RK3 SSP), 4 (RK4) or 7 (RK2Avg)")
+            raise ValueError("ode_solver: 1 (Euler), 2 (RK2), 3 (RK3 SSP), 4 (RK4), 6 (RK6) or 7 (RK2Avg)")
         self.stepper = steppers[ode_solver]
         self.h = hydro
         self.t_final, self.max_steps = t_final, max_steps

@@ -70,10 +70,11 @@ def test_readme_runs_on_gpu(golden, name):
     assert abs(r["e_norm"] - g["e_norm"]) / g["e_norm"] < 1e-9, (r["e_norm"], g["e_norm"])
 
 
-@pytest.mark.parametrize("ode", [1, 2, 3])
+@pytest.mark.parametrize("ode", [1, 2, 3, 6])
 def test_other_rk_integrators_vs_oracle(ode):
-    """-s 1 / 2 / 3 (ForwardEuler, RK2(0.5), RK3SSP; laghos.cpp:521-523): no published values exist
-    for them, so HIP path vs oracle on a short 2D Sedov run, and the C++ driver vs both."""
+    """-s 1 / 2 / 3 / 6 (ForwardEuler, RK2(0.5), RK3SSP, RK6; laghos.cpp:521-525): no published values
+    exist for them, so HIP path vs oracle on a short 2D Sedov run, and the C++ driver vs both.  (RK6: Verner's
+    tableau has weights of +-176, which amplify the round-off differences of the two paths.)"""
     from laghos_amd import host_lib
     from laghos_amd.hydro import run
     from oracle.driver import run as orun
@@ -81,9 +82,10 @@ def test_other_rk_integrators_vs_oracle(ode):
     kw = dict(mesh="square01_quad", rs=2, problem=1)
     r = run(Problem(**kw), t_final=0.6, max_steps=12, ode_solver=ode, probe_steps=(12,))
     o = orun(Problem(**kw), t_final=0.6, max_steps=12, ode_solver=ode, probe_steps=(12,))
-    assert r["steps"] == o["steps"]
-    assert abs(r["probes"][12] - o["probes"][12]) / o["probes"][12] < 1e-9
-    assert rel_err(r["S"], o["S"]) < 1e-8
+    assert (r["steps"], r["repeats"]) == (o["steps"], o["repeats"])
+    if 12 in o["probes"]:  # (a run that repeats steps does not reach the 12th accepted step in 12 RK steps)
+        assert abs(r["probes"][12] - o["probes"][12]) / o["probes"][12] < (1e-9 if ode != 6 else 1e-7)
+    assert rel_err(r["S"], o["S"]) < (1e-8 if ode != 6 else 1e-6)
     sim = host_lib.Sim(["-p", 1, "-m", "data/square01_quad.mesh", "-rs", 2, "-ms", 12, "-tf", 0.6, "-s", ode, "-q"])
     while sim.step() == 1:
         pass
@@ -461,3 +463,40 @@ def test_multi_rank_run_on_one_gpu(nranks, nel, problem):
         assert (got["rk"], got["ti"]) == (want["rk"], want["ti"]), (r, got, want)
         assert abs(got["dt"] - want["dt"]) <= 1e-12 * want["dt"], (r, got, want)
         assert abs(got["e"] - want["e"]) <= 1e-10 * want["e"], (r, got, want)
+
+
+def test_cpp_driver_print_dumps(tmp_path):
+    """`-print -k <basename>` (laghos.cpp:873-900): basename_<ti>_{mesh,rho,v,e} at every visualisation
+    step and at the last one, 8 significant digits; v and e are the blocks of the state vector, the nodes
+    of the mesh file its position block."""
+    from laghos_amd import host_lib
+    base = tmp_path / "out" / "Laghos"
+    sim = host_lib.Sim(["-p", 1, "-m", "data/cube01_hex.mesh", "-rs", 1, "-ok", 2, "-ot", 1, "-ms", 3, "-vs", 2, "-tf", 0.6,
+                        "-print", "-k", str(base), "-q"])
+    while sim.step() == 1:
+        pass
+    S, last = sim.state(), sim.ti
+    sz = sim.sizes()
+    sim.close()
+    tis = sorted({int(p.name.split("_")[1]) for p in base.parent.glob("Laghos_*_v")})
+    assert 2 in tis and last in tis
+    for ti in tis:
+        for what in ("mesh", "rho", "v", "e"):
+            assert (base.parent / f"Laghos_{ti}_{what}").exists()
+    H1V = 3 * sz["N"]
+
+    def values(path, header_lines):
+        txt = path.read_text().split("\n\n")
+        return txt[0], np.array([float(x) for x in txt[-1].split()])
+    head, v = values(base.parent / f"Laghos_{last}_v", 5)
+    assert "FiniteElementCollection: H1_3D_P2" in head and "VDim: 3" in head and "Ordering: 0" in head
+    assert v.size == H1V and np.allclose(v, S[H1V:2 * H1V], rtol=1e-7, atol=1e-300)
+    head, e = values(base.parent / f"Laghos_{last}_e", 5)
+    assert "FiniteElementCollection: L2_T2_3D_P1" in head
+    assert e.size == S.size - 2 * H1V and np.allclose(e, S[2 * H1V:], rtol=1e-7, atol=1e-300)
+    head, rho = values(base.parent / f"Laghos_{last}_rho", 5)
+    assert rho.size == e.size and rho.min() > 0
+    mesh = (base.parent / f"Laghos_{last}_mesh").read_text()
+    assert mesh.startswith("LGH mesh v1.0") and f"elements\n{sz['NE']}\n" in mesh
+    x = np.array([float(t) for t in mesh.split("\n\n")[-1].split()])
+    assert x.size == H1V and np.allclose(x, S[:H1V], rtol=1e-7, atol=1e-12)

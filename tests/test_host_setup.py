@@ -74,3 +74,70 @@ def test_partition(nranks):
                      pgrid={2: [2, 1, 1], 4: [2, 2, 1], 8: [2, 2, 2]}[nranks])
         assert np.array_equal(d["h1map"], pr.h1map.reshape(-1))
         assert np.array_equal(d["owner"], pr.owner)
+
+
+def test_bench_block_grid_is_the_partition_of_the_library():
+    """bench.py derives its weak-scaling mesh from a Python mirror of laghos::Partition: the mirror must be
+    the C++ code (any zone grid, any rank count), and the block grid bench.py reports must be the one the
+    library builds for that mesh - 32^3 zones per rank (N = 6 is 6x1x1, not the 2x3x1 of a cyclic rule)."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for ne in ((32, 32, 32), (64, 96, 32), (24, 36, 60), (7, 9, 11), (64, 64, 64), (128, 32, 32)):
+        for n in range(1, 33):
+            assert bench.partition_grid(ne, n) == host_lib.host_partition(3, ne[0], ne[1], ne[2], n), (ne, n)
+    assert [tuple(bench.block_grid(n)) for n in (1, 2, 4, 8)] == [(1, 1, 1), (2, 1, 1), (2, 2, 1), (2, 2, 2)]
+    for n in range(1, 17):
+        p = bench.block_grid(n)
+        assert p[0] * p[1] * p[2] == n
+        assert host_lib.host_partition(3, 32 * p[0], 32 * p[1], 32 * p[2], n) == tuple(p)
+
+
+def test_rk6_tableau_order_conditions():
+    """`-s 6` (laghos.cpp:525): upstream RK6Solver is Verner's 8-stage 6th-order method.  MFEM is not in the
+    reference tree, so the coefficients are checked by what defines them: row sums = c and the order conditions
+    (all bushy trees and the tall trees through order 6, and the order-3..4 mixed ones) to 1e-28 in exact
+    decimal arithmetic on the source literals; the C++ table, the product's Python driver and the oracle hold
+    the same literals."""
+    import os
+    import re
+    from decimal import Decimal, getcontext
+    getcontext().prec = 60
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "laghos_amd", "host", "laghos_solver.cpp")).read()
+
+    def table(name):
+        body = re.search(r"RK6Solver::%s\[\] = \{(.*?)\};" % name, src, re.S).group(1)
+        return [Decimal(x.strip()) for x in body.replace("\n", " ").split(",") if x.strip()]
+    a, b, c = table("a"), table("b"), [Decimal(0)] + table("c")
+    assert (len(a), len(b), len(c)) == (28, 8, 8)
+    s = 8
+    A = [[Decimal(0)] * s for _ in range(s)]
+    k = 0
+    for i in range(1, s):
+        for j in range(i):
+            A[i][j] = a[k]
+            k += 1
+    dot = lambda u, v: sum(x * y for x, y in zip(u, v))
+    mv = lambda M, v: [dot(M[i], v) for i in range(s)]
+    eps = Decimal("1e-28")
+    for i in range(s):
+        assert abs(sum(A[i]) - c[i]) < eps
+    for p in range(1, 7):  # bushy trees: b . c^(p-1) = 1/p
+        assert abs(dot(b, [x ** (p - 1) if p > 1 else Decimal(1) for x in c]) - Decimal(1) / p) < eps
+    v, fact = c, 1
+    for p in range(2, 7):  # tall trees: b . A^(p-2) c = 1/p!
+        fact *= p
+        assert abs(dot(b, v) - Decimal(1) / fact) < eps
+        v = mv(A, v)
+    c2 = [x * x for x in c]
+    assert abs(dot(b, mv(A, c2)) - Decimal(1) / 12) < eps
+    assert abs(dot(b, [ci * x for ci, x in zip(c, mv(A, c))]) - Decimal(1) / 8) < eps
+    # the same numbers in the two Python drivers
+    from laghos_amd import hydro
+    from oracle import driver
+    for tab in (hydro, driver):
+        assert [float(x) for x in a] == tab.RK6_A and [float(x) for x in b] == tab.RK6_B
