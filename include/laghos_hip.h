@@ -121,6 +121,12 @@ int lgh_cg_solve(lgh_ctx *ctx, int space, const double *b, double *x, double rel
  * E-restriction + reference-gradient + QKernel; updates stressJinvT and folds the
  * point-wise dt estimate into qdata.dt_est (device side, no host sync). */
 int lgh_qupdate(lgh_ctx *ctx, const double *S);
+/* The viscosity branch of QUpdateBody (laghos_solver.cpp:1086-1134) eigen-decomposes sym(grad v) at every
+ * point.  When all 64 points of a wavefront have |sym grad v|_max <= tiny_grad (units 1/time) the kernel takes
+ * the decomposition's own result for a tensor without deviatoric part (mu = tr/3, direction e_x) instead:
+ * identical for exact zeros; for values below the threshold the stress differs by < visc_coeff * tiny_grad.
+ * Default 1e-30 (LGH_Q_TINY_GRAD overrides); 0 = exact zeros only; negative = always decompose. */
+int lgh_qupdate_set_tiny_grad(lgh_ctx *ctx, double tiny_grad);
 
 /* ---- LagrangianHydroOperator pieces kept together for launch efficiency
  * (laghos_solver.cpp:329-399, :442-490).  dS_dt = [dx|dv|de]; one_l2 is the

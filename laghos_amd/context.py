@@ -218,6 +218,9 @@ class Context:
     def qupdate(self, S):
         check(self.lib.lgh_qupdate(self.h, _ptr(S)))
 
+    def qupdate_set_tiny_grad(self, v):
+        check(self.lib.lgh_qupdate_set_tiny_grad(self.h, float(v)))
+
     def solve_velocity(self, S, dS, one, rhs, work, rel_tol, max_iter):
         it = ctypes.c_int(0)
         check(self.lib.lgh_solve_velocity(self.h, _ptr(S), _ptr(dS), _ptr(one), _ptr(rhs), _ptr(work),

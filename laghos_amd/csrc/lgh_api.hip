@@ -222,6 +222,11 @@ static int create_impl(const lgh_config *cfg, lgh_ctx *c, const int kid)
    c->vort = cfg->use_vorticity != 0;
    c->cfl = cfg->cfl;
    c->h1order = (double)cfg->order_v;
+   {
+      // LGH_Q_TINY_GRAD=<value>: default threshold of the QUpdate shortcut; 0: exact zeros only; -1: off
+      const char *env = getenv("LGH_Q_TINY_GRAD");
+      c->q_tiny_grad = env ? atof(env) : 1e-30;
+   }
    c->h0 = 0.0;
    c->device = cfg->device;
    c->cur_ess = -1;
@@ -737,6 +742,13 @@ int lgh_ktime_end(lgh_ctx *c, int *launches, double *mean_seconds)
    *launches = k->n;
    *mean_seconds = k->n ? tot / k->n : 0.0;
    k->which = -1;
+   return LGH_OK;
+}
+
+int lgh_qupdate_set_tiny_grad(lgh_ctx *c, double tiny_grad)
+{
+   LGH_CHECK_ARG(c);
+   c->q_tiny_grad = tiny_grad;
    return LGH_OK;
 }
 

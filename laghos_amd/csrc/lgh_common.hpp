@@ -80,6 +80,7 @@ struct lgh_ctx
    int kid; // (dim<<8)|(D1D<<4)|Q1D, the reference's kernel id
    bool visc, vort;
    double cfl, h0, h1order;
+   double q_tiny_grad;   // QUpdate: threshold of the wave-uniform eigen-decomposition shortcut (lgh_qupdate.hip)
    int device;
    hipStream_t stream;
    // second stream + fork/join events: the energy solve overlaps the velocity solve (lgh_api.hip)

@@ -43,6 +43,7 @@ struct QArgs
    double *result; // dt_est (min-folded) or sum
    double h0, h1order, cfl;
    int visc, vort;
+   double tiny_grad; // wave-uniform shortcut of the eigen-decomposition below this |sym grad v| (see qpoint_body); < 0: off
 };
 
 // Smooth transition between 0 and 1 for x in [-eps, eps] (laghos_solver.cpp:799-805)
@@ -89,7 +90,30 @@ __device__ __forceinline__ double qpoint_body(const QArgs &a, const int e, const
       }
       sm::symmetrize<DIM>(sgrad_v);
       double mu, compr_dir[DIM], Jpi[DIM2], ph_dir[DIM];
-      sm::min_eigenpair<DIM>(sgrad_v, mu, compr_dir);
+      // Zones the flow has not reached carry velocities that are exact zeros or the exponentially small
+      // tails the CG iterations spread from the active region (1e-40 and below), yet every one of their
+      // points runs the full eigen-decomposition - a third of this kernel's instructions.  When EVERY point
+      // of a wavefront has |sym grad v|_max <= tiny_grad (1e-30 by default, in 1/time) the wave takes the
+      // result the decomposition has for a tensor with no deviatoric part: mu = tr/3, direction e_x - for an
+      // exactly zero tensor bit for bit what min_eigenpair returns (its `triple` branch).  For a non-zero
+      // tensor below the threshold only the DIRECTION differs, and it enters through h = h0 |Jpi dir|/|dir|
+      // alone: where the mesh has not deformed (Jpi = I to round-off, which is where such points are) h does
+      // not depend on it, and the stress changes by visc_coeff * 1e-30 at most.  Wave-uniform: no divergence.
+      bool shortcut = false;
+      if (DIM == 3 && a.tiny_grad >= 0.0)
+      {
+         double m = 0.0;
+#pragma unroll
+         for (int k = 0; k < DIM2; k++) { m = fmax(m, fabs(sgrad_v[k])); }
+         shortcut = __all(m <= a.tiny_grad ? 1 : 0) != 0;
+      }
+      if (shortcut)
+      {
+         mu = sm::trace<DIM>(sgrad_v) / 3;
+#pragma unroll
+         for (int d = 0; d < DIM; d++) { compr_dir[d] = (d == 0) ? 1.0 : 0.0; }
+      }
+      else { sm::min_eigenpair<DIM>(sgrad_v, mu, compr_dir); }
       sm::matmul<DIM>(J, J0i, Jpi);
       sm::matvec<DIM>(Jpi, compr_dir, ph_dir);
       const double ph_dir_nl2 = sm::norml2<DIM>(ph_dir);
@@ -531,6 +555,7 @@ static QArgs q_base(lgh_ctx *c)
    a.cfl = c->cfl;
    a.visc = c->visc;
    a.vort = c->vort;
+   a.tiny_grad = c->q_tiny_grad;
    return a;
 }
 

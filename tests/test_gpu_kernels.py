@@ -302,3 +302,47 @@ def test_problem7_vorticity_and_gravity():
     assert rel_err(dS.cpu().numpy(), dS_o) < 1e-9
     g.close()
     o.close()
+
+
+def test_qupdate_shortcut_on_live_sedov_state():
+    """The wave-uniform shortcut of the eigen-decomposition (lgh_qupdate_set_tiny_grad; zones the blast has not
+    reached) on the state it is meant for: 12 real time steps of 3D Sedov Q3Q2 (512 zones), then the QUpdate of
+    that state with the shortcut at its default threshold, restricted to exact zeros, and switched off, and
+    the oracle's.  The three device results must agree to <= 1e-14 of the largest entry (the bar the kernel has
+    against the oracle is 1e-12), the time-step estimates to 1e-14, and the shortcut must have something to do:
+    a part of this state lies below the threshold."""
+    import torch
+    from laghos_amd.hydro import TimeLoop
+    from oracle.fem import Problem
+    prob = Problem(mesh="cube01_hex", rs=2, order_v=3, order_e=2, problem=1)
+    g, o = make_gpu(prob), make_oracle(prob)
+    try:
+        loop = TimeLoop(g, t_final=1e9, max_steps=12)
+        while loop.step():
+            pass
+        S = loop.S
+        out = {}
+        for name, thr in (("default", 1e-30), ("zeros", 0.0), ("off", -1.0)):
+            g.ctx.qupdate_set_tiny_grad(thr)
+            g.reset_time_step_estimate()
+            g.reset_quadrature_data()
+            g.update_quadrature_data(S)
+            out[name] = (g.ctx.stressJinvT.copy(), g.ctx.get_dt_est())
+        g.ctx.qupdate_set_tiny_grad(1e-30)
+        ref, dt_ref = out["off"]
+        for name in ("default", "zeros"):
+            sj, dt = out[name]
+            assert rel_err(sj, ref) <= 1e-14, name
+            assert abs(dt - dt_ref) <= 1e-14 * dt_ref, name
+        Sh = S.cpu().numpy()
+        o.reset_time_step_estimate()
+        o.qdata_is_current = False
+        o.update_quadrature_data(Sh)
+        assert rel_err(out["default"][0], o.stressJinvT) < 1e-12
+        assert abs(out["default"][1] - o.L.lgo_get_dt_est(o.h)) / dt_ref < 1e-12
+        # the state does contain such points (exact zeros and tails of the CG iterations)
+        v = Sh[prob.H1V:2 * prob.H1V]
+        assert np.mean(np.abs(v) <= 1e-30) > 0.02
+    finally:
+        g.close()
+        o.close()
