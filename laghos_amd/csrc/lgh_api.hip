@@ -339,6 +339,7 @@ int lgh_destroy(lgh_ctx *c)
    }
    cg_l2_free(c);
    pcg_free(c);
+   vcg_free(c);
    if (c->stream2)
    {
       (void)hipStreamSynchronize(c->stream2);

@@ -130,6 +130,7 @@ struct lgh_ctx
    int vcg_last;
    int vcg_grid;         // persistent grid size of the K1 kernel (one resident wave)
    int vcg_variant;      // LGH_VCG_VARIANT: which K1 form vcg_solve launches (lgh_vcg.hip)
+   void *vcg_aux;        // tables of the node kernel K2 (lgh_vcg.hip VcgAux), allocated on first use
    void *pcg;            // state of the persistent solve kernel (lgh_pcg.hip), allocated on first use
    long pcg_iterations;  // loop trips of the persistent solve kernel since lgh_pcg_iterations()
 
@@ -343,6 +344,12 @@ bool pcg_available(const lgh_ctx *c);
 int pcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, int iters[3],
               const double *force_E);
 void pcg_free(lgh_ctx *c);
+// tables shared by the node kernels of lgh_vcg.hip and lgh_pcg.hip (built in lgh_pcg.hip)
+int partition_nodes_by_cost(lgh_ctx *c, int W, int **out);
+int make_ellz(lgh_ctx *c, unsigned **out);
+int make_essbits(lgh_ctx *c, uint8_t **out);
+void vcg_free(lgh_ctx *c);
+constexpr int kYePad = 16; // doubles behind every Y_E plane of the CG; the first one (slot NE*ND) stays 0.0
 bool vcg_available(const lgh_ctx *c);
 // multi-rank: flags / list of the nodes shared with other ranks (nullptr / 0 without neighbours)
 void comm_shared_nodes(const lgh_ctx *c, const uint8_t **hmask, const int **sh_node, int *n_shared);

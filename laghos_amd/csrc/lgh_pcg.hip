@@ -846,7 +846,6 @@ pcg_solve_k(const PcgArgs *ap)
 // ---- host side -------------------------------------------------------------------------
 constexpr size_t kGranWords = (size_t)2 * 64 * kSweepMax * 2 * kPC;
 constexpr size_t kSyncWords = kGranWords + (kCtrShards + 1) * kCtrStride / 2; // granules, then the counters
-constexpr int kYePad = 16;
 struct PcgHost
 {
    PcgResult *res_dev = nullptr;
@@ -903,9 +902,9 @@ bool pcg_available(const lgh_ctx *c)
 // (measured: t = 4.2..5.3 ns + 1.7..1.8 ns * valence per node and workgroup, LGH_PCG_TRACE); with equal
 // node counts the workgroups whose range covers element-boundary planes take 40 % longer and every barrier
 // waits for them.  Ranges of equal cost instead, boundaries rounded to 16 nodes (128 B).
-static int pcg_partition_nodes(lgh_ctx *c, PcgHost *h)
+int partition_nodes_by_cost(lgh_ctx *c, const int W, int **out)
 {
-   const int N = c->N, W = (h->grid >> 3) << 3;
+   const int N = c->N;
    std::vector<int> off((size_t)N + 1);
    LGH_HIP_CHECK(hipMemcpy(off.data(), c->t_off, off.size() * sizeof(int), hipMemcpyDeviceToHost));
    static const char *wenv = getenv("LGH_PCG_NODE_WEIGHT"); // fixed part in units of half a contribution; <0: equal counts
@@ -924,8 +923,30 @@ static int pcg_partition_nodes(lgh_ctx *c, PcgHost *h)
       ns[w] = std::min(nb, N);
    }
    ns[std::max(W, 1)] = N;
-   LGH_HIP_CHECK(hipMalloc((void **)&h->nstart, ns.size() * sizeof(int)));
-   LGH_HIP_CHECK(hipMemcpy(h->nstart, ns.data(), ns.size() * sizeof(int), hipMemcpyHostToDevice));
+   LGH_HIP_CHECK(hipMalloc((void **)out, ns.size() * sizeof(int)));
+   LGH_HIP_CHECK(hipMemcpy(*out, ns.data(), ns.size() * sizeof(int), hipMemcpyHostToDevice));
+   return LGH_OK;
+}
+static int pcg_partition_nodes(lgh_ctx *c, PcgHost *h) { return partition_nodes_by_cost(c, (h->grid >> 3) << 3, &h->nstart); }
+
+// ELL transpose of the restriction as byte offsets into a Y_E plane of NE*ND + pad doubles whose slot NE*ND is
+// zero: absent contributions point there, so the gather needs no predicate
+int make_ellz(lgh_ctx *c, unsigned **out)
+{
+   const size_t ell_n = (size_t)8 * c->N;
+   LGH_HIP_CHECK(hipMalloc((void **)out, ell_n * sizeof(unsigned)));
+   hipLaunchKernelGGL(pcg_ellz_k, dim3((unsigned)((ell_n + 255) / 256)), dim3(256), 0, nullptr, c->t_ell, *out,
+                      (size_t)c->t_deg * c->N, ell_n, c->NE * c->ND);
+   LGH_HIP_CHECK(hipGetLastError());
+   return LGH_OK;
+}
+// bit k of entry n: node n is essential for component k
+int make_essbits(lgh_ctx *c, uint8_t **out)
+{
+   LGH_HIP_CHECK(hipMalloc((void **)out, (size_t)c->N));
+   hipLaunchKernelGGL(pcg_essbits_k, dim3((unsigned)((c->N + 255) / 256)), dim3(256), 0, nullptr, c->essmask[0], c->essmask[1],
+                      c->essmask[2], *out, c->N);
+   LGH_HIP_CHECK(hipGetLastError());
    return LGH_OK;
 }
 
@@ -992,15 +1013,10 @@ int pcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
       const size_t ye_n = (size_t)kPV * ((size_t)c->NE * c->ND + kYePad);
       LGH_HIP_CHECK(hipMalloc((void **)&h->ye, ye_n * sizeof(double)));
       LGH_HIP_CHECK(hipMemset(h->ye, 0, ye_n * sizeof(double)));
-      const size_t ell_n = (size_t)8 * N;
-      LGH_HIP_CHECK(hipMalloc((void **)&h->ellz, ell_n * sizeof(unsigned)));
-      hipLaunchKernelGGL(pcg_ellz_k, dim3((unsigned)((ell_n + 255) / 256)), dim3(256), 0, nullptr, c->t_ell, h->ellz,
-                         (size_t)c->t_deg * N, ell_n, c->NE * c->ND);
-      LGH_HIP_CHECK(hipGetLastError());
-      LGH_HIP_CHECK(hipMalloc((void **)&h->essbits, N));
-      hipLaunchKernelGGL(pcg_essbits_k, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, nullptr, c->essmask[0], c->essmask[1],
-                         c->essmask[2], h->essbits, c->N);
-      LGH_HIP_CHECK(hipGetLastError());
+      int rcb = make_ellz(c, &h->ellz);
+      if (rcb) { return rcb; }
+      rcb = make_essbits(c, &h->essbits);
+      if (rcb) { return rcb; }
       if (!c->vcg_vec)
       {
          LGH_HIP_CHECK(hipMalloc((void **)&c->vcg_vec, 3 * kPV * N * sizeof(double))); // r, d (, yL of the multi-rank path)

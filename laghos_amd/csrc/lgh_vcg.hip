@@ -24,8 +24,10 @@ struct VcgScalars
 {
    double rz[kVC], rz_prev[kVC], den[kVC], r0[kVC];
    double rel_tol2;
+   double alpha_last[kVC]; // vcg_update_p_k: alpha of the latest completed update of component c
    int done[kVC], iters[kVC], first;
    int all_done, pad;
+   int nupd[kVC], pad2;    // vcg_update_p_k: iteration of that update (x lags one update behind when it is odd)
 };
 
 // three-value variant of grid_reduce_last_block (sum): partials[v*stride + i]
@@ -168,6 +170,11 @@ struct VcgArgs
    const uint8_t *hmask;      // N flags, or nullptr
    const int *sh_node;        // the shared nodes
    int n_shared;
+   // vcg_update_p_k
+   const unsigned *ellz;      // ell as byte offsets into a Y_E plane, absent entries -> its zero slot NE*ND
+   const uint8_t *essbits;    // bit k: node essential for component k
+   const int *nstart;         // node range of block w: [nstart[w], nstart[w+1]), balanced by cost
+   int ye_store;              // K1 (plane form): 0 plain, 1 write-through, 2 non-temporal stores of Y_E (LGH_K1_STORE)
 };
 
 // ---- K1: y_e^c = B^T D_e B d_e^c for the unconverged components, d^c = z^c + beta_c d^c.
@@ -655,7 +662,9 @@ vcg_apply_plane(const VcgArgs a, const int nbatch)
             double u = 0.0;
 #pragma unroll
             for (int q = 0; q < Q; q++) { u = fma(bt[q], sE[q + Q * k], u); }
-            yc[qx + D * k] = u;
+            if (a.ye_store == 1) { __hip_atomic_store(&yc[qx + D * k], u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            else if (a.ye_store == 2) { __builtin_nontemporal_store(u, &yc[qx + D * k]); }
+            else { yc[qx + D * k] = u; }
             dot = fma(sIn[qx + D * k], u, dot);
          }
       }
@@ -825,7 +834,7 @@ __global__ void vcg_set_tol_k(VcgScalars *s, double rel_tol2)
    s->rel_tol2 = rel_tol2;
    s->all_done = 0;
    s->first = 1;
-   for (int c = 0; c < kVC; c++) { s->done[c] = 0; s->iters[c] = 0; }
+   for (int c = 0; c < kVC; c++) { s->done[c] = 0; s->iters[c] = 0; s->nupd[c] = 0; s->alpha_last[c] = 0.0; }
 }
 // Several ranks: the host enqueues the iteration count of the previous solve without looking at the flags,
 // so a few launches may follow convergence.  Their kernels return at once, but the exchanges between them
@@ -948,6 +957,175 @@ vcg_update_k(const VcgArgs a)
    }
 }
 
+// ---- K2, bounded-grid form (one rank) ---------------------------------------------------------------
+// The same node update as vcg_update_k, organised the way the node phase of the persistent kernel
+// (lgh_pcg.hip) turned out to run fastest - its measurements carry over to a kernel of its own:
+//  * two workgroups of 512 threads per CU, each with a contiguous node range of equal COST (a node costs a
+//    fixed part plus a part per element contribution; with equal counts the ranges that cover
+//    element-boundary planes take 40 % longer), two nodes per thread and pass, all ~70 loads of a pass issued
+//    before the first use, straight-line code;
+//  * the ELL row holds byte offsets and absent contributions point at a zero slot behind the Y_E plane: no
+//    predicated loads, addresses are one SGPR base + a 32-bit VGPR offset;
+//  * x is only needed at the end of the solve: it is updated every second iteration with both terms,
+//      x = (x + alpha_{it-1} d_{it-1}) + alpha_it d_it     (the roundings of two single updates),
+//    and vcg_xfix_k adds the pending term of a component that stopped after an odd number of updates -
+//    22 MB less traffic per iteration on average at C2;
+//  * 1024 workgroup partials instead of 3566 for the ticketed reduction.
+__device__ __forceinline__ double vcg_ld(const double *base, const unsigned off) { return *(const double *)((const char *)base + off); }
+__device__ __forceinline__ double *vcg_ptr(double *base, const unsigned off) { return (double *)((char *)base + off); }
+
+// ST: 0 plain stores, 1 write-through (sc1, agent-scope atomic store), 2 non-temporal - A/B of what the kernel
+// leaves dirty in the L2s for the end-of-kernel write-back (LGH_K2_STORE)
+template <int ST> __device__ __forceinline__ void vcg_st(double *p, const double v)
+{
+   if (ST == 1) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+   else if (ST == 2) { __builtin_nontemporal_store(v, p); }
+   else { *p = v; }
+}
+template <bool XU, int ST>
+__global__ void __launch_bounds__(512)
+vcg_update_p_k(const VcgArgs a)
+{
+   constexpr int U = 2, NT = 512;
+   __shared__ double red[16];
+   if (a.s->all_done) { return; }
+   const int it = a.iter;
+   const bool first = (it == 1);
+   const int tid = threadIdx.x;
+   const int w = xcd_swizzle(blockIdx.x, gridDim.x);
+   const int n0 = a.nstart[w], n1 = a.nstart[w + 1];
+   bool todo[kVC];
+   double alpha[kVC], alpha_prev[kVC], beta[kVC];
+#pragma unroll
+   for (int k = 0; k < kVC; k++)
+   {
+      todo[k] = a.s->done[k] == 0;
+      alpha[k] = todo[k] ? a.s->rz[k] / a.s->den[k] : 0.0;
+      alpha_prev[k] = todo[k] ? a.s->alpha_last[k] : 0.0;
+      beta[k] = (first || !todo[k]) ? 0.0 : a.s->rz[k] / a.s->rz_prev[k];
+   }
+   const bool xload = XU && it > 2;
+   const unsigned rowb = 4u * (unsigned)a.N, compb = 8u * (unsigned)a.N;
+   double part[kVC] = {0.0, 0.0, 0.0};
+   for (int base = n0; base < n1; base += NT * U)
+   {
+      unsigned nn[U];
+      bool ok[U];
+#pragma unroll
+      for (int u = 0; u < U; u++)
+      {
+         const int n = base + tid + u * NT;
+         ok[u] = n < n1;
+         nn[u] = (unsigned)(ok[u] ? n : n0);
+      }
+      unsigned ix[U][8];
+#pragma unroll
+      for (int u = 0; u < U; u++)
+      {
+#pragma unroll
+         for (int j = 0; j < 8; j++) { ix[u][j] = *(const unsigned *)((const char *)a.ellz + (4u * nn[u] + (unsigned)j * rowb)); }
+      }
+      double di[U], ro[U][kVC], dol[U][kVC], xo[U][kVC];
+      unsigned es[U];
+#pragma unroll
+      for (int u = 0; u < U; u++)
+      {
+         di[u] = vcg_ld(a.dinv, 8u * nn[u]);
+         es[u] = a.essbits[nn[u]];
+#pragma unroll
+         for (int k = 0; k < kVC; k++)
+         {
+            const unsigned vb = 8u * nn[u] + (unsigned)k * compb;
+            ro[u][k] = vcg_ld(a.r, vb);
+            dol[u][k] = vcg_ld(a.d, vb);
+            xo[u][k] = 0.0;
+            if (XU) { xo[u][k] = vcg_ld(a.x, vb); }
+         }
+      }
+      double ye[U][kVC][8];
+#pragma unroll
+      for (int k = 0; k < kVC; k++)
+      {
+         const double *yc = a.YE + (size_t)k * a.ye_stride;
+#pragma unroll
+         for (int u = 0; u < U; u++)
+         {
+#pragma unroll
+            for (int j = 0; j < 8; j++) { ye[u][k][j] = vcg_ld(yc, ix[u][j]); }
+         }
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++)
+      {
+#pragma unroll
+         for (int k = 0; k < kVC; k++)
+         {
+            const unsigned vb = 8u * nn[u] + (unsigned)k * compb;
+            double zs = 0.0; // ascending contribution order (absent slots add 0.0 at the end): the sum of vcg_update_k
+#pragma unroll
+            for (int j = 0; j < 8; j++) { zs += ye[u][k][j]; }
+            const double z_ = ((es[u] >> k) & 1u) ? 0.0 : zs;
+            const double zold = __dmul_rn(ro[u][k], di[u]); // z of the previous iterate, not stored
+            const double dnew = first ? zold : fma(beta[k], dol[u][k], zold);
+            const double rnew = ro[u][k] - alpha[k] * z_;
+            if (ok[u] && todo[k])
+            {
+               vcg_st<ST>(vcg_ptr(a.d, vb), dnew);
+               vcg_st<ST>(vcg_ptr(a.r, vb), rnew);
+               if (XU)
+               {
+                  const double x0 = xload ? xo[u][k] : 0.0;
+                  vcg_st<ST>(vcg_ptr(a.x, vb), fma(alpha[k], dnew, fma(alpha_prev[k], first ? 0.0 : dol[u][k], x0)));
+               }
+               part[k] += rnew * __dmul_rn(rnew, di[u]);
+            }
+         }
+      }
+   }
+   double bp[kVC], total[kVC];
+#pragma unroll
+   for (int k = 0; k < kVC; k++)
+   {
+      bp[k] = block_sum(part[k], red);
+      __syncthreads();
+   }
+   if (grid_sum3_last_block(bp, a.partials, a.stride, a.ticket, red, total))
+   {
+      if (tid == 0)
+      {
+         VcgScalars *s = a.s;
+         int all = 1;
+         for (int k = 0; k < kVC; k++)
+         {
+            if (!s->done[k])
+            {
+               s->alpha_last[k] = s->rz[k] / s->den[k]; // the alpha this launch used
+               s->nupd[k] = it;
+               s->rz_prev[k] = s->rz[k];
+               s->rz[k] = total[k]; // betanom
+               s->iters[k] = it;
+               if (total[k] < 0.0 || total[k] <= s->r0[k]) { s->done[k] = 1; }
+            }
+            all = all && s->done[k];
+         }
+         s->all_done = all;
+      }
+   }
+}
+// components whose last update of x is still pending (an odd number of updates)
+__global__ void __launch_bounds__(256)
+vcg_xfix_k(const VcgArgs a)
+{
+   const int n = blockIdx.x * blockDim.x + threadIdx.x;
+   if (n >= a.N) { return; }
+   for (int k = 0; k < kVC; k++)
+   {
+      if ((a.s->nupd[k] & 1) == 0) { continue; }
+      const size_t i = (size_t)k * a.N + n;
+      a.x[i] = fma(a.s->alpha_last[k], a.d[i], a.x[i]);
+   }
+}
+
 // unfused E -> L sum of the kVC planes (multi-GPU path, unusual valence)
 __global__ void __launch_bounds__(256)
 vcg_gather_k(const VcgArgs a)
@@ -990,6 +1168,26 @@ vcg_gather_list_k(const VcgArgs a)
 }
 
 // ---- host side -----------------------------------------------------------------------
+struct VcgAux
+{
+   double *ye = nullptr;     // kVC planes of NE*ND + kYePad doubles (slot NE*ND of each plane stays 0.0)
+   unsigned *ellz = nullptr;
+   uint8_t *essbits = nullptr;
+   int *nstart = nullptr;    // cost-balanced node ranges of the grid2 workgroups of vcg_update_p_k
+   int grid2 = 0;
+};
+void vcg_free(lgh_ctx *c)
+{
+   VcgAux *x = (VcgAux *)c->vcg_aux;
+   if (!x) { return; }
+   (void)hipFree(x->ye);
+   (void)hipFree(x->ellz);
+   (void)hipFree(x->essbits);
+   (void)hipFree(x->nstart);
+   delete x;
+   c->vcg_aux = nullptr;
+}
+
 static bool vcg_supported(const lgh_ctx *c)
 {
    if (c->dim != 3) { return false; }
@@ -1078,13 +1276,36 @@ int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
          LGH_HIP_CHECK(hipMalloc((void **)&c->vcg_vec, 3 * kVC * N * sizeof(double))); // r, d, yL (z = r/diag is never stored)
          LGH_HIP_CHECK(hipMemset(c->vcg_vec, 0, 3 * kVC * N * sizeof(double)));
       }
-      c->vcg_stride = (unsigned)(std::max<size_t>((size_t)c->NE, (N + 255) / 256) + kShards);
+      // block partials of the largest reducing launch: K1 (<= NE batches), vcg_update_k (N/256 blocks), vcg_update_p_k (2 per CU)
+      c->vcg_stride = (unsigned)(std::max<size_t>(std::max<size_t>((size_t)c->NE, (N + 255) / 256), 4096) + kShards);
       LGH_HIP_CHECK(hipMalloc((void **)&c->vcg_partials, 2 * kVC * (size_t)c->vcg_stride * sizeof(double)));
       LGH_HIP_CHECK(hipMemset(c->vcg_partials, 0, 2 * kVC * (size_t)c->vcg_stride * sizeof(double)));
       LGH_HIP_CHECK(hipMalloc((void **)&c->vcg_tickets, 2 * kTicketSlot * sizeof(unsigned int)));
       LGH_HIP_CHECK(hipMemset(c->vcg_tickets, 0, 2 * kTicketSlot * sizeof(unsigned int)));
+      // the CG's own E-vector (the force E-vector of the fused init stays in c->YE) and the tables of K2
+      VcgAux *x = new VcgAux();
+      c->vcg_aux = x;
+      const size_t ye_n = (size_t)kVC * ((size_t)c->NE * c->ND + kYePad);
+      LGH_HIP_CHECK(hipMalloc((void **)&x->ye, ye_n * sizeof(double)));
+      LGH_HIP_CHECK(hipMemset(x->ye, 0, ye_n * sizeof(double)));
+      if (!multi && c->t_deg <= 8 && (size_t)c->N * 8 * kVC < 0xffffffffull && ((size_t)c->NE * c->ND + kYePad) * 8 < 0xffffffffull)
+      {
+         int ncu = 256;
+         hipDeviceProp_t prop;
+         if (hipGetDeviceProperties(&prop, c->device) == hipSuccess) { ncu = prop.multiProcessorCount; }
+         x->grid2 = 2 * ncu;
+         rc = make_ellz(c, &x->ellz);
+         if (rc) { return rc; }
+         rc = make_essbits(c, &x->essbits);
+         if (rc) { return rc; }
+         rc = partition_nodes_by_cost(c, x->grid2, &x->nstart);
+         if (rc) { return rc; }
+      }
       LGH_HIP_CHECK(hipStreamSynchronize(nullptr)); // the fills run asynchronously on the null stream
    }
+   VcgAux *aux = (VcgAux *)c->vcg_aux;
+   static const char *k2env = getenv("LGH_K2P"); // A/B: 0 = vcg_update_k (one node per thread, x every iteration)
+   const bool k2p = aux->ellz != nullptr && !multi && !(k2env && k2env[0] == '0');
    VcgScalars *ds = (VcgScalars *)c->vcg_s;
    hipLaunchKernelGGL(vcg_set_tol_k, dim3(1), dim3(1), 0, c->stream, ds, rel_tol * rel_tol);
 
@@ -1105,8 +1326,15 @@ int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
    a.r = c->vcg_vec;
    a.d = c->vcg_vec + kVC * N;
    a.yL = c->vcg_vec + 2 * kVC * N;
-   a.YE = c->YE;
-   a.ye_stride = (size_t)c->NE * c->ND;
+   a.YE = aux->ye;
+   a.ye_stride = (size_t)c->NE * c->ND + kYePad;
+   a.ellz = aux->ellz;
+   a.essbits = aux->essbits;
+   a.nstart = aux->nstart;
+   {
+      static const char *e1 = getenv("LGH_K1_STORE");
+      a.ye_store = e1 ? atoi(e1) : 0;
+   }
    a.s = ds;
    a.stride = c->vcg_stride;
    a.multi = multi ? 1 : 0;
@@ -1175,7 +1403,18 @@ int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
          LGH_HIP_CHECK(hipGetLastError());
          a.partials = c->vcg_partials;
          a.ticket = c->vcg_tickets;
-         if (!multi && c->t_deg <= 8)
+         if (k2p)
+         {
+            kt_begin(c, LGH_KERNEL_CG_UPDATE_H1);
+            static const char *stenv = getenv("LGH_K2_STORE");
+            const int st = stenv ? atoi(stenv) : 0;
+#define LGH_K2P_LAUNCH(XU_, ST_) hipLaunchKernelGGL((vcg_update_p_k<XU_, ST_>), dim3(aux->grid2), dim3(512), 0, c->stream, a)
+            if (it & 1) { if (st == 1) { LGH_K2P_LAUNCH(false, 1); } else if (st == 2) { LGH_K2P_LAUNCH(false, 2); } else { LGH_K2P_LAUNCH(false, 0); } }
+            else { if (st == 1) { LGH_K2P_LAUNCH(true, 1); } else if (st == 2) { LGH_K2P_LAUNCH(true, 2); } else { LGH_K2P_LAUNCH(true, 0); } }
+#undef LGH_K2P_LAUNCH
+            kt_end(c, LGH_KERNEL_CG_UPDATE_H1);
+         }
+         else if (!multi && c->t_deg <= 8)
          {
             kt_begin(c, LGH_KERNEL_CG_UPDATE_H1);
             hipLaunchKernelGGL((vcg_update_k<true, 8>), dim3(nb), dim3(256), 0, c->stream, a);
@@ -1224,6 +1463,12 @@ int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
          }
          LGH_HIP_CHECK(hipGetLastError());
       }
+   }
+   if (k2p && ((hs->nupd[0] | hs->nupd[1] | hs->nupd[2]) & 1))
+   {
+      // x lags one update behind for the components that stopped after an odd number of updates
+      hipLaunchKernelGGL(vcg_xfix_k, dim3(nb), dim3(256), 0, c->stream, a);
+      LGH_HIP_CHECK(hipGetLastError());
    }
    if (trace_dev)
    {
