@@ -294,6 +294,10 @@ static int create_impl(const lgh_config *cfg, lgh_ctx *c, const int kid)
    LGH_TRY(dev_alloc_zero(&c->diagV, (size_t)c->N));
    LGH_TRY(dev_alloc_zero(&c->dinvV, (size_t)c->N));
    LGH_TRY(dev_alloc_zero(&c->dt_est_dev, 1));
+   {
+      const char *env = getenv("LGH_FUSED_FTV"); // A/B: 0 = F^T v always by its own kernel
+      if (!(env && env[0] == '0')) { LGH_TRY(dev_alloc_zero(&c->erhs_q, (size_t)c->L2V)); }
+   }
    const size_t ne_nd = nmap * dim;
    LGH_TRY(dev_alloc_zero(&c->XE, std::max<size_t>(ne_nd, (size_t)c->L2V)));
    LGH_TRY(dev_alloc_zero(&c->YE, ne_nd));
@@ -325,7 +329,7 @@ int lgh_destroy(lgh_ctx *c)
    void *ptrs[] = {c->B, c->G, c->Bl, c->W, c->gamma, c->h1map, c->t_off, c->t_idx, c->t_ell, c->essmask[0],
                    c->essmask[1], c->essmask[2], c->ess[0], c->ess[1], c->ess[2], c->owner,
                    c->stressJinvT, c->Jac0inv, c->Jac0inv_soa, c->rho0DetJ0w, c->massD, c->diagV, c->dinvV,
-                   c->dt_est_dev, c->XE, c->YE, c->cg_r, c->cg_z, c->cg_d0, c->cg_d1, c->cg_y,
+                   c->dt_est_dev, c->erhs_q, c->XE, c->YE, c->cg_r, c->cg_z, c->cg_d0, c->cg_d1, c->cg_y,
                    c->partials, c->tickets, c->cgs, c->scal, c->vcg_s, c->vcg_vec, c->vcg_partials,
                    c->vcg_tickets};
    for (void *p : ptrs) { if (p) { (void)hipFree(p); } }
@@ -362,7 +366,11 @@ int lgh_sync(lgh_ctx *c)
 }
 void *lgh_stream(lgh_ctx *c) { return c ? (void *)c->stream : nullptr; }
 
-double *lgh_qdata_stressJinvT(lgh_ctx *c) { return c->stressJinvT; }
+double *lgh_qdata_stressJinvT(lgh_ctx *c)
+{
+   c->erhs_state = nullptr; // the caller may write through this pointer: F^T v of the fused update no longer belongs to it
+   return c->stressJinvT;
+}
 double *lgh_qdata_Jac0inv(lgh_ctx *c) { return c->Jac0inv; }
 double *lgh_qdata_rho0DetJ0w(lgh_ctx *c) { return c->rho0DetJ0w; }
 double *lgh_mass_D(lgh_ctx *c) { return c->massD; }
@@ -552,6 +560,19 @@ int lgh_solve_velocity(lgh_ctx *c, const double *S, double *dS_dt, const double 
    return LGH_OK;
 }
 
+// ForcePA->MultTranspose(v, e_rhs) of SolveEnergy (laghos_solver.cpp:473).  When v is the velocity block of
+// the state the quadrature data was last updated for, the fused QUpdate has already formed it (one pass over
+// the 9 stressJinvT planes less per stage); any other v - RK2Avg's averaged velocity - goes through the kernel.
+static int energy_rhs(lgh_ctx *c, const double *v_h1, double *e_rhs)
+{
+   if (c->erhs_q && c->erhs_state && v_h1 == c->erhs_state + c->H1V)
+   {
+      LGH_HIP_CHECK(hipMemcpyAsync(e_rhs, c->erhs_q, sizeof(double) * (size_t)c->L2V, hipMemcpyDeviceToDevice, c->stream));
+      return LGH_OK;
+   }
+   return lgh_force_mult_transpose(c, v_h1, e_rhs);
+}
+
 // SolveEnergy, PA branch (laghos_solver.cpp:442-490)
 int lgh_solve_energy(lgh_ctx *c, const double *S, const double *v_h1, double *dS_dt, double *e_rhs,
                      const double *e_source, double rel_tol, int max_iter, int *l2_iters)
@@ -560,7 +581,7 @@ int lgh_solve_energy(lgh_ctx *c, const double *S, const double *v_h1, double *dS
    (void)S;
    double *de = dS_dt + 2 * (size_t)c->H1V;
    timer_start(c);
-   int rc = lgh_force_mult_transpose(c, v_h1, e_rhs); // :473
+   int rc = energy_rhs(c, v_h1, e_rhs); // :473
    timer_stop(c, 2);
    if (rc) { return rc; }
    if (e_source)
@@ -613,7 +634,7 @@ int lgh_solve_energy_begin(lgh_ctx *c, const double *S, const double *v_h1, doub
    LGH_HIP_CHECK(hipEventRecord(c->ev_fork, c->stream));
    LGH_HIP_CHECK(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
    std::swap(c->stream, c->stream2); // everything below is enqueued on the second stream
-   int rc = lgh_force_mult_transpose(c, v_h1, e_rhs); // :473
+   int rc = energy_rhs(c, v_h1, e_rhs); // :473
    if (rc == LGH_OK && e_source) { rc = vec_axpby(c, e_rhs, 1.0, e_rhs, 1.0, e_source, c->L2V); } // :477
    if (rc == LGH_OK) { rc = cg_l2_begin(c, e_rhs, dS_dt + 2 * (size_t)c->H1V, rel_tol, max_iter); } // :481
    std::swap(c->stream, c->stream2);

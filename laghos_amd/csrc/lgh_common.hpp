@@ -111,6 +111,8 @@ struct lgh_ctx
    double *stressJinvT, *Jac0inv, *rho0DetJ0w, *massD, *diagV, *dinvV;
    double *Jac0inv_soa;  // plane-major copy of Jac0inv for coalesced reads in QUpdate
    double *dt_est_dev;   // 1 double: running min of the point-wise estimate
+   double *erhs_q;       // L2V: F^T v formed inside the fused QUpdate for the velocity block of ...
+   const double *erhs_state; // ... this state vector (the S of the last lgh_qupdate), or nullptr
    // scratch
    double *XE;           // max(L2V, NE*ND*dim)
    double *YE;           // NE*ND*dim

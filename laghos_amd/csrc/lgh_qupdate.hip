@@ -43,6 +43,7 @@ struct QArgs
    double *result; // dt_est (min-folded) or sum
    double h0, h1order, cfl;
    int visc, vort;
+   double *erhs_q;   // update mode: F^T v of the SAME state (the velocity block of S), L2 vector, or nullptr (see below)
    double tiny_grad; // wave-uniform shortcut of the eigen-decomposition below this |sym grad v| (see qpoint_body); < 0: off
 };
 
@@ -61,7 +62,7 @@ template <int DIM>
 __device__ __forceinline__ double qpoint_body(const QArgs &a, const int e, const size_t eq,
                                               const double weight, const double *J, const double *dV,
                                               const double e_val, const size_t plane,
-                                              const double *J0i, const double rho0DetJ0w)
+                                              const double *J0i, const double rho0DetJ0w, double &ftv)
 {
    constexpr int DIM2 = DIM * DIM;
    double Jinv[DIM2], stress[DIM2], sgrad_v[DIM2], stressJiT[DIM2];
@@ -135,6 +136,14 @@ __device__ __forceinline__ double qpoint_body(const QArgs &a, const int e, const
    else if (idt > 0.0) { dt_cand = a.cfl / idt; }
    sm::matmul_abt<DIM>(stress, Jinv, stressJiT);
    const double wd = weight * detJ;
+   // integrand of ForceMultTranspose at this point (laghos_assembly.cpp:859-872): sum over (c, gd) of
+   // stressJinvT(q, gd, c) * d v_c / d xi_gd - the gradient is in registers here, the stress just formed
+   {
+      double acc = 0.0;
+#pragma unroll
+      for (int k = 0; k < DIM2; k++) { acc += stressJiT[k] * dV[k]; }
+      ftv = acc * wd;
+   }
 #pragma unroll
    for (int vd = 0; vd < DIM; vd++)
 #pragma unroll
@@ -409,8 +418,71 @@ qpoint_kernel(const QArgs a)
             J[c + DIM * d] = grad[c * DIM + d];
             dV[c + DIM * d] = grad[(DIM + c) * DIM + d];
          }
-      double cand = INFINITY;
-      if (active) { cand = qpoint_body<DIM>(a, e, eq, weight, J, dV, e_val, plane, J0i, rdw); }
+      double cand = INFINITY, ftv = 0.0;
+      if (active) { cand = qpoint_body<DIM>(a, e, eq, weight, J, dV, e_val, plane, J0i, rdw, ftv); }
+      if (a.erhs_q)
+      {
+         // F^T v fused into the update (ForcePAOperator::MultTranspose, laghos_assembly.cpp:875-921: test the
+         // point values with the L2 basis): SolveEnergy's right-hand side for the velocity of THIS state costs
+         // three small LDS contractions here instead of a second pass over the 9 stressJinvT planes (510 MB at
+         // C2).  lgh_solve_energy uses it when its v is the velocity block of the state of the last update.
+         // the interpolation buffers of this element are free now: point values at their start, the z-contracted
+         // array behind them (with few fields per pass, Q5Q4, sX alone is smaller than the NQ point values)
+         static_assert(SU + SXs + SYs >= NQ + ((DIM == 3) ? L * Q * Q : 0), "LDS: no room for the F^T v contraction");
+         double *sS = sU, *sT = sU + NQ;
+         __syncthreads(); // every thread has finished reading the interpolation buffers
+         sS[lt] = active ? ftv : 0.0;
+         __syncthreads();
+         if (DIM == 3)
+         {
+            for (int i = lt; i < L * Q * Q; i += NTE)
+            {
+               const int qx = i % Q, qy = (i / Q) % Q, lz = i / (Q * Q);
+               double u = 0.0;
+#pragma unroll
+               for (int qz = 0; qz < Q; qz++) { u += sBl[qz + Q * lz] * sS[qx + Q * (qy + Q * qz)]; }
+               sT[i] = u;
+            }
+            __syncthreads();
+            for (int i = lt; i < L * L * Q; i += NTE)
+            {
+               const int qx = i % Q, ly = (i / Q) % L, lz = i / (Q * L);
+               double u = 0.0;
+#pragma unroll
+               for (int qy = 0; qy < Q; qy++) { u += sBl[qy + Q * ly] * sT[qx + Q * (qy + Q * lz)]; }
+               sE1[i] = u;
+            }
+            __syncthreads();
+            for (int i = lt; i < NL; i += NTE)
+            {
+               const int lx = i % L, ly = (i / L) % L, lz = i / (L * L);
+               double u = 0.0;
+#pragma unroll
+               for (int qx = 0; qx < Q; qx++) { u += sBl[qx + Q * lx] * sE1[qx + Q * (ly + L * lz)]; }
+               if (active) { a.erhs_q[(size_t)e * NL + i] = u; }
+            }
+         }
+         else
+         {
+            for (int i = lt; i < L * Q; i += NTE)
+            {
+               const int qx = i % Q, ly = i / Q;
+               double u = 0.0;
+#pragma unroll
+               for (int qy = 0; qy < Q; qy++) { u += sBl[qy + Q * ly] * sS[qx + Q * qy]; }
+               sE1[i] = u;
+            }
+            __syncthreads();
+            for (int i = lt; i < NL; i += NTE)
+            {
+               const int lx = i % L, ly = i / L;
+               double u = 0.0;
+#pragma unroll
+               for (int qx = 0; qx < Q; qx++) { u += sBl[qx + Q * lx] * sE1[qx + Q * ly]; }
+               if (active) { a.erhs_q[(size_t)e * NL + i] = u; }
+            }
+         }
+      }
       const double bmin = block_min(cand, red);
       double total;
       if (grid_min_last_block(bmin, a.partials, a.ticket, red, total))
@@ -556,6 +628,7 @@ static QArgs q_base(lgh_ctx *c)
    a.visc = c->visc;
    a.vort = c->vort;
    a.tiny_grad = c->q_tiny_grad;
+   a.erhs_q = c->erhs_q;
    return a;
 }
 
@@ -566,7 +639,10 @@ int qupdate(lgh_ctx *c, const double *S)
    a.v = S + c->H1V;
    a.e = S + 2 * (size_t)c->H1V;
    a.result = c->dt_est_dev;
-   return launch_q<QMODE_UPDATE>(c, a);
+   const int rc = launch_q<QMODE_UPDATE>(c, a);
+   // F^T v of this state's velocity block is now in c->erhs_q (lgh_solve_energy)
+   c->erhs_state = (rc == LGH_OK && c->erhs_q) ? S : nullptr;
+   return rc;
 }
 
 int setup_rho0detj0(lgh_ctx *c, const double *x0, const double *rho0_l2, const double *rho0_q,
