@@ -297,6 +297,8 @@ static int create_impl(const lgh_config *cfg, lgh_ctx *c, const int kid)
    {
       const char *env = getenv("LGH_FUSED_FTV"); // A/B: 0 = F^T v always by its own kernel
       if (!(env && env[0] == '0')) { LGH_TRY(dev_alloc_zero(&c->erhs_q, (size_t)c->L2V)); }
+      env = getenv("LGH_FUSED_F1");              // A/B: 0 = F.1 always by its own kernel
+      if (c->dim == 3 && !(env && env[0] == '0')) { LGH_TRY(dev_alloc_zero(&c->force_e_q, nmap * dim)); }
    }
    const size_t ne_nd = nmap * dim;
    LGH_TRY(dev_alloc_zero(&c->XE, std::max<size_t>(ne_nd, (size_t)c->L2V)));
@@ -329,7 +331,7 @@ int lgh_destroy(lgh_ctx *c)
    void *ptrs[] = {c->B, c->G, c->Bl, c->W, c->gamma, c->h1map, c->t_off, c->t_idx, c->t_ell, c->essmask[0],
                    c->essmask[1], c->essmask[2], c->ess[0], c->ess[1], c->ess[2], c->owner,
                    c->stressJinvT, c->Jac0inv, c->Jac0inv_soa, c->rho0DetJ0w, c->massD, c->diagV, c->dinvV,
-                   c->dt_est_dev, c->erhs_q, c->XE, c->YE, c->cg_r, c->cg_z, c->cg_d0, c->cg_d1, c->cg_y,
+                   c->dt_est_dev, c->erhs_q, c->force_e_q, c->XE, c->YE, c->cg_r, c->cg_z, c->cg_d0, c->cg_d1, c->cg_y,
                    c->partials, c->tickets, c->cgs, c->scal, c->vcg_s, c->vcg_vec, c->vcg_partials,
                    c->vcg_tickets};
    for (void *p : ptrs) { if (p) { (void)hipFree(p); } }
@@ -368,7 +370,9 @@ void *lgh_stream(lgh_ctx *c) { return c ? (void *)c->stream : nullptr; }
 
 double *lgh_qdata_stressJinvT(lgh_ctx *c)
 {
-   c->erhs_state = nullptr; // the caller may write through this pointer: F^T v of the fused update no longer belongs to it
+   // the caller may write through this pointer: F^T v and F.1 of the fused update no longer belong to it
+   c->force_e_state = nullptr;
+   c->erhs_state = nullptr;
    return c->stressJinvT;
 }
 double *lgh_qdata_Jac0inv(lgh_ctx *c) { return c->Jac0inv; }
@@ -467,13 +471,33 @@ int lgh_qupdate(lgh_ctx *c, const double *S)
    return rc;
 }
 
+// The fused update forms F.1 for the constant-one L2 function, which is what SolveVelocity passes
+// (laghos_solver.cpp:170-171, :354).  The C ABI takes the vector as an argument, so it is checked once per
+// pointer that it really is all ones before the fused result is used in its place.
+__global__ void __launch_bounds__(256) not_all_ones_k(const double *x, const long n, int *flag)
+{
+   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+   if (i < n && x[i] != 1.0) { *flag = 1; }
+}
+static bool is_the_one_vector(lgh_ctx *c, const double *one_l2)
+{
+   if (c->one_checked == one_l2) { return true; }
+   int *flag = (int *)c->scal; // 16 doubles of device scratch
+   if (hipMemsetAsync(flag, 0, sizeof(int), c->stream) != hipSuccess) { return false; }
+   hipLaunchKernelGGL(not_all_ones_k, dim3(ceil_div(c->L2V, 256)), dim3(256), 0, c->stream, one_l2, (long)c->L2V, flag);
+   int h = 1;
+   if (hipMemcpyAsync(&h, flag, sizeof(int), hipMemcpyDeviceToHost, c->stream) != hipSuccess) { return false; }
+   if (hipStreamSynchronize(c->stream) != hipSuccess) { return false; }
+   if (h == 0) { c->one_checked = one_l2; }
+   return h == 0;
+}
+
 // SolveVelocity, PA branch without acceleration source (laghos_solver.cpp:329-399).
 // The caller has already run UpdateQuadratureData(S) if the data was stale (:332).
 int lgh_solve_velocity(lgh_ctx *c, const double *S, double *dS_dt, const double *one_l2,
                        double *rhs_h1, double *work_B, double rel_tol, int max_iter, int *h1_iters)
 {
    LGH_CHECK_ARG(c && S && dS_dt && one_l2 && rhs_h1 && work_B);
-   (void)S;
    const int dim = c->dim, N = c->N;
    double *dv = dS_dt + c->H1V;
    int rc;
@@ -482,12 +506,18 @@ int lgh_solve_velocity(lgh_ctx *c, const double *S, double *dS_dt, const double 
    // bit-identical results.  With the timers on the reference's regions are kept apart.
    if (!c->timers.enabled && !c->accel_src && vcg_fused_init_ok(c))
    {
-      kt_begin(c, LGH_KERNEL_FORCE_MULT);
-      rc = force_mult_E(c, c->stressJinvT, one_l2, c->YE); // :354 up to the E-vector (K1 reuses c->YE after the init)
-      kt_end(c, LGH_KERNEL_FORCE_MULT);
-      if (rc) { return rc; }
+      // F.1 up to the E-vector (:354): formed by the fused update for this very state, or by the force kernel
+      const double *force_E = c->YE;
+      if (c->force_e_q && c->force_e_state == S && is_the_one_vector(c, one_l2)) { force_E = c->force_e_q; }
+      else
+      {
+         kt_begin(c, LGH_KERNEL_FORCE_MULT);
+         rc = force_mult_E(c, c->stressJinvT, one_l2, c->YE);
+         kt_end(c, LGH_KERNEL_FORCE_MULT);
+         if (rc) { return rc; }
+      }
       int its[3] = {0, 0, 0};
-      rc = vcg_solve(c, rhs_h1, dv, rel_tol, max_iter, its, c->YE); // :358-388
+      rc = vcg_solve(c, rhs_h1, dv, rel_tol, max_iter, its, force_E); // :358-388
       if (rc) { return rc; }
       for (int cc = 0; cc < dim; cc++)
       {
@@ -500,7 +530,14 @@ int lgh_solve_velocity(lgh_ctx *c, const double *S, double *dS_dt, const double 
    rc = vec_set(c, dv, 0.0, c->H1V); // dv = 0.0 (:338)
    if (rc) { return rc; }
    timer_start(c);
-   rc = lgh_force_mult(c, one_l2, rhs_h1); // :354
+   if (c->force_e_q && c->force_e_state == S && is_the_one_vector(c, one_l2))
+   {
+      // F.1 of this state from the fused update: only H1R^T (and the sum over the ranks) is left of :354, and
+      // the right-hand side has the bits of the fused-init path above
+      rc = h1_transpose_gather(c, c->dim, c->force_e_q, rhs_h1);
+      if (rc == LGH_OK && c->multi != 0) { rc = halo_sum(c, rhs_h1, c->dim); }
+   }
+   else { rc = lgh_force_mult(c, one_l2, rhs_h1); } // :354
    timer_stop(c, 2);
    if (rc) { return rc; }
    rc = vec_neg_inplace(c, rhs_h1, c->H1V); // :358

@@ -113,6 +113,9 @@ struct lgh_ctx
    double *dt_est_dev;   // 1 double: running min of the point-wise estimate
    double *erhs_q;       // L2V: F^T v formed inside the fused QUpdate for the velocity block of ...
    const double *erhs_state; // ... this state vector (the S of the last lgh_qupdate), or nullptr
+   double *force_e_q;    // NE*ND*dim: F.1 as E-vector formed inside the fused QUpdate (3D) for ...
+   const double *force_e_state; // ... this state vector, or nullptr
+   const double *one_checked;   // the caller's `one` L2 vector that has been verified to be all ones
    // scratch
    double *XE;           // max(L2V, NE*ND*dim)
    double *YE;           // NE*ND*dim

@@ -43,6 +43,7 @@ struct QArgs
    double *result; // dt_est (min-folded) or sum
    double h0, h1order, cfl;
    int visc, vort;
+   double *force_e;  // update mode (3D): F.1 as E-vector (D1D^3, dim, NE), or nullptr (see below)
    double *erhs_q;   // update mode: F^T v of the SAME state (the velocity block of S), L2 vector, or nullptr (see below)
    double tiny_grad; // wave-uniform shortcut of the eigen-decomposition below this |sym grad v| (see qpoint_body); < 0: off
 };
@@ -62,7 +63,7 @@ template <int DIM>
 __device__ __forceinline__ double qpoint_body(const QArgs &a, const int e, const size_t eq,
                                               const double weight, const double *J, const double *dV,
                                               const double e_val, const size_t plane,
-                                              const double *J0i, const double rho0DetJ0w, double &ftv)
+                                              const double *J0i, const double rho0DetJ0w, double &ftv, double *sjw)
 {
    constexpr int DIM2 = DIM * DIM;
    double Jinv[DIM2], stress[DIM2], sgrad_v[DIM2], stressJiT[DIM2];
@@ -149,7 +150,9 @@ __device__ __forceinline__ double qpoint_body(const QArgs &a, const int e, const
 #pragma unroll
       for (int gd = 0; gd < DIM; gd++)
       {
-         a.stressJinvT[eq + plane * (gd + vd * DIM)] = stressJiT[vd + gd * DIM] * wd;
+         const double sv_ = stressJiT[vd + gd * DIM] * wd;
+         sjw[gd + vd * DIM] = sv_;
+         a.stressJinvT[eq + plane * (gd + vd * DIM)] = sv_;
       }
    return dt_cand;
 }
@@ -180,7 +183,17 @@ qpoint_kernel(const QArgs a)
    constexpr int SXs = (DIM == 3) ? 2 * NF * D * D * Q : 2 * NF * D * Q; // B,G applied in x
    constexpr int SYs = (DIM == 3) ? 3 * NF * D * Q * Q : 0;              // BB,GB,BG (3D only)
    constexpr int SEs = NL + ((DIM == 3) ? (L * L * Q + L * Q * Q) : (L * Q));
-   constexpr int PER = SU + SXs + SYs + SEs + 1;
+   constexpr int PER0 = SU + SXs + SYs + SEs + 1;
+   // F.1 fused into the update (3D): the point values of CPR components x 3 reference directions and their
+   // z-contracted arrays live in this element's interpolation buffers; all 3 components per round where that
+   // fits, one per round otherwise (the slice is enlarged if even that does not fit: Q5Q4)
+   constexpr int FTN = NQ + ((DIM == 3) ? L * Q * Q : 0); // point values + z-contracted array of F^T v
+   constexpr int FNEED3 = 9 * NQ + 9 * D * Q * Q + FTN, FNEED1 = 3 * NQ + 3 * D * Q * Q + FTN;
+   constexpr int AVAIL = SU + SXs + SYs + ((DIM == 3) ? L * L * L : L * L); // the slice up to the array the y stage of F^T v writes
+   constexpr int CPR = (DIM == 3 && MODE == QMODE_UPDATE) ? ((AVAIL >= FNEED3) ? 3 : 1) : 0;
+   // (one component per round where three do not fit; the slice is enlarged if even that does not: Q5Q4)
+   constexpr int GROW = (CPR == 1 && AVAIL < FNEED1) ? FNEED1 - AVAIL : 0;
+   constexpr int PER = PER0 + GROW;
    __shared__ double smem[NEB * PER];
    __shared__ double sB[Q * D], sG[Q * D], sBl[Q * L];
    __shared__ double red[16];
@@ -194,7 +207,7 @@ qpoint_kernel(const QArgs a)
    double *sU = smem + eb * PER;
    double *sX = sU + SU;
    double *sY = sX + SXs;
-   double *sE = sY + SYs;
+   double *sE = sY + SYs + GROW; // (GROW: room for the force contractions of the update mode, see above)
    double *sE1 = sE + NL;                            // 3D [lz][ly][qx]; 2D [ly][qx]
    double *sE2 = sE1 + ((DIM == 3) ? L * L * Q : 0); // 3D [lz][qy][qx]
 
@@ -418,68 +431,159 @@ qpoint_kernel(const QArgs a)
             J[c + DIM * d] = grad[c * DIM + d];
             dV[c + DIM * d] = grad[(DIM + c) * DIM + d];
          }
-      double cand = INFINITY, ftv = 0.0;
-      if (active) { cand = qpoint_body<DIM>(a, e, eq, weight, J, dV, e_val, plane, J0i, rdw, ftv); }
-      if (a.erhs_q)
+      double cand = INFINITY, ftv = 0.0, sjw[DIM * DIM];
+#pragma unroll
+      for (int k = 0; k < DIM * DIM; k++) { sjw[k] = 0.0; }
+      if (active) { cand = qpoint_body<DIM>(a, e, eq, weight, J, dV, e_val, plane, J0i, rdw, ftv, sjw); }
+      // ---- the two force products of this state, from the values still in registers -------------------
+      // F^T v (ForcePAOperator::MultTranspose, laghos_assembly.cpp:859-921: the point integrand above tested
+      // with the L2 basis) is SolveEnergy's right-hand side for the velocity block of THIS state, and F.1
+      // (ForcePA->Mult(one), :296-514 with x = 1 - the Bernstein functions sum to one, so the interpolated
+      // `one` is 1 at every point: Y(d, c) = sum_q sum_gd stressJinvT(q, gd, c) d_gd phi_d(q)) is
+      // SolveVelocity's.  Formed here they cost a few LDS contractions (transposed sum factorisation z -> y -> x)
+      // instead of two more passes over the 9 stressJinvT planes (2 x 510 MB at C2).  The stages of both share
+      // their barriers.  lgh_solve_velocity / lgh_solve_energy use the results when they are called for the
+      // state of the last update (and, for F^T v, with its own velocity).
+      const bool do_f = (DIM == 3) && (CPR > 0) && (a.force_e != nullptr);
+      const bool do_t = (a.erhs_q != nullptr);
+      if (do_f || do_t)
       {
-         // F^T v fused into the update (ForcePAOperator::MultTranspose, laghos_assembly.cpp:875-921: test the
-         // point values with the L2 basis): SolveEnergy's right-hand side for the velocity of THIS state costs
-         // three small LDS contractions here instead of a second pass over the 9 stressJinvT planes (510 MB at
-         // C2).  lgh_solve_energy uses it when its v is the velocity block of the state of the last update.
-         // the interpolation buffers of this element are free now: point values at their start, the z-contracted
-         // array behind them (with few fields per pass, Q5Q4, sX alone is smaller than the NQ point values)
-         static_assert(SU + SXs + SYs >= NQ + ((DIM == 3) ? L * Q * Q : 0), "LDS: no room for the F^T v contraction");
-         double *sS = sU, *sT = sU + NQ;
-         __syncthreads(); // every thread has finished reading the interpolation buffers
-         sS[lt] = active ? ftv : 0.0;
-         __syncthreads();
-         if (DIM == 3)
+         const double eps2 = 2.220446049250313e-16 * 2.220446049250313e-16;
+         constexpr int CP = (CPR > 0) ? CPR : 1;
+         constexpr bool F3 = (DIM == 3) && (CPR > 0);
+         constexpr int OFF_A = F3 ? CP * 3 * NQ : 0;                   // sF: [cc][gd][q]
+         constexpr int OFF_S = OFF_A + (F3 ? CP * 3 * D * Q * Q : 0);  // sA: [cc][gd][dz][qy][qx]
+         constexpr int OFF_T = OFF_S + NQ;                                     // sS: point values of F^T v
+         static_assert(OFF_T + ((DIM == 3) ? L * Q * Q : 0) <= PER - 1 - SEs + NL, "LDS: no room for the force contractions");
+         double *sF = sU, *sA = sU + OFF_A, *sW = sU; // sW [cc][which][dz][dy][qx] over sF (dead by then)
+         double *sS = sU + OFF_S, *sT = sU + OFF_T;   // sT [lz][qy][qx] (3D)
+#pragma unroll 1
+         for (int c0 = 0; c0 < (do_f ? 3 : 1); c0 += CP)
          {
-            for (int i = lt; i < L * Q * Q; i += NTE)
+            const bool t_now = do_t && (c0 == 0);
+            __syncthreads(); // the buffers are free (interpolation / previous round done)
+            if constexpr (F3)
             {
-               const int qx = i % Q, qy = (i / Q) % Q, lz = i / (Q * Q);
-               double u = 0.0;
+               if (do_f)
+               {
 #pragma unroll
-               for (int qz = 0; qz < Q; qz++) { u += sBl[qz + Q * lz] * sS[qx + Q * (qy + Q * qz)]; }
-               sT[i] = u;
+                  for (int cc = 0; cc < CP; cc++)
+                  {
+#pragma unroll
+                     for (int gd = 0; gd < 3; gd++) { sF[lt + NQ * (gd + 3 * cc)] = sjw[gd + 3 * (c0 + cc)]; }
+                  }
+               }
             }
+            if (t_now) { sS[lt] = active ? ftv : 0.0; }
             __syncthreads();
-            for (int i = lt; i < L * L * Q; i += NTE)
+            if constexpr (DIM == 3)
             {
-               const int qx = i % Q, ly = (i / Q) % L, lz = i / (Q * L);
-               double u = 0.0;
+               // ---- z
+               if (do_f)
+               {
+                  for (int i = lt; i < CP * 3 * D * Q * Q; i += NTE)
+                  {
+                     const int qx = i % Q, qy = (i / Q) % Q, dz = (i / (Q * Q)) % D, k = i / (Q * Q * D); // k = gd + 3 cc
+                     const double *tab = ((k % 3) == 2) ? sG : sB;
+                     double u = 0.0;
 #pragma unroll
-               for (int qy = 0; qy < Q; qy++) { u += sBl[qy + Q * ly] * sT[qx + Q * (qy + Q * lz)]; }
-               sE1[i] = u;
+                     for (int qz = 0; qz < Q; qz++) { u += tab[qz + Q * dz] * sF[qx + Q * (qy + Q * qz) + NQ * k]; }
+                     sA[i] = u;
+                  }
+               }
+               if (t_now)
+               {
+                  for (int i = lt; i < L * Q * Q; i += NTE)
+                  {
+                     const int qx = i % Q, qy = (i / Q) % Q, lz = i / (Q * Q);
+                     double u = 0.0;
+#pragma unroll
+                     for (int qz = 0; qz < Q; qz++) { u += sBl[qz + Q * lz] * sS[qx + Q * (qy + Q * qz)]; }
+                     sT[i] = u;
+                  }
+               }
+               __syncthreads();
+               // ---- y
+               if (do_f)
+               {
+                  for (int i = lt; i < CP * 2 * D * D * Q; i += NTE)
+                  {
+                     const int qx = i % Q, dy = (i / Q) % D, dz = (i / (Q * D)) % D, wh = (i / (Q * D * D)) % 2, cc = i / (Q * D * D * 2);
+                     const double *a0 = sA + D * Q * Q * (0 + 3 * cc) + Q * Q * dz + qx;
+                     const double *a1 = sA + D * Q * Q * (1 + 3 * cc) + Q * Q * dz + qx;
+                     const double *a2 = sA + D * Q * Q * (2 + 3 * cc) + Q * Q * dz + qx;
+                     double u = 0.0;
+                     if (wh == 0)
+                     {
+#pragma unroll
+                        for (int qy = 0; qy < Q; qy++) { u += sB[qy + Q * dy] * a0[Q * qy]; } // gd 0: G in x below
+                     }
+                     else
+                     {
+#pragma unroll
+                        for (int qy = 0; qy < Q; qy++) { u += sG[qy + Q * dy] * a1[Q * qy] + sB[qy + Q * dy] * a2[Q * qy]; }
+                     }
+                     sW[i] = u;
+                  }
+               }
+               if (t_now)
+               {
+                  for (int i = lt; i < L * L * Q; i += NTE)
+                  {
+                     const int qx = i % Q, ly = (i / Q) % L, lz = i / (Q * L);
+                     double u = 0.0;
+#pragma unroll
+                     for (int qy = 0; qy < Q; qy++) { u += sBl[qy + Q * ly] * sT[qx + Q * (qy + Q * lz)]; }
+                     sE1[i] = u;
+                  }
+               }
+               __syncthreads();
+               // ---- x
+               if (do_f)
+               {
+                  for (int i = lt; i < CP * ND; i += NTE)
+                  {
+                     const int dx = i % D, dy = (i / D) % D, dz = (i / (D * D)) % D, cc = i / ND;
+                     const double *wg = sW + Q * (dy + D * (dz + D * (0 + 2 * cc)));
+                     const double *wb = sW + Q * (dy + D * (dz + D * (1 + 2 * cc)));
+                     double r = 0.0;
+#pragma unroll
+                     for (int qx = 0; qx < Q; qx++) { r += sG[qx + Q * dx] * wg[qx] + sB[qx + Q * dx] * wb[qx]; }
+                     if (fabs(r) < eps2) { r = 0.0; } // laghos_assembly.cpp:495-512
+                     if (active) { a.force_e[dx + D * (dy + D * dz) + (size_t)ND * ((c0 + cc) + 3 * (size_t)e)] = r; }
+                  }
+               }
+               if (t_now)
+               {
+                  for (int i = lt; i < NL; i += NTE)
+                  {
+                     const int lx = i % L, ly = (i / L) % L, lz = i / (L * L);
+                     double u = 0.0;
+#pragma unroll
+                     for (int qx = 0; qx < Q; qx++) { u += sBl[qx + Q * lx] * sE1[qx + Q * (ly + L * lz)]; }
+                     if (active) { a.erhs_q[(size_t)e * NL + i] = u; }
+                  }
+               }
             }
-            __syncthreads();
-            for (int i = lt; i < NL; i += NTE)
+            else if (t_now)
             {
-               const int lx = i % L, ly = (i / L) % L, lz = i / (L * L);
-               double u = 0.0;
+               for (int i = lt; i < L * Q; i += NTE)
+               {
+                  const int qx = i % Q, ly = i / Q;
+                  double u = 0.0;
 #pragma unroll
-               for (int qx = 0; qx < Q; qx++) { u += sBl[qx + Q * lx] * sE1[qx + Q * (ly + L * lz)]; }
-               if (active) { a.erhs_q[(size_t)e * NL + i] = u; }
-            }
-         }
-         else
-         {
-            for (int i = lt; i < L * Q; i += NTE)
-            {
-               const int qx = i % Q, ly = i / Q;
-               double u = 0.0;
+                  for (int qy = 0; qy < Q; qy++) { u += sBl[qy + Q * ly] * sS[qx + Q * qy]; }
+                  sE1[i] = u;
+               }
+               __syncthreads();
+               for (int i = lt; i < NL; i += NTE)
+               {
+                  const int lx = i % L, ly = i / L;
+                  double u = 0.0;
 #pragma unroll
-               for (int qy = 0; qy < Q; qy++) { u += sBl[qy + Q * ly] * sS[qx + Q * qy]; }
-               sE1[i] = u;
-            }
-            __syncthreads();
-            for (int i = lt; i < NL; i += NTE)
-            {
-               const int lx = i % L, ly = i / L;
-               double u = 0.0;
-#pragma unroll
-               for (int qx = 0; qx < Q; qx++) { u += sBl[qx + Q * lx] * sE1[qx + Q * ly]; }
-               if (active) { a.erhs_q[(size_t)e * NL + i] = u; }
+                  for (int qx = 0; qx < Q; qx++) { u += sBl[qx + Q * lx] * sE1[qx + Q * ly]; }
+                  if (active) { a.erhs_q[(size_t)e * NL + i] = u; }
+               }
             }
          }
       }
@@ -629,6 +733,7 @@ static QArgs q_base(lgh_ctx *c)
    a.vort = c->vort;
    a.tiny_grad = c->q_tiny_grad;
    a.erhs_q = c->erhs_q;
+   a.force_e = (c->dim == 3) ? c->force_e_q : nullptr;
    return a;
 }
 
@@ -642,6 +747,7 @@ int qupdate(lgh_ctx *c, const double *S)
    const int rc = launch_q<QMODE_UPDATE>(c, a);
    // F^T v of this state's velocity block is now in c->erhs_q (lgh_solve_energy)
    c->erhs_state = (rc == LGH_OK && c->erhs_q) ? S : nullptr;
+   c->force_e_state = (rc == LGH_OK && a.force_e) ? S : nullptr;
    return rc;
 }
 
