@@ -127,6 +127,12 @@ int lgh_qupdate(lgh_ctx *ctx, const double *S);
  * identical for exact zeros; for values below the threshold the stress differs by < visc_coeff * tiny_grad.
  * Default 1e-30 (LGH_Q_TINY_GRAD overrides); 0 = exact zeros only; negative = always decompose. */
 int lgh_qupdate_set_tiny_grad(lgh_ctx *ctx, double tiny_grad);
+/* lgh_qupdate also forms the two force products of the state it is called for - F.1 as E-vector (3D) and
+ * F^T v for the state's own velocity - from the stress values it has in registers; lgh_solve_velocity and
+ * lgh_solve_energy use them instead of a pass over stressJinvT each when they are called for that state (and
+ * lgh_solve_energy with that velocity; `one_l2` is checked to be all ones).  on = 0 switches that off: the
+ * force products then always come from the ForcePAOperator kernels (per-kernel timing, A/B).  Default on. */
+int lgh_set_fused_forces(lgh_ctx *ctx, int on);
 
 /* ---- LagrangianHydroOperator pieces kept together for launch efficiency
  * (laghos_solver.cpp:329-399, :442-490).  dS_dt = [dx|dv|de]; one_l2 is the

@@ -804,6 +804,15 @@ int lgh_ktime_end(lgh_ctx *c, int *launches, double *mean_seconds)
    return LGH_OK;
 }
 
+int lgh_set_fused_forces(lgh_ctx *c, int on)
+{
+   LGH_CHECK_ARG(c);
+   c->fused_forces_off = on ? 0 : 1;
+   c->force_e_state = nullptr;
+   c->erhs_state = nullptr;
+   return LGH_OK;
+}
+
 int lgh_qupdate_set_tiny_grad(lgh_ctx *c, double tiny_grad)
 {
    LGH_CHECK_ARG(c);

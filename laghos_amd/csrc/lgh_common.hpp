@@ -116,6 +116,7 @@ struct lgh_ctx
    double *force_e_q;    // NE*ND*dim: F.1 as E-vector formed inside the fused QUpdate (3D) for ...
    const double *force_e_state; // ... this state vector, or nullptr
    const double *one_checked;   // the caller's `one` L2 vector that has been verified to be all ones
+   int fused_forces_off;        // lgh_set_fused_forces(ctx, 0): the update forms no force products (measurement / A-B)
    // scratch
    double *XE;           // max(L2V, NE*ND*dim)
    double *YE;           // NE*ND*dim

@@ -732,8 +732,8 @@ static QArgs q_base(lgh_ctx *c)
    a.visc = c->visc;
    a.vort = c->vort;
    a.tiny_grad = c->q_tiny_grad;
-   a.erhs_q = c->erhs_q;
-   a.force_e = (c->dim == 3) ? c->force_e_q : nullptr;
+   a.erhs_q = c->fused_forces_off ? nullptr : c->erhs_q;
+   a.force_e = (c->dim == 3 && !c->fused_forces_off) ? c->force_e_q : nullptr;
    return a;
 }
 
@@ -746,7 +746,7 @@ int qupdate(lgh_ctx *c, const double *S)
    a.result = c->dt_est_dev;
    const int rc = launch_q<QMODE_UPDATE>(c, a);
    // F^T v of this state's velocity block is now in c->erhs_q (lgh_solve_energy)
-   c->erhs_state = (rc == LGH_OK && c->erhs_q) ? S : nullptr;
+   c->erhs_state = (rc == LGH_OK && a.erhs_q) ? S : nullptr;
    c->force_e_state = (rc == LGH_OK && a.force_e) ? S : nullptr;
    return rc;
 }
