@@ -236,6 +236,192 @@ mass_apply_3d(const MassArgs a)
    }
 }
 
+// ---------------------------------------------------------------------------
+// L2 mass apply for the high orders (Q1D >= 8: Q4Q3, Q5Q4), plane-per-thread form.
+// The column form above keeps Q*Q threads per element and the quadrature data of one z-column per thread:
+// at Q1D = 10 that is one wave per SIMD (NEB = 2 elements per workgroup) and the kernel reaches 1.7 TB/s,
+// and the unpreconditioned energy CG (237 iterations per solve at Q5Q4) makes it the dominant kernel of
+// BASELINE config 5.  Here a thread owns one x-index qx of an element and keeps (y, z) data of that index in
+// registers (as vcg_apply_plane does for the H1 solve): only the two x contractions go through LDS, and
+// 256 / (Q HY) elements share a workgroup, two workgroups per CU.
+// Register budget: the plane w[qy][dz] (Q*L doubles) AND the 1-D table (Q*L doubles - too large for the
+// scalar registers at 50 entries, and re-reading it from LDS per use would make the kernel LDS-issue bound)
+// both want registers.  At Q = 10 that is 2 x 100 VGPRs and does not fit, so the qy rows of a plane are split
+// over HY = 2 threads: thread (qx, h) runs the rows qy in [h Q/HY, (h+1) Q/HY) through the z stage (the rows are
+// independent there) and contributes a partial sum to the backward y contraction; the HY partial planes are
+// summed by the backward x contraction, which reads them from LDS anyway.
+// The quadrature data is read straight from memory, one qy row of Q values ahead of its use (each value is
+// needed by exactly one thread: LDS staging would only add traffic); rows of Q consecutive doubles.
+// MODE 0: y = M x.  MODE 3: CG K1 of the L2 solve (d = r + beta d stored in place, den = (d, M d)).
+template <int L, int Q, int HY, int NEB, int MODE>
+__global__ void __launch_bounds__(Q *HY *NEB, 2)
+mass_apply_l2_plane(const MassArgs a)
+{
+   constexpr int NQ = Q * Q * Q, NL = L * L * L, LL = L * L;
+   constexpr int TE = Q * HY, NT = TE * NEB, QH = Q / HY;
+   static_assert(Q % HY == 0, "qy rows split evenly");
+   constexpr int CS = NL | 1;            // odd strides: the broadcast reads of different elements hit different banks
+   constexpr int CE = (HY * LL * Q) | 1; // [h][dy,dz][qx]
+   __shared__ double sIn[NEB * CS], sE[NEB * CE], sB[Q * L];
+   __shared__ double red[16];
+   const int tid = threadIdx.x;
+   const int eb = tid / TE, lt = tid - eb * TE;
+   const int h = lt / Q, qx = lt - h * Q;
+   const int e0 = blockIdx.x * NEB, e = e0 + eb;
+   const bool active = (e < a.NE);
+   double beta = 0.0;
+   bool first = false;
+   if (MODE == 3)
+   {
+      if (a.cgs->done) { return; }
+      first = a.cgs->first != 0;
+      beta = first ? 0.0 : a.cgs->rz / a.cgs->rz_prev;
+   }
+   for (int i = tid; i < Q * L; i += NT) { sB[i] = a.B[i]; }
+   {
+      const int nel = min(NEB, a.NE - e0);
+      for (int i = tid; i < nel * NL; i += NT)
+      {
+         const int el = i / NL, d = i - el * NL;
+         const size_t p = (size_t)e0 * NL + i;
+         double val = a.x[p];
+         if (MODE == 3)
+         {
+            if (!first) { val += beta * a.d[p]; }
+            a.d[p] = val;
+         }
+         sIn[el * CS + d] = val;
+      }
+   }
+   // first row of this thread's quadrature data, in flight across the barrier
+   const double *Dp = a.Dq + (size_t)(active ? e : 0) * NQ + qx + Q * (h * QH);
+   double dq[Q];
+#pragma unroll
+   for (int qz = 0; qz < Q; qz++) { dq[qz] = Dp[Q * Q * qz]; }
+   __syncthreads();
+   const double *sI = sIn + eb * CS;
+   // the 1-D table in registers (every lane holds the same values; the scalar file has no room for them)
+   double Bt[Q * L];
+#pragma unroll
+   for (int i = 0; i < Q * L; i++) { Bt[i] = sB[i]; }
+   // forward x: t[dy,dz] = sum_dx B[qx,dx] d[dx,dy,dz]   (the HY threads of a plane each form it)
+   double t[LL];
+   {
+      double bx[L];
+#pragma unroll
+      for (int dx = 0; dx < L; dx++) { bx[dx] = sB[qx + Q * dx]; }
+#pragma unroll
+      for (int k = 0; k < LL; k++)
+      {
+         double u = 0.0;
+#pragma unroll
+         for (int dx = 0; dx < L; dx++) { u = fma(bx[dx], sI[dx + L * k], u); }
+         t[k] = u;
+      }
+   }
+   // this thread's rows: forward y, then per row forward z, scaling, backward z; partial backward y on the fly
+   double acc[LL]; // [dy + L*dz]: sum over this thread's qy rows of B[qy,dy] w[qy][dz]
+#pragma unroll
+   for (int k = 0; k < LL; k++) { acc[k] = 0.0; }
+#pragma unroll
+   for (int r = 0; r < QH; r++)
+   {
+      double dn[Q];
+      if (r + 1 < QH)
+      {
+#pragma unroll
+         for (int qz = 0; qz < Q; qz++) { dn[qz] = Dp[Q * (r + 1) + Q * Q * qz]; }
+      }
+      // the table row of qy = h*QH + r (h differs between lanes: select, not index)
+      double by[L];
+#pragma unroll
+      for (int dy = 0; dy < L; dy++)
+      {
+         double v = Bt[r + Q * dy];
+#pragma unroll
+         for (int hh = 1; hh < HY; hh++) { v = (h == hh) ? Bt[hh * QH + r + Q * dy] : v; }
+         by[dy] = v;
+      }
+      double wr[L];
+#pragma unroll
+      for (int dz = 0; dz < L; dz++)
+      {
+         double u = 0.0;
+#pragma unroll
+         for (int dy = 0; dy < L; dy++) { u = fma(by[dy], t[dy + L * dz], u); }
+         wr[dz] = u;
+      }
+      double cz[Q];
+#pragma unroll
+      for (int qz = 0; qz < Q; qz++)
+      {
+         double u = 0.0;
+#pragma unroll
+         for (int dz = 0; dz < L; dz++) { u = fma(Bt[qz + Q * dz], wr[dz], u); }
+         cz[qz] = u * dq[qz];
+      }
+#pragma unroll
+      for (int dz = 0; dz < L; dz++)
+      {
+         double u = 0.0;
+#pragma unroll
+         for (int qz = 0; qz < Q; qz++) { u = fma(Bt[qz + Q * dz], cz[qz], u); }
+#pragma unroll
+         for (int dy = 0; dy < L; dy++) { acc[dy + L * dz] = fma(by[dy], u, acc[dy + L * dz]); }
+      }
+      if (r + 1 < QH)
+      {
+#pragma unroll
+         for (int qz = 0; qz < Q; qz++) { dq[qz] = dn[qz]; }
+      }
+   }
+   double *sEe = sE + eb * CE + h * (LL * Q);
+#pragma unroll
+   for (int k = 0; k < LL; k++) { sEe[qx + Q * k] = acc[k]; }
+   __syncthreads();
+   // backward x: thread (lx = qx < L, h) sums the Q planes of both halves for its share of the (dy,dz) pairs
+   double dot = 0.0;
+   if (qx < L && active)
+   {
+      const double *sEa = sE + eb * CE;
+      double bt[Q];
+#pragma unroll
+      for (int q = 0; q < Q; q++) { bt[q] = sB[q + Q * qx]; }
+      constexpr int KH = (LL + HY - 1) / HY;
+#pragma unroll
+      for (int kk = 0; kk < KH; kk++)
+      {
+         const int k = h * KH + kk;
+         if (k < LL)
+         {
+            double u = 0.0;
+#pragma unroll
+            for (int hh = 0; hh < HY; hh++)
+            {
+#pragma unroll
+               for (int q = 0; q < Q; q++) { u = fma(bt[q], sEa[hh * (LL * Q) + q + Q * k], u); }
+            }
+            a.y[(size_t)e * NL + qx + L * k] = u;
+            if (MODE == 3) { dot = fma(sI[qx + L * k], u, dot); }
+         }
+      }
+   }
+   if (MODE == 3)
+   {
+      const double bsum = block_sum(dot, red);
+      double total;
+      if (grid_sum_last_block(bsum, a.partials, a.ticket, red, total))
+      {
+         if (tid == 0)
+         {
+            a.cgs->den = total;
+            if (a.cgs->first) { a.cgs->first = 0; }
+            if (total == 0.0 && !a.multi) { a.cgs->done = 1; } // breakdown (den == 0): stop, as upstream
+         }
+      }
+   }
+}
+
 // 2D: one thread per quadrature point; same MODE semantics.
 template <int D, int Q, int NEB, int MODE>
 __global__ void __launch_bounds__(Q *Q *NEB)
@@ -352,6 +538,17 @@ template <int MODE> static int launch_mass(lgh_ctx *c, int space, const MassArgs
                          dim3(Q_ * Q_ * NEB_), 0, c->stream, a);                              \
    }                                                                                          \
    break
+   if ((MODE == 0 || MODE == 3) && space == LGH_SPACE_L2 && (id == 0x348 || id == 0x35A))
+   {
+      static const char *penv = getenv("LGH_L2_PLANE"); // A/B: 0 = column form
+      if (!(penv && penv[0] == '0'))
+      {
+         if (id == 0x348) { hipLaunchKernelGGL((mass_apply_l2_plane<4, 8, 1, 32, (MODE == 3 ? 3 : 0)>), dim3(ceil_div(c->NE, 32)), dim3(256), 0, c->stream, a); }
+         else { hipLaunchKernelGGL((mass_apply_l2_plane<5, 10, 2, 12, (MODE == 3 ? 3 : 0)>), dim3(ceil_div(c->NE, 12)), dim3(240), 0, c->stream, a); }
+         LGH_HIP_CHECK(hipGetLastError());
+         return LGH_OK;
+      }
+   }
    switch (id)
    {
       case 0x212: LGH_MASS_CASE(mass_apply_2d, 1, 2);
