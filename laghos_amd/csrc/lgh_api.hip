@@ -268,7 +268,7 @@ static int create_impl(const lgh_config *cfg, lgh_ctx *c, const int kid)
       const char *env = getenv("LGH_ATOMIC_SCATTER");
       c->atomic_scatter = (env && env[0] == '1') ? 1 : 0;
       env = getenv("LGH_VCG_VARIANT"); // A/B switch of the lockstep K1 (lgh_vcg.hip)
-      c->vcg_variant = (env && env[0] >= '0' && env[0] <= '2') ? env[0] - '0' : 2;
+      c->vcg_variant = (env && env[0] >= '0' && env[0] <= '9') ? env[0] - '0' : 2;
    }
    for (int k = 0; k < 3; k++)
    {
@@ -642,14 +642,15 @@ int lgh_solve_energy(lgh_ctx *c, const double *S, const double *v_h1, double *dS
 // and the first chunk of the L2 CG on the second stream behind a fork event, _end
 // completes the solve and joins.  Falls back to the sequential lgh_solve_energy
 // inside _end when region timers / kernel timing are on (their semantics are
-// sequential, as in the reference), on several ranks (one RCCL communicator must not
-// be driven from two streams), or when the velocity solve would use the scalar CG
-// (shared scratch).  LGH_OVERLAP=0 switches it off.
+// sequential, as in the reference), on several ranks without a second communicator
+// (one RCCL communicator must not be driven from two streams: lgh_comm_init creates a
+// second one for this), or when the velocity solve would use the scalar CG (shared
+// scratch).  LGH_OVERLAP=0 switches it off.
 static bool energy_overlap_ok(const lgh_ctx *c)
 {
    static const bool on = !(getenv("LGH_OVERLAP") && getenv("LGH_OVERLAP")[0] == '0');
    // the persistent solve kernel (lgh_pcg.hip) needs all its workgroups resident: nothing runs beside it
-   return on && c->multi == 0 && !c->timers.enabled && !(c->ktime && c->ktime->which >= 0) && vcg_available(c) &&
+   return on && (c->multi == 0 || comm_second_channel(c)) && !c->timers.enabled && !(c->ktime && c->ktime->which >= 0) && vcg_available(c) &&
           !pcg_available(c);
 }
 int lgh_solve_energy_begin(lgh_ctx *c, const double *S, const double *v_h1, double *dS_dt, double *e_rhs,
@@ -671,10 +672,12 @@ int lgh_solve_energy_begin(lgh_ctx *c, const double *S, const double *v_h1, doub
    LGH_HIP_CHECK(hipEventRecord(c->ev_fork, c->stream));
    LGH_HIP_CHECK(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
    std::swap(c->stream, c->stream2); // everything below is enqueued on the second stream
+   c->on_stream2 = 1;
    int rc = energy_rhs(c, v_h1, e_rhs); // :473
    if (rc == LGH_OK && e_source) { rc = vec_axpby(c, e_rhs, 1.0, e_rhs, 1.0, e_source, c->L2V); } // :477
    if (rc == LGH_OK) { rc = cg_l2_begin(c, e_rhs, dS_dt + 2 * (size_t)c->H1V, rel_tol, max_iter); } // :481
    std::swap(c->stream, c->stream2);
+   c->on_stream2 = 0;
    if (rc) { return rc; }
    c->e_async = 1;
    return LGH_OK;
@@ -691,9 +694,11 @@ int lgh_solve_energy_end(lgh_ctx *c, int *l2_iters)
    }
    int it = 0;
    std::swap(c->stream, c->stream2);
+   c->on_stream2 = 1;
    int rc = cg_l2_end(c, &it);
    if (rc == LGH_OK) { rc = (hipEventRecord(c->ev_join, c->stream) == hipSuccess) ? LGH_OK : LGH_ERR_HIP; }
    std::swap(c->stream, c->stream2);
+   c->on_stream2 = 0;
    if (rc) { return rc; }
    LGH_HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
    const int counted = (it == 0) ? 1 : it; // :486

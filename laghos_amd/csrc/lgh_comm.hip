@@ -45,6 +45,7 @@ struct NcclApi
    int (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
    int (*CommDestroy)(ncclComm_t) = nullptr;
    int (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+   int (*Broadcast)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr; // optional
    int (*Send)(const void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
    int (*Recv)(void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
    int (*GroupStart)() = nullptr;
@@ -79,6 +80,7 @@ static int load_nccl()
    LGH_SYM(GroupEnd, "ncclGroupEnd");
    LGH_SYM(GetErrorString, "ncclGetErrorString");
 #undef LGH_SYM
+   *(void **)(&g_nccl.Broadcast) = dlsym(h, "ncclBroadcast");
    return LGH_OK;
 }
 
@@ -140,6 +142,12 @@ static std::map<std::string, std::shared_ptr<LocalGroup>> g_local;
 struct Comm
 {
    ncclComm_t comm = nullptr;
+   // Second channel: a communicator and message buffers of its own for the stream the energy solve runs on
+   // beside the velocity solve (lgh_solve_energy_begin/_end) - one communicator must not be driven from two
+   // streams.  It only ever carries sums of scalars.  Present on every rank or on none (decided collectively).
+   ncclComm_t comm2 = nullptr;
+   bool channel2 = false;
+   double *sendbuf2 = nullptr, *recvbuf2 = nullptr;
    std::shared_ptr<LocalGroup> local;
    int n_nbr = 0;
    std::vector<int> nbr_rank, nbr_count, nbr_off, nbr_base; // node offsets / buffer bases of the neighbours
@@ -238,18 +246,23 @@ int halo_sum(lgh_ctx *c, double *v, int ncomp, double *extra, int nextra)
    if (extra && (!cm->allpairs || nextra < 1 || nextra > 3)) { set_error("halo_sum: cannot piggy-back"); return LGH_ERR_ARG; }
    const int nx = extra ? nextra : 0;
    const int tot = cm->total;
+   const bool ch2 = c->on_stream2 != 0;
+   if (ch2 && (!cm->channel2 || ncomp != 0)) { set_error("halo_sum: the second channel carries scalars only"); return LGH_ERR_ARG; }
+   double *const sbuf = ch2 ? cm->sendbuf2 : cm->sendbuf;
+   double *const rbuf = ch2 ? cm->recvbuf2 : cm->recvbuf;
+   const ncclComm_t ncomm = ch2 ? cm->comm2 : cm->comm;
    // ncomp == 0 (v unused): the messages carry the scalars only - a sum over the ranks as one
    // exchange with every peer (allreduce_dev uses it in all-pairs partitions)
    const long npack = std::max((long)tot * ncomp, (long)cm->n_nbr * nx);
    hipLaunchKernelGGL(halo_pack_k, dim3(ceil_div(npack, 256)), dim3(256), 0, c->stream, tot,
-                      ncomp, c->N, cm->nodes, cm->pos, cm->cnt, v, cm->sendbuf, cm->n_nbr, nx, cm->d_base, cm->d_cnt,
+                      ncomp, c->N, cm->nodes, cm->pos, cm->cnt, v, sbuf, cm->n_nbr, nx, cm->d_base, cm->d_cnt,
                       extra);
    LGH_HIP_CHECK(hipGetLastError());
    auto combine = [&]() {
       const long ncomb = std::max((long)cm->n_shared * ncomp, (long)nx);
       hipLaunchKernelGGL(halo_combine_k, dim3(ceil_div(ncomb, 256)), dim3(256), 0,
                          c->stream, cm->n_shared, ncomp, c->N, cm->sh_node, cm->sh_off, cm->sh_src, cm->pos,
-                         cm->cnt, cm->recvbuf, v, c->nranks, nx, cm->rank_src, cm->d_base, cm->d_cnt, extra);
+                         cm->cnt, rbuf, v, c->nranks, nx, cm->rank_src, cm->d_base, cm->d_cnt, extra);
    };
    if (cm->local)
    {
@@ -266,7 +279,7 @@ int halo_sum(lgh_ctx *c, double *v, int ncomp, double *extra, int nextra)
             set_error("local communicator: neighbour lists of ranks %d and %d do not match", c->rank, cm->nbr_rank[k]);
             return LGH_ERR_COMM;
          }
-         LGH_HIP_CHECK(hipMemcpyAsync(cm->recvbuf + cm->nbr_base[k], pc->sendbuf + pc->nbr_base[kk],
+         LGH_HIP_CHECK(hipMemcpyAsync(rbuf + cm->nbr_base[k], (ch2 ? pc->sendbuf2 : pc->sendbuf) + pc->nbr_base[kk],
                                       ((size_t)ncomp * cm->nbr_count[k] + nx) * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
       }
       LGH_HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -280,14 +293,17 @@ int halo_sum(lgh_ctx *c, double *v, int ncomp, double *extra, int nextra)
    {
       const size_t o = (size_t)cm->nbr_base[k];
       const size_t n = (size_t)ncomp * cm->nbr_count[k] + nx;
-      LGH_NCCL_CHECK(g_nccl.Send(cm->sendbuf + o, n, ncclFloat64, cm->nbr_rank[k], cm->comm, c->stream));
-      LGH_NCCL_CHECK(g_nccl.Recv(cm->recvbuf + o, n, ncclFloat64, cm->nbr_rank[k], cm->comm, c->stream));
+      LGH_NCCL_CHECK(g_nccl.Send(sbuf + o, n, ncclFloat64, cm->nbr_rank[k], ncomm, c->stream));
+      LGH_NCCL_CHECK(g_nccl.Recv(rbuf + o, n, ncclFloat64, cm->nbr_rank[k], ncomm, c->stream));
    }
    LGH_NCCL_CHECK(g_nccl.GroupEnd());
    combine();
    LGH_HIP_CHECK(hipGetLastError());
    return LGH_OK;
 }
+
+// may the energy solve run its reductions on the context's second stream?
+bool comm_second_channel(const lgh_ctx *c) { return c->comm && c->comm->channel2; }
 
 void comm_shared_nodes(const lgh_ctx *c, const uint8_t **hmask, const int **sh_node, int *n_shared)
 {
@@ -335,7 +351,9 @@ int allreduce_dev(lgh_ctx *c, double *dev, int count, int op)
       return LGH_OK;
    }
    if (!cm || !cm->comm) { return LGH_OK; }
-   LGH_NCCL_CHECK(g_nccl.AllReduce(dev, dev, (size_t)count, ncclFloat64, op == 0 ? ncclSum : ncclMin, cm->comm, c->stream));
+   if (c->on_stream2 && !cm->comm2) { set_error("all-reduce on the second stream without a second communicator"); return LGH_ERR_COMM; }
+   LGH_NCCL_CHECK(g_nccl.AllReduce(dev, dev, (size_t)count, ncclFloat64, op == 0 ? ncclSum : ncclMin,
+                                   c->on_stream2 ? cm->comm2 : cm->comm, c->stream));
    return LGH_OK;
 }
 
@@ -365,8 +383,9 @@ void lgh_comm_free(lgh_ctx *c)
          else { ++it; }
       }
    }
+   if (cm->comm2 && g_nccl.CommDestroy) { g_nccl.CommDestroy(cm->comm2); }
    if (cm->comm && g_nccl.CommDestroy) { g_nccl.CommDestroy(cm->comm); }
-   void *ptrs[] = {cm->nodes, cm->sendbuf, cm->recvbuf, cm->sh_node, cm->sh_off, cm->sh_src, cm->pos, cm->cnt, cm->hmask,
+   void *ptrs[] = {cm->nodes, cm->sendbuf, cm->recvbuf, cm->sendbuf2, cm->recvbuf2, cm->sh_node, cm->sh_off, cm->sh_src, cm->pos, cm->cnt, cm->hmask,
                    cm->d_base, cm->d_cnt, cm->rank_src};
    for (void *p : ptrs) { if (p) { (void)hipFree(p); } }
    delete cm;
@@ -407,6 +426,7 @@ int lgh_comm_init(lgh_ctx *c, int nranks, int rank, const char unique_id[128])
          g = slot;
       }
       c->comm->local = g;
+      c->comm->channel2 = !(getenv("LGH_COMM2") && getenv("LGH_COMM2")[0] == '0');
       c->nranks = nranks;
       c->rank = rank;
       c->multi = 1;
@@ -425,6 +445,33 @@ int lgh_comm_init(lgh_ctx *c, int nranks, int rank, const char unique_id[128])
    {
       const char *env = getenv("LGH_FORCE_MULTI");
       c->multi = (nranks > 1 || (env && env[0] == '1')) ? 1 : 0;
+   }
+   // Second communicator (same ranks) for the second stream: its id is drawn by rank 0 and travels over the
+   // first one.  Collective; the outcome is agreed on by a MIN over the ranks, so either every rank has it
+   // (and overlaps the energy solve with the velocity solve) or none does.  LGH_COMM2=0 (set on every rank)
+   // skips it.
+   if (c->multi && g_nccl.Broadcast && !(getenv("LGH_COMM2") && getenv("LGH_COMM2")[0] == '0'))
+   {
+      Comm *cm = c->comm;
+      char *dbuf = nullptr;
+      LGH_HIP_CHECK(hipMalloc((void **)&dbuf, 128 + sizeof(double)));
+      ncclUniqueId id2;
+      memset(&id2, 0, sizeof(id2));
+      double ok = 1.0;
+      if (rank == 0 && g_nccl.GetUniqueId(&id2) != ncclSuccess) { ok = 0.0; }
+      LGH_HIP_CHECK(hipMemcpy(dbuf, id2.internal, 128, hipMemcpyHostToDevice));
+      LGH_NCCL_CHECK(g_nccl.Broadcast(dbuf, dbuf, 128, /* ncclChar */ 0, 0, cm->comm, c->stream));
+      LGH_HIP_CHECK(hipStreamSynchronize(c->stream));
+      LGH_HIP_CHECK(hipMemcpy(id2.internal, dbuf, 128, hipMemcpyDeviceToHost));
+      if (ok != 0.0 && g_nccl.CommInitRank(&cm->comm2, nranks, id2, rank) != ncclSuccess) { ok = 0.0; cm->comm2 = nullptr; }
+      double *dok = (double *)(dbuf + 128);
+      LGH_HIP_CHECK(hipMemcpy(dok, &ok, sizeof(double), hipMemcpyHostToDevice));
+      LGH_NCCL_CHECK(g_nccl.AllReduce(dok, dok, 1, ncclFloat64, ncclMin, cm->comm, c->stream));
+      LGH_HIP_CHECK(hipStreamSynchronize(c->stream));
+      LGH_HIP_CHECK(hipMemcpy(&ok, dok, sizeof(double), hipMemcpyDeviceToHost));
+      (void)hipFree(dbuf);
+      cm->channel2 = (ok != 0.0);
+      if (!cm->channel2 && cm->comm2) { g_nccl.CommDestroy(cm->comm2); cm->comm2 = nullptr; }
    }
    return LGH_OK;
 }
@@ -531,6 +578,15 @@ int lgh_comm_set_neighbors(lgh_ctx *c, int n_nbr, const int *nbr_rank, const int
    LGH_HIP_CHECK(hipMalloc((void **)&cm->recvbuf, (size_t)cm->bufsize * sizeof(double)));
    LGH_HIP_CHECK(hipMemset(cm->sendbuf, 0, (size_t)cm->bufsize * sizeof(double)));
    LGH_HIP_CHECK(hipMemset(cm->recvbuf, 0, (size_t)cm->bufsize * sizeof(double)));
+   if (cm->channel2)
+   {
+      (void)hipFree(cm->sendbuf2);
+      (void)hipFree(cm->recvbuf2);
+      LGH_HIP_CHECK(hipMalloc((void **)&cm->sendbuf2, (size_t)cm->bufsize * sizeof(double)));
+      LGH_HIP_CHECK(hipMalloc((void **)&cm->recvbuf2, (size_t)cm->bufsize * sizeof(double)));
+      LGH_HIP_CHECK(hipMemset(cm->sendbuf2, 0, (size_t)cm->bufsize * sizeof(double)));
+      LGH_HIP_CHECK(hipMemset(cm->recvbuf2, 0, (size_t)cm->bufsize * sizeof(double)));
+   }
    LGH_HIP_CHECK(hipStreamSynchronize(nullptr)); // the fills run asynchronously on the null stream
    {
       // per-neighbour tables and the rank -> neighbour map of the piggy-backed scalars

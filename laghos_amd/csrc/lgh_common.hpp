@@ -85,6 +85,7 @@ struct lgh_ctx
    hipStream_t stream;
    // second stream + fork/join events: the energy solve overlaps the velocity solve (lgh_api.hip)
    hipStream_t stream2;
+   int on_stream2;       // 1 while `stream` holds the second stream (energy solve beside the velocity solve): reductions use the communicator's second channel
    hipEvent_t ev_fork, ev_join;
    void *l2run;          // state of a split L2 solve (lgh_mass.hip)
    const double *accel_src; // dim*N acceleration source of SolveVelocity (source_type 2) or nullptr
@@ -378,6 +379,7 @@ int vec_zero_list(lgh_ctx *c, double *y, const int *list, int n);
 int vec_dot(lgh_ctx *c, const double *x, const double *y, const double *w, long n, double *dev_out);
 int halo_sum(lgh_ctx *c, double *v, int ncomp, double *extra = nullptr, int nextra = 0);
 bool halo_can_piggyback(const lgh_ctx *c);
+bool comm_second_channel(const lgh_ctx *c); // reductions may run on the context's second stream as well
 int allreduce_dev(lgh_ctx *c, double *dev, int count, int op);
 
 // bracket one launch of kernel `id` with an event pair when sampling is on

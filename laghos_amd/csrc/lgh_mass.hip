@@ -49,7 +49,45 @@ struct MassArgs
    double *partials;
    unsigned int *ticket;
    int multi; // multi-GPU: den is all-reduced before any decision is taken on it
+   int iter;  // CG iteration this launch belongs to (several ranks: see cg_pending_update)
 };
+
+// Several ranks: the sums of den and (r, z) over the ranks complete outside the kernels that produce the
+// local parts, so the decisions they feed (breakdown, convergence, iteration count) are taken by the NEXT
+// kernel of the sequence instead of a single-thread kernel after every exchange: each workgroup evaluates the
+// same predicate on the same reduced values, and thread 0 of workgroup 0 also commits the outcome to the
+// state.  A commit only writes values under which the predicate stays true (done = 1, rz = den = 0: sums of
+// zeros stay zero in the exchanges of launches enqueued past convergence), so a thread that reads the
+// state after the commit decides like one that read it before.
+// K1 of iteration iter >= 2: outcome of the update of iteration iter - 1.
+__device__ __forceinline__ bool cg_pending_update(CgScalars *s, const int iter, const bool commit)
+{
+   const double rz = s->rz;
+   const bool conv = rz < 0.0 || rz <= s->r0;
+   if (commit)
+   {
+      // write-through stores: another XCD's L2 may hold the same line dirty (K1's last workgroup writes den / first)
+      __hip_atomic_store(&s->iters, iter - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (conv)
+      {
+         __hip_atomic_store(&s->done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+         __hip_atomic_store(&s->rz, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+         __hip_atomic_store(&s->den, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+   }
+   return conv;
+}
+// K2: breakdown (den == 0 after the sum over the ranks), as upstream
+__device__ __forceinline__ bool cg_pending_den(CgScalars *s, const bool commit)
+{
+   const bool brk = s->den == 0.0;
+   if (brk && commit)
+   {
+      __hip_atomic_store(&s->done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&s->rz, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+   }
+   return brk;
+}
 
 template <int D, int Q, int NEB, int MODE>
 __global__ void __launch_bounds__(Q *Q *NEB)
@@ -79,6 +117,7 @@ mass_apply_3d(const MassArgs a)
    {
       if (a.cgs->done) { return; }
       first = a.cgs->first != 0;
+      if (a.multi && !first && cg_pending_update(a.cgs, a.iter, blockIdx.x == 0 && threadIdx.x == 0)) { return; }
       beta = first ? 0.0 : a.cgs->rz / a.cgs->rz_prev;
    }
 
@@ -275,6 +314,7 @@ mass_apply_l2_plane(const MassArgs a)
    {
       if (a.cgs->done) { return; }
       first = a.cgs->first != 0;
+      if (a.multi && !first && cg_pending_update(a.cgs, a.iter, blockIdx.x == 0 && threadIdx.x == 0)) { return; }
       beta = first ? 0.0 : a.cgs->rz / a.cgs->rz_prev;
    }
    for (int i = tid; i < Q * L; i += NT) { sB[i] = a.B[i]; }
@@ -445,6 +485,7 @@ mass_apply_2d(const MassArgs a)
    {
       if (a.cgs->done) { return; }
       first = a.cgs->first != 0;
+      if (a.multi && !first && cg_pending_update(a.cgs, a.iter, blockIdx.x == 0 && threadIdx.x == 0)) { return; }
       beta = first ? 0.0 : a.cgs->rz / a.cgs->rz_prev;
    }
    {
@@ -816,6 +857,7 @@ cg_update_k(const CgVecArgs a)
 {
    __shared__ double red[16];
    if (a.cgs->done) { return; }
+   if (a.allreduce_pending && cg_pending_den(a.cgs, blockIdx.x == 0 && threadIdx.x == 0)) { return; }
    const double alpha = a.cgs->rz / a.cgs->den;
    // `first` was cleared by K1 of this iteration: iteration 1 is recognised by iter
    const bool it1 = (a.iter == 1);
@@ -926,14 +968,6 @@ __global__ void cg_update_finish_k(CgScalars *s, int iter)
    if (s->rz < 0.0 || s->rz <= s->r0) { s->done = 1; s->rz = 0.0; s->den = 0.0; }
 }
 
-// In multi-GPU runs a rank-local `done` can only be set from all-reduced values,
-// so every rank takes identical decisions.
-__global__ void cg_den_finish_k(CgScalars *s)
-{
-   if (s->done) { s->den = 0.0; return; }
-   if (s->den == 0.0) { s->done = 1; }
-}
-
 __global__ void cg_set_tol_k(CgScalars *s, double rel_tol2)
 {
    s->rel_tol2 = rel_tol2;
@@ -1018,6 +1052,8 @@ int cg_solve(lgh_ctx *c, int space, const double *b, double *x, double rel_tol, 
    bool first_look = true;
    while (!done)
    {
+      // several ranks: the outcome of the last enqueued update is still pending (cg_pending_update) - commit it
+      if (multi && it > 0) { hipLaunchKernelGGL(cg_update_finish_k, dim3(1), dim3(1), 0, c->stream, c->cgs, it); }
       LGH_HIP_CHECK(hipMemcpyAsync(hs, c->cgs, sizeof(CgScalars), hipMemcpyDeviceToHost, c->stream));
       LGH_HIP_CHECK(hipStreamSynchronize(c->stream));
       if (hs->done || it >= max_iter) { break; }
@@ -1027,6 +1063,7 @@ int cg_solve(lgh_ctx *c, int space, const double *b, double *x, double rel_tol, 
       for (; it < upto;)
       {
          ++it;
+         m.iter = it;
          kt_begin(c, h1 ? LGH_KERNEL_MASS_CG_H1 : LGH_KERNEL_MASS_CG_L2);
          rc = h1 ? launch_mass<2>(c, space, m) : launch_mass<3>(c, space, m);
          kt_end(c, h1 ? LGH_KERNEL_MASS_CG_H1 : LGH_KERNEL_MASS_CG_L2);
@@ -1069,17 +1106,15 @@ int cg_solve(lgh_ctx *c, int space, const double *b, double *x, double rel_tol, 
             }
             if (multi)
             {
-               rc = allreduce_dev(c, &c->cgs->den, 1, 0);
+               rc = allreduce_dev(c, &c->cgs->den, 1, 0); // breakdown is looked at by cg_update_k (cg_pending_den)
                if (rc) { return rc; }
-               hipLaunchKernelGGL(cg_den_finish_k, dim3(1), dim3(1), 0, c->stream, c->cgs);
             }
             v.yL = c->cg_y;
             hipLaunchKernelGGL((cg_update_k<false, 0>), dim3(nbu), dim3(256), 0, c->stream, v);
             if (multi)
             {
-               rc = allreduce_dev(c, &c->cgs->rz, 1, 0);
+               rc = allreduce_dev(c, &c->cgs->rz, 1, 0); // convergence is looked at by the next K1 (cg_pending_update)
                if (rc) { return rc; }
-               hipLaunchKernelGGL(cg_update_finish_k, dim3(1), dim3(1), 0, c->stream, c->cgs, it);
             }
          }
          LGH_HIP_CHECK(hipGetLastError());
@@ -1114,18 +1149,21 @@ static int l2_enqueue(lgh_ctx *c, L2Run *r, int upto)
    for (; r->it < upto;)
    {
       ++r->it;
+      r->m.iter = r->it;
       int rc = launch_mass<3>(c, LGH_SPACE_L2, r->m);
       if (rc) { return rc; }
+      if (r->m.multi) { rc = allreduce_dev(c, &c->cgs->den, 1, 0); if (rc) { return rc; } } // as cg_solve
       r->v.iter = r->it;
       hipLaunchKernelGGL((cg_update_k<false, 0>), dim3(r->nbu), dim3(256), 0, c->stream, r->v);
       LGH_HIP_CHECK(hipGetLastError());
+      if (r->m.multi) { rc = allreduce_dev(c, &c->cgs->rz, 1, 0); if (rc) { return rc; } }
    }
    return LGH_OK;
 }
 
 int cg_l2_begin(lgh_ctx *c, const double *b, double *x, double rel_tol, int max_iter)
 {
-   if (c->multi != 0) { return LGH_ERR_UNSUPPORTED; }
+   const bool multi = c->multi != 0; // several ranks: the caller has checked that the second stream has a communicator
    if (!c->l2run) { c->l2run = new L2Run(); }
    L2Run *r = (L2Run *)c->l2run;
    const int n = c->L2V;
@@ -1140,10 +1178,17 @@ int cg_l2_begin(lgh_ctx *c, const double *b, double *x, double rel_tol, int max_
    v.cgs = c->cgs;
    v.partials = c->partials;
    v.ticket = c->tickets;
+   v.allreduce_pending = multi ? 1 : 0;
    int rc = vec_set(c, x, 0.0, n); // the L2 solve starts from x = 0
    if (rc) { return rc; }
    hipLaunchKernelGGL(cg_init_k<false>, dim3(ceil_div(n, 256)), dim3(256), 0, c->stream, v);
    LGH_HIP_CHECK(hipGetLastError());
+   if (multi)
+   {
+      rc = allreduce_dev(c, &c->cgs->rz, 1, 0);
+      if (rc) { return rc; }
+      hipLaunchKernelGGL(cg_init_finish_k, dim3(1), dim3(1), 0, c->stream, c->cgs);
+   }
    MassArgs &m = r->m;
    m = base_args(c, LGH_SPACE_L2);
    m.x = c->cg_r;
@@ -1152,7 +1197,7 @@ int cg_l2_begin(lgh_ctx *c, const double *b, double *x, double rel_tol, int max_
    m.cgs = c->cgs;
    m.partials = c->partials + c->part_stride;
    m.ticket = c->tickets + 1 * kTicketSlot;
-   m.multi = 0;
+   m.multi = multi ? 1 : 0;
    m.d = c->cg_d0;
    v.d = c->cg_d0;
    v.d_in_place = 1;
@@ -1172,6 +1217,7 @@ int cg_l2_end(lgh_ctx *c, int *iters)
    CgScalars *hs = (CgScalars *)c->host_pinned;
    while (true)
    {
+      if (r->m.multi && r->it > 0) { hipLaunchKernelGGL(cg_update_finish_k, dim3(1), dim3(1), 0, c->stream, c->cgs, r->it); } // as cg_solve
       LGH_HIP_CHECK(hipMemcpyAsync(hs, c->cgs, sizeof(CgScalars), hipMemcpyDeviceToHost, c->stream));
       LGH_HIP_CHECK(hipStreamSynchronize(c->stream));
       if (hs->done || r->it >= r->max_iter) { break; }

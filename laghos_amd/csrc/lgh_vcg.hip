@@ -30,6 +30,52 @@ struct VcgScalars
    int nupd[kVC], pad2;    // vcg_update_p_k: iteration of that update (x lags one update behind when it is odd)
 };
 
+// Several ranks (see cg_pending_update, lgh_mass.hip): the sums of den and (r, z) over the ranks complete between
+// the kernels, and the decisions they feed are taken by the next kernel of the sequence - every workgroup evaluates
+// the same predicate on the same reduced values, thread 0 of workgroup 0 also commits the outcome (write-through
+// stores; a commit only writes values under which the predicate stays true).
+// K1 of iteration iter >= 2: outcome of the update of iteration iter - 1.  live[c]: component c still iterates.
+// Returns false when none does.
+__device__ __forceinline__ bool vcg_pending_update(VcgScalars *s, const int iter, const bool commit, bool live[kVC])
+{
+   bool any = false;
+#pragma unroll
+   for (int c = 0; c < kVC; c++)
+   {
+      bool dn = s->done[c] != 0;
+      if (!dn)
+      {
+         const double rz = s->rz[c];
+         dn = rz < 0.0 || rz <= s->r0[c];
+         if (commit)
+         {
+            __hip_atomic_store(&s->iters[c], iter - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (dn)
+            {
+               __hip_atomic_store(&s->done[c], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+               __hip_atomic_store(&s->rz[c], 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+               __hip_atomic_store(&s->den[c], 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+         }
+      }
+      live[c] = !dn;
+      any = any || !dn;
+   }
+   if (!any && commit) { __hip_atomic_store(&s->all_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+   return any;
+}
+// K2: breakdown of component c (den == 0 after the sum over the ranks), as upstream
+__device__ __forceinline__ bool vcg_pending_den(VcgScalars *s, const int c, const bool commit)
+{
+   const bool brk = s->den[c] == 0.0;
+   if (brk && commit)
+   {
+      __hip_atomic_store(&s->done[c], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&s->rz[c], 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+   }
+   return brk;
+}
+
 // three-value variant of grid_reduce_last_block (sum): partials[v*stride + i]
 __device__ __forceinline__ bool grid_sum3_last_block(const double bp[kVC], double *partials,
                                                      const unsigned stride, unsigned int *ticket,
@@ -211,11 +257,10 @@ vcg_apply_3d(const VcgArgs a, const int nbatch)
    bool todo[kVC];
    double beta[kVC];
 #pragma unroll
-   for (int c = 0; c < kVC; c++)
-   {
-      todo[c] = a.s->done[c] == 0;
-      beta[c] = (first || !todo[c]) ? 0.0 : a.s->rz[c] / a.s->rz_prev[c];
-   }
+   for (int c = 0; c < kVC; c++) { todo[c] = a.s->done[c] == 0; }
+   if (a.multi && !first && !vcg_pending_update(a.s, a.iter, blockIdx.x == 0 && tid == 0, todo)) { return; }
+#pragma unroll
+   for (int c = 0; c < kVC; c++) { beta[c] = (first || !todo[c]) ? 0.0 : a.s->rz[c] / a.s->rz_prev[c]; }
    // the 1-D table lives in LDS (thread-dependent rows are read at use: the
    // persistent kernel is register-, not LDS-limited)
    __shared__ double sB[Q * D];
@@ -422,7 +467,7 @@ vcg_apply_3d(const VcgArgs a, const int nbatch)
          VcgScalars *s = a.s;
          for (int c = 0; c < kVC; c++)
          {
-            if (s->done[c]) { continue; }
+            if (!todo[c]) { continue; }
             s->den[c] = total[c];
             if (total[c] == 0.0 && !a.multi) { s->done[c] = 1; } // breakdown, as upstream
          }
@@ -500,12 +545,11 @@ vcg_apply_plane(const VcgArgs a, const int nbatch)
    bool todo[kVC];
    double beta[kVC];
 #pragma unroll
-   for (int k = 0; k < kVC; k++)
-   {
-      todo[k] = a.s->done[k] == 0;
-      beta[k] = (first || !todo[k]) ? 0.0 : a.s->rz[k] / a.s->rz_prev[k];
-   }
-   const bool mine = a.s->done[c] == 0;
+   for (int k = 0; k < kVC; k++) { todo[k] = a.s->done[k] == 0; }
+   if (a.multi && !first && !vcg_pending_update(a.s, a.iter, blockIdx.x == 0 && tid == 0, todo)) { return; }
+#pragma unroll
+   for (int k = 0; k < kVC; k++) { beta[k] = (first || !todo[k]) ? 0.0 : a.s->rz[k] / a.s->rz_prev[k]; }
+   const bool mine = (c == 0) ? todo[0] : (c == 1) ? todo[1] : todo[2];
    // 1-D table: scalar registers for the register-resident contractions, this
    // thread's row / column for the two x contractions
    double Bs[Q * D];
@@ -685,7 +729,7 @@ vcg_apply_plane(const VcgArgs a, const int nbatch)
          VcgScalars *s = a.s;
          for (int k = 0; k < kVC; k++)
          {
-            if (s->done[k]) { continue; }
+            if (!todo[k]) { continue; }
             s->den[k] = total[k];
             if (total[k] == 0.0 && !a.multi) { s->done[k] = 1; } // breakdown, as upstream
          }
@@ -701,6 +745,244 @@ vcg_apply_plane(const VcgArgs a, const int nbatch)
       a.trace[4 * blockIdx.x + 1] = t_loop;
       a.trace[4 * blockIdx.x + 2] = wall_clock64();
       a.trace[4 * blockIdx.x + 3] = clock64() - c_start; // shader cycles between the two wall-clock stamps 0 and 2
+   }
+}
+
+// ---- K1, plane form for D1D >= 5 (Q4Q3 0x358, Q5Q4 0x36A) ------------------------
+// Same thread layout as vcg_apply_plane, sized for the larger planes: at Q1D = 10 the
+// (y, z) plane of one x-index is 100 doubles, so HY = 2 threads (adjacent lanes) share
+// it, each taking Q/HY of its qy rows; their partial backward-y sums are combined with
+// one DPP lane swap per pair of values.  The 1-D table sits in scalar registers in
+// half: the Gauss-Lobatto basis at Gauss-Legendre points is mirror symmetric,
+// B[q,d] = B[Q-1-q, D-1-d], so Q*D/2 values serve all Q*D indices (60 doubles would
+// not fit the scalar file, 30 do).  One batch of NEB elements per workgroup; its
+// quadrature data is fetched in one coalesced sweep at the start (when the registers
+// are still free) into the LDS region that later takes the x-contracted planes.
+__device__ __forceinline__ double lane_pair_swap(const double v)
+{
+   int lo = __double2loint(v), hi = __double2hiint(v);
+   lo = __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xF, 0xF, true); // quad_perm [1,0,3,2]
+   hi = __builtin_amdgcn_mov_dpp(hi, 0xB1, 0xF, 0xF, true);
+   return __hiloint2double(hi, lo);
+}
+
+template <int D, int Q, int HY, int NEB>
+__global__ void __launch_bounds__(kVC *Q *HY *NEB, 2)
+vcg_apply_plane_ho(const VcgArgs a)
+{
+   constexpr int NQ = Q * Q * Q, ND = D * D * D, DD = D * D, QD = Q * D, HB = QD / 2;
+   constexpr int TE = kVC * Q * HY, NT = TE * NEB, QH = Q / HY;
+   static_assert(Q % HY == 0 && (HY == 1 || HY == 2), "qy rows split evenly over one or two lanes");
+   static_assert(QD % 2 == 0 && TE % 2 == 0, "mirror-symmetric table, lane pairs inside a wave");
+   constexpr int CS = (ND + 3) & ~1;
+   constexpr int CE = (DD * Q + 3) & ~1;
+   constexpr int PER0 = kVC * (CS + CE);
+   constexpr int PER = PER0 + ((6 - PER0 % 16) + 16) % 16;
+   constexpr int GPT = (NEB * ND + NT - 1) / NT;
+   constexpr int DPT = (NEB * NQ + NT - 1) / NT;
+   static_assert(kVC * CE >= NQ, "the quadrature data of an element is staged where its x-contracted planes go later");
+   __shared__ double smem[NEB * PER];
+   __shared__ double sB[QD];
+   __shared__ double red[16];
+
+   const int tid = threadIdx.x;
+   const int eb = tid / TE, lt = tid - eb * TE;
+   const int c = lt / (Q * HY), r2 = lt - c * (Q * HY);
+   const int qx = r2 / HY, h = r2 - qx * HY;
+   const int e0 = xcd_swizzle(blockIdx.x, gridDim.x) * NEB, e = e0 + eb;
+   const int nel = min(NEB, a.NE - e0);
+   double *sIn = smem + eb * PER + c * CS;           // [dx + D*(dy + D*dz)]
+   double *sE = smem + eb * PER + kVC * CS + c * CE; // [qx + Q*(dy + D*dz)]
+   const double *sD = smem + eb * PER + kVC * CS;    // [qx + Q*(qy + Q*qz)] until the planes are handed over
+
+   int mi[GPT];
+#pragma unroll
+   for (int k = 0; k < GPT; k++)
+   {
+      const int i = tid + k * NT;
+      mi[k] = (i < nel * ND) ? a.map[(size_t)e0 * ND + i] : -1;
+   }
+   if (a.s->all_done) { return; }
+   // quadrature data of the batch: one coalesced sweep while the registers are still free
+   double dst[DPT];
+#pragma unroll
+   for (int k = 0; k < DPT; k++)
+   {
+      const int i = tid + k * NT;
+      dst[k] = (i < nel * NQ) ? a.Dq[(size_t)e0 * NQ + i] : 0.0;
+   }
+   const bool first = a.s->first != 0;
+   bool todo[kVC];
+   double beta[kVC];
+#pragma unroll
+   for (int k = 0; k < kVC; k++) { todo[k] = a.s->done[k] == 0; }
+   if (a.multi && !first && !vcg_pending_update(a.s, a.iter, blockIdx.x == 0 && tid == 0, todo)) { return; }
+#pragma unroll
+   for (int k = 0; k < kVC; k++) { beta[k] = (first || !todo[k]) ? 0.0 : a.s->rz[k] / a.s->rz_prev[k]; }
+   const bool active = (e < a.NE) && ((c == 0) ? todo[0] : (c == 1) ? todo[1] : todo[2]);
+   double Bs[HB];
+#pragma unroll
+   for (int i = 0; i < HB; i++) { Bs[i] = uniform_f64(a.B[i]); }
+   auto Bc = [&](const int q, const int d) -> double {
+      const int idx = q + Q * d;
+      return idx < HB ? Bs[idx] : Bs[QD - 1 - idx];
+   };
+   for (int i = tid; i < QD; i += NT) { sB[i] = a.B[i]; }
+#pragma unroll
+   for (int k = 0; k < DPT; k++)
+   {
+      const int i = tid + k * NT;
+      if (i < NEB * NQ)
+      {
+         const int el = i / NQ, j = i - el * NQ;
+         smem[el * PER + kVC * CS + j] = dst[k];
+      }
+   }
+   // directions d = z + beta d of the three components (K2 stores the same values)
+#pragma unroll
+   for (int k = 0; k < GPT; k++)
+   {
+      const int i = tid + k * NT;
+      if (i < nel * ND)
+      {
+         const int el = i / ND, dd = i - el * ND;
+         const int n = mi[k];
+         const double gi = a.dinv[n];
+#pragma unroll
+         for (int k2 = 0; k2 < kVC; k2++)
+         {
+            const double gz = a.r[(size_t)k2 * a.N + n];
+            const double gd = first ? 0.0 : a.d[(size_t)k2 * a.N + n];
+            smem[el * PER + k2 * CS + dd] = fma(beta[k2], gd, __dmul_rn(gz, gi));
+         }
+      }
+   }
+   __syncthreads();
+   // forward x: t[dy,dz] = sum_dx B[qx,dx] d[dx,dy,dz] (each lane of a pair forms it)
+   double t[DD];
+   {
+      double bx[D];
+#pragma unroll
+      for (int dx = 0; dx < D; dx++) { bx[dx] = sB[qx + Q * dx]; }
+#pragma unroll
+      for (int k = 0; k < DD; k++)
+      {
+         double u = 0.0;
+#pragma unroll
+         for (int dx = 0; dx < D; dx++) { u = fma(bx[dx], sIn[dx + D * k], u); }
+         t[k] = u;
+      }
+   }
+   // this lane's qy rows: forward y, then per row forward z, scaling, backward z; backward y accumulated
+   double acc[DD];
+#pragma unroll
+   for (int k = 0; k < DD; k++) { acc[k] = 0.0; }
+#pragma unroll
+   for (int r = 0; r < QH; r++)
+   {
+      double by[D]; // table row of qy = h*QH + r
+#pragma unroll
+      for (int dy = 0; dy < D; dy++)
+      {
+         double v = Bc(r, dy);
+         if (HY == 2) { v = h ? Bc(QH + r, dy) : v; }
+         by[dy] = v;
+      }
+      double wr[D];
+#pragma unroll
+      for (int dz = 0; dz < D; dz++)
+      {
+         double u = 0.0;
+#pragma unroll
+         for (int dy = 0; dy < D; dy++) { u = fma(by[dy], t[dy + D * dz], u); }
+         wr[dz] = u;
+      }
+      double cz[Q];
+#pragma unroll
+      for (int qz = 0; qz < Q; qz++)
+      {
+         double u = 0.0;
+#pragma unroll
+         for (int dz = 0; dz < D; dz++) { u = fma(Bc(qz, dz), wr[dz], u); }
+         cz[qz] = u * sD[qx + Q * (h * QH + r) + Q * Q * qz];
+      }
+#pragma unroll
+      for (int dz = 0; dz < D; dz++)
+      {
+         double u = 0.0;
+#pragma unroll
+         for (int qz = 0; qz < Q; qz++) { u = fma(Bc(qz, dz), cz[qz], u); }
+#pragma unroll
+         for (int dy = 0; dy < D; dy++) { acc[dy + D * dz] = fma(by[dy], u, acc[dy + D * dz]); }
+      }
+   }
+   __syncthreads(); // every lane of the element has read its quadrature data
+   // hand the plane over: lane h of a pair delivers the (dy,dz) entries k = h (mod 2)
+   if (HY == 1)
+   {
+#pragma unroll
+      for (int k = 0; k < DD; k++) { sE[qx + Q * k] = acc[k]; }
+   }
+   else
+   {
+#pragma unroll
+      for (int k = 0; k + 1 < DD; k += 2)
+      {
+         const double give = h ? acc[k] : acc[k + 1];
+         const double keep = h ? acc[k + 1] : acc[k];
+         sE[qx + Q * (k + h)] = keep + lane_pair_swap(give);
+      }
+      if (DD & 1)
+      {
+         const double tot = acc[DD - 1] + lane_pair_swap(acc[DD - 1]);
+         if (h == 0) { sE[qx + Q * (DD - 1)] = tot; }
+      }
+   }
+   __syncthreads();
+   // backward x: lane (dx = qx < D, h) sums the Q planes for its share of the (dy,dz) pairs
+   double dot = 0.0;
+   if (qx < D && active)
+   {
+      double bt[Q];
+#pragma unroll
+      for (int q = 0; q < Q; q++) { bt[q] = sB[q + Q * qx]; }
+      double *yc = a.YE + (size_t)c * a.ye_stride + (size_t)ND * e;
+      constexpr int KH = (DD + HY - 1) / HY;
+#pragma unroll
+      for (int kk = 0; kk < KH; kk++)
+      {
+         const int k = h * KH + kk;
+         if (k < DD)
+         {
+            double u = 0.0;
+#pragma unroll
+            for (int q = 0; q < Q; q++) { u = fma(bt[q], sE[q + Q * k], u); }
+            yc[qx + D * k] = u;
+            dot = fma(sIn[qx + D * k], u, dot);
+         }
+      }
+   }
+   double bp[kVC];
+#pragma unroll
+   for (int k = 0; k < kVC; k++)
+   {
+      bp[k] = block_sum(c == k ? dot : 0.0, red);
+      __syncthreads();
+   }
+   double total[kVC];
+   if (grid_sum3_last_block(bp, a.partials, a.stride, a.ticket, red, total))
+   {
+      if (tid == 0)
+      {
+         VcgScalars *s = a.s;
+         for (int k = 0; k < kVC; k++)
+         {
+            if (!todo[k]) { continue; }
+            s->den[k] = total[k];
+            if (total[k] == 0.0 && !a.multi) { s->done[k] = 1; } // breakdown, as upstream
+         }
+         s->first = 0;
+      }
    }
 }
 
@@ -839,17 +1121,10 @@ __global__ void vcg_set_tol_k(VcgScalars *s, double rel_tol2)
 // Several ranks: the host enqueues the iteration count of the previous solve without looking at the flags,
 // so a few launches may follow convergence.  Their kernels return at once, but the exchanges between them
 // still run and would re-sum the (already global) den / rz of a finished component once per surplus
-// iteration - growing by the number of ranks each time, to inf after a long solve.  The finish kernels
-// therefore zero the scalars of finished components: sums of zeros stay zero.  den[c] and rz[c] are
-// undefined (0) once done[c] is set; nothing reads them after that.
-__global__ void vcg_den_finish_k(VcgScalars *s)
-{
-   for (int c = 0; c < kVC; c++)
-   {
-      if (!s->done[c] && s->den[c] == 0.0) { s->done[c] = 1; }
-      if (s->done[c]) { s->den[c] = 0.0; }
-   }
-}
+// iteration - growing by the number of ranks each time, to inf after a long solve.  Whoever marks a
+// component done (vcg_pending_update / vcg_pending_den inside the kernels, this kernel before the host
+// looks) therefore zeroes its scalars: sums of zeros stay zero.  den[c] and rz[c] are undefined (0) once
+// done[c] is set; nothing reads them after that.
 __global__ void vcg_update_finish_k(VcgScalars *s, int iter)
 {
    int all = 1;
@@ -860,7 +1135,7 @@ __global__ void vcg_update_finish_k(VcgScalars *s, int iter)
          s->iters[c] = iter;
          if (s->rz[c] < 0.0 || s->rz[c] <= s->r0[c]) { s->done[c] = 1; }
       }
-      if (s->done[c]) { s->rz[c] = 0.0; s->den[c] = 0.0; } // see vcg_den_finish_k
+      if (s->done[c]) { s->rz[c] = 0.0; s->den[c] = 0.0; }
       all = all && s->done[c];
    }
    s->all_done = all;
@@ -894,6 +1169,7 @@ vcg_update_k(const VcgArgs a)
    for (int c = 0; c < kVC; c++)
    {
       if (a.s->done[c]) { continue; } // uniform
+      if (a.multi && vcg_pending_den(a.s, c, blockIdx.x == 0 && threadIdx.x == 0)) { continue; }
       const double alpha = a.s->rz[c] / a.s->den[c];
       const double beta = it1 ? 0.0 : a.s->rz[c] / a.s->rz_prev[c];
       const size_t i = (size_t)c * a.N + nn;
@@ -940,7 +1216,7 @@ vcg_update_k(const VcgArgs a)
          int all = 1;
          for (int c = 0; c < kVC; c++)
          {
-            if (!s->done[c])
+            if (!s->done[c] && !(a.multi && s->den[c] == 0.0)) // (several ranks: breakdown found by this launch)
             {
                s->rz_prev[c] = s->rz[c];
                s->rz[c] = total[c]; // betanom
@@ -1220,6 +1496,11 @@ template <int D, int Q> static void launch_vcg_plane(lgh_ctx *c, const VcgArgs &
    hipLaunchKernelGGL((vcg_apply_plane<D, Q, NEB>), dim3(grid), dim3(kVC * Q * NEB), 0, c->stream, a, nbatch);
 }
 
+template <int D, int Q, int HY, int NEB> static void launch_vcg_plane_ho(lgh_ctx *c, const VcgArgs &a)
+{
+   hipLaunchKernelGGL((vcg_apply_plane_ho<D, Q, HY, NEB>), dim3(ceil_div(c->NE, NEB)), dim3(kVC * Q * HY * NEB), 0, c->stream, a);
+}
+
 template <int D, int Q> static void launch_vcg_apply(lgh_ctx *c, const VcgArgs &a)
 {
    constexpr int NEB = (256 / (Q * Q)) > 0 ? (256 / (Q * Q)) : 1;
@@ -1377,6 +1658,8 @@ int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
       // with the GPU idle meanwhile, less per solve.
       if (!first_look || max_iter <= 0)
       {
+         // several ranks: the outcome of the last enqueued update is still pending (vcg_pending_update) - commit it
+         if (multi && it > 0) { hipLaunchKernelGGL(vcg_update_finish_k, dim3(1), dim3(1), 0, c->stream, ds, it); }
          LGH_HIP_CHECK(hipMemcpyAsync(hs, ds, sizeof(VcgScalars), hipMemcpyDeviceToHost, c->stream));
          LGH_HIP_CHECK(hipStreamSynchronize(c->stream));
          if (hs->all_done || it >= max_iter) { break; }
@@ -1396,8 +1679,15 @@ int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
             case 0x322: VCG_DISPATCH(2, 2); break;
             case 0x334: VCG_DISPATCH(3, 4); break;
             case 0x346: VCG_DISPATCH(4, 6); break;
-            case 0x358: launch_vcg_apply<5, 8>(c, a); break;
-            case 0x36A: launch_vcg_apply<6, 10>(c, a); break;
+            case 0x358: // LGH_VCG_VARIANT=1: the two-lanes-per-plane split at Q1D = 8 as well (A/B, tests)
+               if (c->vcg_variant == 0) { launch_vcg_apply<5, 8>(c, a); }
+               else if (c->vcg_variant == 1) { launch_vcg_plane_ho<5, 8, 2, 5>(c, a); }
+               else { launch_vcg_plane_ho<5, 8, 1, 5>(c, a); }
+               break;
+            case 0x36A:
+               if (c->vcg_variant == 0) { launch_vcg_apply<6, 10>(c, a); }
+               else { launch_vcg_plane_ho<6, 10, 2, 4>(c, a); }
+               break;
          }
          kt_end(c, LGH_KERNEL_MASS_CG_H1);
          LGH_HIP_CHECK(hipGetLastError());
@@ -1450,15 +1740,13 @@ int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
                   rc = allreduce_dev(c, ds->den, kVC, 0);
                   if (rc) { return rc; }
                }
-               hipLaunchKernelGGL(vcg_den_finish_k, dim3(1), dim3(1), 0, c->stream, ds);
             }
             if (mixed) { hipLaunchKernelGGL((vcg_update_k<true, 8>), dim3(nb), dim3(256), 0, c->stream, a); }
             else { hipLaunchKernelGGL((vcg_update_k<false, 0>), dim3(nb), dim3(256), 0, c->stream, a); }
             if (multi)
             {
-               rc = allreduce_dev(c, ds->rz, kVC, 0);
+               rc = allreduce_dev(c, ds->rz, kVC, 0); // convergence is looked at by the next K1 (vcg_pending_update)
                if (rc) { return rc; }
-               hipLaunchKernelGGL(vcg_update_finish_k, dim3(1), dim3(1), 0, c->stream, ds, it);
             }
          }
          LGH_HIP_CHECK(hipGetLastError());

@@ -170,9 +170,11 @@ def test_config4_3d_sedov_q3q2_rs5_full_size_one_gpu():
 
 def test_config4_eight_emulated_ranks_q3q2_16cubed():
     """config4's partition (2x2x2 blocks) at Q3/Q2 with a 16^3 global mesh: eight contexts on one GPU over
-    the loopback communicator must reproduce the single-rank run (steps, dt, |e|)."""
+    the loopback communicator must reproduce the single-rank run (steps, dt, |e|) - with the region timers on
+    (sequential solves, the reference's order) and off (energy solve beside the velocity solve, as in bench.py)."""
     from test_gpu_pipeline import test_multi_rank_run_on_one_gpu as run_ranks
-    run_ranks(8, (16, 16, 16), 1)
+    run_ranks(8, (16, 16, 16), 1, 1)
+    run_ranks(8, (16, 16, 16), 1, 0)
 
 
 # ---- config5 ---------------------------------------------------------------------------------

@@ -346,3 +346,40 @@ def test_qupdate_shortcut_on_live_sedov_state():
     finally:
         g.close()
         o.close()
+
+
+@pytest.mark.parametrize("order", [(4, 3), (5, 4)], ids=["Q4Q3", "Q5Q4"])
+def test_lockstep_k1_forms_agree_at_high_order(order, monkeypatch):
+    """The lockstep velocity solve at D1D >= 5 through each form of its mass-apply kernel (LGH_VCG_VARIANT:
+    0 = column form, 1 = plane form with two lanes per plane, default = plane form as dispatched): 16 zones
+    (a ragged last batch for the batches of 5), distorted state, CG to 1e-14: the velocity part of dS/dt
+    agrees with the oracle to the operator tolerance in every form."""
+    from oracle.fem import Problem
+    prob = Problem(mesh="box01_hex", rs=0, order_v=order[0], order_e=order[1], problem=1)
+    S = deformed_state(prob, seed=33)
+    o = make_oracle(prob)
+    try:
+        o.cg_tol = 1e-14
+        dS_o = np.empty_like(S)
+        o.qdata_is_current = False
+        o.mult(S, dS_o)
+    finally:
+        o.close()
+    H1V = prob.H1V
+    for variant in ("0", "1", None):
+        if variant is None:
+            monkeypatch.delenv("LGH_VCG_VARIANT", raising=False)
+        else:
+            monkeypatch.setenv("LGH_VCG_VARIANT", variant)
+        g = make_gpu(prob)
+        try:
+            g.cg_tol = 1e-14
+            Sd = g.ctx.to_dev(S)
+            dS = g.ctx.zeros(S.size)
+            g.reset_quadrature_data()
+            g.mult(Sd, dS)
+            g.ctx.sync()
+            dS = dS.cpu().numpy()
+        finally:
+            g.close()
+        assert rel_err(dS[H1V:2 * H1V], dS_o[H1V:2 * H1V]) < 1e-10, variant

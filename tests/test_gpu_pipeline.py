@@ -413,9 +413,10 @@ def test_halo_logic_emulated_ranks(pgrid):
         c.close()
 
 
-@pytest.mark.parametrize("nranks,nel,problem", [(2, (8, 8, 8), 1), (8, (8, 8, 8), 1), (3, (9, 6, 6), 1),
-                                                (4, (8, 8, 4), 7)])
-def test_multi_rank_run_on_one_gpu(nranks, nel, problem):
+@pytest.mark.parametrize("nranks,nel,problem,timers", [(2, (8, 8, 8), 1, 1), (8, (8, 8, 8), 1, 1), (3, (9, 6, 6), 1, 1),
+                                                       (4, (8, 8, 4), 7, 1), (2, (8, 8, 8), 1, 0), (8, (8, 8, 8), 1, 0),
+                                                       (3, (9, 6, 6), 1, 0)])
+def test_multi_rank_run_on_one_gpu(nranks, nel, problem, timers):
     """The complete multi-rank algorithm (block partition, owner-weighted dot products,
     halo pack / canonical combine, separate-gather CG sequencing with its finish
     kernels, dt / |e| reductions) on ONE GPU: the ranks are contexts driven by one host
@@ -426,13 +427,16 @@ def test_multi_rank_run_on_one_gpu(nranks, nel, problem):
     2 and 2x2x2 ranks are all-pairs neighbours: (d, A d) rides on the halo messages; in the
     3x1x1 partition only the middle rank sees all others, so the (collective) decision
     must fall back to the all-reduce on every rank.  The 4-rank case runs problem 7
-    (vorticity-scaled viscosity, gravity source through the halo-summed MultFull)."""
+    (vorticity-scaled viscosity, gravity source through the halo-summed MultFull).
+    timers = 0: region timers off, as in bench.py - the energy solve then runs beside the velocity solve on
+    the second stream, with its dot products summed over the ranks on the communicator's second channel."""
     import os
     import threading
     from laghos_amd import host_lib
     args = ["-p", problem, "-dim", 3, "-nx", nel[0], "-ny", nel[1], "-nz", nel[2], "-Sx", 1, "-Sy", 1, "-Sz", 1, "-rs", 0,
             "-ok", 3, "-ot", 2, "-pa", "-tf", 0.6, "-ms", 6, "-q"]
     ref = host_lib.Sim(args)
+    ref.enable_timers(timers)
     while ref.step() == 1:
         pass
     want = dict(e=ref.e_norm(), t=ref.t, dt=ref.dt, rk=ref.rk_steps, ti=ref.ti)
@@ -444,6 +448,7 @@ def test_multi_rank_run_on_one_gpu(nranks, nel, problem):
     def rank_main(rank):
         try:
             sim = host_lib.Sim(args, nranks=nranks, rank=rank, nccl_id=cid)
+            sim.enable_timers(timers)
             while sim.step() == 1:
                 pass
             out[rank] = dict(e=sim.e_norm(), t=sim.t, dt=sim.dt, rk=sim.rk_steps, ti=sim.ti)
