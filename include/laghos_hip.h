@@ -241,6 +241,23 @@ int lgh_comm_unique_id(char id_out[128]);
 int lgh_comm_init(lgh_ctx *ctx, int nranks, int rank, const char unique_id[128]);
 int lgh_comm_set_neighbors(lgh_ctx *ctx, int n_nbr, const int *nbr_rank, const int *nbr_count,
                            const int *const *nbr_nodes);
+/* Host helper (no GPU, no context): the `owner` mask of lgh_config and the neighbour lists of
+ * lgh_comm_set_neighbors from a description of the shared dofs by GROUPS - the form in which MFEM holds them
+ * (ParFiniteElementSpace::GroupComm(): GroupTopology = the rank set and master of every group,
+ * GroupLDofTable = its L-dofs in an order common to all members; this is what P / P^T of
+ * laghos_solver.cpp:368, :393 are built from).  INTEGRATION.md §4 shows the MFEM side.
+ *   group g: ranks  group_ranks[group_off[g] .. group_off[g+1])  (my_rank among them, any order),
+ *            master group_master[g] (NULL: the lowest rank of the group),
+ *            L-dofs ldofs[ldof_off[g] .. ldof_off[g+1]) in the group's common order.
+ * Outputs: owner[N] = 0 for dofs of groups mastered elsewhere, 1 otherwise;  *n_nbr peers in ascending rank
+ * order, nbr_rank[k], nbr_count[k], and their node lists concatenated in nbr_nodes (neighbour k starts at the sum
+ * of the counts before it).  For a peer the groups are taken in the order of their sorted rank sets (a key that
+ * is the same on both sides) and the dofs inside a group in the group's order, so the two ranks of a pair
+ * enumerate their shared dofs identically.  Capacities: nbr_rank / nbr_count >= number of distinct peers,
+ * nbr_nodes >= sum over the groups of (size - 1) * number of dofs; cap_nbr / cap_nodes are checked. */
+int lgh_groups_to_neighbors(int my_rank, int N, int n_groups, const int *group_off, const int *group_ranks,
+                            const int *group_master, const int *ldof_off, const int *ldofs, double *owner,
+                            int *n_nbr, int *nbr_rank, int *nbr_count, int cap_nbr, int *nbr_nodes, long cap_nodes);
 /* in-place sum of shared nodes of an H1 L-vector with ncomp components */
 int lgh_halo_sum(lgh_ctx *ctx, double *v_h1, int ncomp);
 /* op 0 = sum, 1 = min; synchronous */

@@ -90,6 +90,8 @@ SYMBOLS = {
     "lgh_comm_unique_id": (_I, [ctypes.c_char_p]),
     "lgh_comm_init": (_I, [_P, _I, _I, ctypes.c_char_p]),
     "lgh_comm_set_neighbors": (_I, [_P, _I, c_int_p, c_int_p, ctypes.POINTER(c_int_p)]),
+    "lgh_groups_to_neighbors": (_I, [_I, _I, _I, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p, c_dbl_p, c_int_p, c_int_p,
+                                     c_int_p, _I, c_int_p, _L]),
     "lgh_halo_sum": (_I, [_P, _P, _I]),
     "lgh_allreduce": (_I, [_P, c_dbl_p, _I]),
     "lgh_force_mult_E": (_I, [_P, _P, _P, _P]),

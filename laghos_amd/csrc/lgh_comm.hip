@@ -692,6 +692,68 @@ int lgh_test_rccl_self_sendrecv(lgh_ctx *c, int n, double *max_abs_diff)
    return LGH_OK;
 }
 
+int lgh_groups_to_neighbors(int my_rank, int N, int n_groups, const int *group_off, const int *group_ranks,
+                            const int *group_master, const int *ldof_off, const int *ldofs, double *owner,
+                            int *n_nbr, int *nbr_rank, int *nbr_count, int cap_nbr, int *nbr_nodes, long cap_nodes)
+{
+   LGH_CHECK_ARG(my_rank >= 0 && N >= 0 && n_groups >= 0 && owner && n_nbr);
+   LGH_CHECK_ARG(n_groups == 0 || (group_off && group_ranks && ldof_off && ldofs));
+   for (int i = 0; i < N; i++) { owner[i] = 1.0; }
+   // groups ordered by their sorted rank sets: the same sequence on every member
+   std::vector<std::vector<int>> sets((size_t)n_groups);
+   std::vector<int> order((size_t)n_groups);
+   for (int g = 0; g < n_groups; g++)
+   {
+      LGH_CHECK_ARG(group_off[g + 1] - group_off[g] >= 2 && ldof_off[g + 1] >= ldof_off[g]);
+      sets[g].assign(group_ranks + group_off[g], group_ranks + group_off[g + 1]);
+      std::sort(sets[g].begin(), sets[g].end());
+      if (std::adjacent_find(sets[g].begin(), sets[g].end()) != sets[g].end() ||
+          !std::binary_search(sets[g].begin(), sets[g].end(), my_rank) || sets[g].front() < 0)
+      {
+         set_error("lgh_groups_to_neighbors: group %d must list distinct ranks including this one", g);
+         return LGH_ERR_ARG;
+      }
+      order[g] = g;
+      const int master = group_master ? group_master[g] : sets[g].front();
+      if (!std::binary_search(sets[g].begin(), sets[g].end(), master)) { set_error("lgh_groups_to_neighbors: master of group %d is not a member", g); return LGH_ERR_ARG; }
+      for (int k = ldof_off[g]; k < ldof_off[g + 1]; k++)
+      {
+         if (ldofs[k] < 0 || ldofs[k] >= N) { set_error("lgh_groups_to_neighbors: dof out of range in group %d", g); return LGH_ERR_ARG; }
+         if (master != my_rank) { owner[ldofs[k]] = 0.0; }
+      }
+   }
+   std::sort(order.begin(), order.end(), [&](int a, int b) { return sets[a] < sets[b]; });
+   for (int i = 0; i + 1 < n_groups; i++)
+   {
+      if (sets[order[i]] == sets[order[i + 1]]) { set_error("lgh_groups_to_neighbors: two groups with the same rank set"); return LGH_ERR_ARG; }
+   }
+   std::vector<int> peers;
+   for (int g = 0; g < n_groups; g++) { for (int r : sets[g]) { if (r != my_rank) { peers.push_back(r); } } }
+   std::sort(peers.begin(), peers.end());
+   peers.erase(std::unique(peers.begin(), peers.end()), peers.end());
+   if ((int)peers.size() > cap_nbr) { set_error("lgh_groups_to_neighbors: %d peers, room for %d", (int)peers.size(), cap_nbr); return LGH_ERR_ARG; }
+   LGH_CHECK_ARG(peers.empty() || (nbr_rank && nbr_count && nbr_nodes));
+   long pos = 0;
+   for (size_t k = 0; k < peers.size(); k++)
+   {
+      nbr_rank[k] = peers[k];
+      int cnt = 0;
+      for (int i = 0; i < n_groups; i++)
+      {
+         const int g = order[i];
+         if (!std::binary_search(sets[g].begin(), sets[g].end(), peers[k])) { continue; }
+         const int nd = ldof_off[g + 1] - ldof_off[g];
+         if (pos + nd > cap_nodes) { set_error("lgh_groups_to_neighbors: node list capacity %ld too small", cap_nodes); return LGH_ERR_ARG; }
+         for (int j = 0; j < nd; j++) { nbr_nodes[pos + j] = ldofs[ldof_off[g] + j]; }
+         pos += nd;
+         cnt += nd;
+      }
+      nbr_count[k] = cnt;
+   }
+   *n_nbr = (int)peers.size();
+   return LGH_OK;
+}
+
 int lgh_halo_sum(lgh_ctx *c, double *v_h1, int ncomp)
 {
    LGH_CHECK_ARG(c && v_h1 && ncomp >= 1 && ncomp <= 3);

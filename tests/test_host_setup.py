@@ -141,3 +141,75 @@ def test_rk6_tableau_order_conditions():
     from oracle import driver
     for tab in (hydro, driver):
         assert [float(x) for x in a] == tab.RK6_A and [float(x) for x in b] == tab.RK6_B
+
+
+@pytest.mark.parametrize("nranks", [2, 4, 8])
+def test_owner_and_neighbours_from_group_lists(nranks):
+    """The MPI binding of INTEGRATION.md §4: MFEM describes shared dofs by GROUPS (GroupTopology: rank set and
+    master of every group; GroupLDofTable: its L-dofs in an order common to the members), not by per-peer
+    lists.  The groups are derived here from the global identity of the nodes alone (which ranks hold a node),
+    independently of laghos::Partition, and lgh_groups_to_neighbors must turn them into an owner mask with
+    every global node owned exactly once and equal to Partition's (both: lowest rank owns), and into per-peer
+    lists that name the same physical nodes, in the same order, on both ranks of every pair, and cover exactly
+    the nodes Partition shares between them."""
+    import ctypes
+    from laghos_amd import _lib
+    lib = _lib.load()
+    mesh, rs, ok, ot, dim = "cube01_hex", 1, 2, 1, 3
+    discs = [host_lib.host_disc(mesh, rs, ok, ot, 1, nranks=nranks, rank=r) for r in range(nranks)]
+    keys = []      # per rank: global identity of every local node
+    holders = {}   # global node -> ranks holding it
+    for r, d in enumerate(discs):
+        N = len(d["owner"])
+        X = np.round(d["S0"][:dim * N].reshape(dim, N).T * 4096).astype(np.int64)
+        keys.append([tuple(x) for x in X])
+        for k in keys[r]:
+            holders.setdefault(k, []).append(r)
+    IP = ctypes.POINTER(ctypes.c_int)
+    ip = lambda a: a.ctypes.data_as(IP)
+    result = []
+    for r, d in enumerate(discs):
+        N = len(d["owner"])
+        groups = {}  # rank set -> [(global key, local dof)]
+        for n, k in enumerate(keys[r]):
+            if len(holders[k]) > 1:
+                groups.setdefault(tuple(sorted(holders[k])), []).append((k, n))
+        # any order of the groups and of the ranks inside a group must do; the dofs of a group in its common order
+        names = sorted(groups, key=lambda s: (len(s), s[::-1]))
+        g_off = np.cumsum([0] + [len(s) for s in names]).astype(np.int32)
+        g_ranks = np.array([x for s in names for x in s[::-1]], dtype=np.int32)
+        l_off = np.cumsum([0] + [len(groups[s]) for s in names]).astype(np.int32)
+        ldofs = np.array([n for s in names for _, n in sorted(groups[s])], dtype=np.int32)
+        cap_nodes = int(sum((len(s) - 1) * len(groups[s]) for s in names))
+        owner = np.full(N, -1.0)
+        n_nbr = ctypes.c_int(-1)
+        nbr_rank = np.zeros(nranks, dtype=np.int32)
+        nbr_count = np.zeros(nranks, dtype=np.int32)
+        nodes = np.zeros(max(cap_nodes, 1), dtype=np.int32)
+        rc = lib.lgh_groups_to_neighbors(r, N, len(names), ip(g_off), ip(g_ranks), None, ip(l_off), ip(ldofs),
+                                         owner.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), ctypes.byref(n_nbr),
+                                         ip(nbr_rank), ip(nbr_count), nranks, ip(nodes), cap_nodes)
+        assert rc == 0, lib.lgh_last_error()
+        k = n_nbr.value
+        off = np.concatenate([[0], np.cumsum(nbr_count[:k])])
+        lists = {int(nbr_rank[i]): nodes[off[i]:off[i + 1]].copy() for i in range(k)}
+        assert off[-1] == cap_nodes
+        assert np.array_equal(owner, d["owner"])
+        assert sorted(lists) == sorted(int(x) for x in d["nbr_rank"])
+        for i, nr in enumerate(d["nbr_rank"]):
+            assert sorted(lists[int(nr)]) == sorted(d["nbr_nodes"][i])  # the same set of shared nodes as Partition's
+        result.append(lists)
+    assert sum(int(np.sum(host_lib.host_disc(mesh, rs, ok, ot, 1, nranks=nranks, rank=r)["owner"])) for r in range(nranks)) == len(holders)
+    for a in range(nranks):
+        for b, mine in result[a].items():
+            theirs = result[b][a]
+            assert len(mine) == len(theirs) > 0
+            assert [keys[a][n] for n in mine] == [keys[b][n] for n in theirs]  # same nodes, same order
+    # malformed descriptions are refused
+    bad = np.array([0, 0], dtype=np.int32)
+    one = np.array([0, 2], dtype=np.int32)
+    z = np.array([0, 0], dtype=np.int32)
+    ow = np.zeros(4)
+    nn = ctypes.c_int(0)
+    assert lib.lgh_groups_to_neighbors(0, 4, 1, ip(one), ip(bad), None, ip(z), ip(z), ow.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                       ctypes.byref(nn), ip(z), ip(z), 2, ip(z), 0) != 0
