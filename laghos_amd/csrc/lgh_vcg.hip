@@ -220,6 +220,7 @@ struct VcgArgs
    const unsigned *ellz;      // ell as byte offsets into a Y_E plane, absent entries -> its zero slot NE*ND
    const uint8_t *essbits;    // bit k: node essential for component k
    const int *nstart;         // node range of block w: [nstart[w], nstart[w+1]), balanced by cost
+   int k2_skip;               // vcg_update_p_k: skip ELL slots no node of the wavefront uses (LGH_K2_SKIP=0: fetch all 8)
    int ye_store;              // K1 (plane form): 0 plain, 1 write-through, 2 non-temporal stores of Y_E (LGH_K1_STORE)
 };
 
@@ -1282,6 +1283,7 @@ vcg_update_p_k(const VcgArgs a)
    }
    const bool xload = XU && it > 2;
    const unsigned rowb = 4u * (unsigned)a.N, compb = 8u * (unsigned)a.N;
+   const unsigned zoff = 8u * (unsigned)(a.ye_stride - kYePad); // byte offset of the zero slot (make_ellz)
    double part[kVC] = {0.0, 0.0, 0.0};
    for (int base = n0; base < n1; base += NT * U)
    {
@@ -1318,16 +1320,42 @@ vcg_update_p_k(const VcgArgs a)
             if (XU) { xo[u][k] = vcg_ld(a.x, vb); }
          }
       }
+      // Slot j of the ELL rows is only fetched when some node of the wavefront has a j-th contribution (rows hold
+      // their contributions first): a wave of consecutive nodes of a tensor-product mesh rarely needs all 8 (a
+      // node needs 1, 2, 4 or 8), and the loads of absent slots - all lanes at the zero slot - still occupy the
+      // address path.
+      bool need[8];
+      need[0] = true;
+#pragma unroll
+      for (int j = 1; j < 8; j++)
+      {
+         bool any = false;
+#pragma unroll
+         for (int u = 0; u < U; u++) { any = any || (ix[u][j] != zoff); }
+         need[j] = !a.k2_skip || __any(any);
+      }
       double ye[U][kVC][8];
 #pragma unroll
-      for (int k = 0; k < kVC; k++)
+      for (int j = 0; j < 8; j++)
       {
-         const double *yc = a.YE + (size_t)k * a.ye_stride;
-#pragma unroll
-         for (int u = 0; u < U; u++)
+         if (need[j])
          {
 #pragma unroll
-            for (int j = 0; j < 8; j++) { ye[u][k][j] = vcg_ld(yc, ix[u][j]); }
+            for (int k = 0; k < kVC; k++)
+            {
+               const double *yc = a.YE + (size_t)k * a.ye_stride;
+#pragma unroll
+               for (int u = 0; u < U; u++) { ye[u][k][j] = vcg_ld(yc, ix[u][j]); }
+            }
+         }
+         else
+         {
+#pragma unroll
+            for (int k = 0; k < kVC; k++)
+            {
+#pragma unroll
+               for (int u = 0; u < U; u++) { ye[u][k][j] = 0.0; }
+            }
          }
       }
 #pragma unroll
@@ -1574,7 +1602,8 @@ int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
          int ncu = 256;
          hipDeviceProp_t prop;
          if (hipGetDeviceProperties(&prop, c->device) == hipSuccess) { ncu = prop.multiProcessorCount; }
-         x->grid2 = 2 * ncu;
+         static const char *genv = getenv("LGH_K2_GRID"); // A/B: workgroups (= node ranges) per CU
+         x->grid2 = ((genv && atoi(genv) > 0) ? atoi(genv) : 2) * ncu;
          rc = make_ellz(c, &x->ellz);
          if (rc) { return rc; }
          rc = make_essbits(c, &x->essbits);
@@ -1613,6 +1642,8 @@ int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
    a.essbits = aux->essbits;
    a.nstart = aux->nstart;
    {
+      static const char *e0 = getenv("LGH_K2_SKIP");
+      a.k2_skip = (e0 && e0[0] == '0') ? 0 : 1;
       static const char *e1 = getenv("LGH_K1_STORE");
       a.ye_store = e1 ? atoi(e1) : 0;
    }
