@@ -1237,33 +1237,28 @@ vcg_update_k(const VcgArgs a)
 // ---- K2, bounded-grid form (one rank) ---------------------------------------------------------------
 // The same node update as vcg_update_k, organised the way the node phase of the persistent kernel
 // (lgh_pcg.hip) turned out to run fastest - its measurements carry over to a kernel of its own:
-//  * two workgroups of 512 threads per CU, each with a contiguous node range of equal COST (a node costs a
+//  * four workgroups of 512 threads per CU, each with a contiguous node range of equal COST (a node costs a
 //    fixed part plus a part per element contribution; with equal counts the ranges that cover
-//    element-boundary planes take 40 % longer), two nodes per thread and pass, all ~70 loads of a pass issued
-//    before the first use, straight-line code;
+//    element-boundary planes take 40 % longer), all ~35 loads of a node issued before the first use,
+//    straight-line code.  One node per thread and pass (U = 1: 106 VGPRs, two workgroups resident per CU)
+//    beats two (U = 2: 182 VGPRs, one resident; what the persistent kernel's node phase used): 55.4 -> 49.7 us
+//    at C2 (LGH_K2_U=2, LGH_K2_GRID=<workgroups per CU> for A/B);
 //  * the ELL row holds byte offsets and absent contributions point at a zero slot behind the Y_E plane: no
 //    predicated loads, addresses are one SGPR base + a 32-bit VGPR offset;
 //  * x is only needed at the end of the solve: it is updated every second iteration with both terms,
 //      x = (x + alpha_{it-1} d_{it-1}) + alpha_it d_it     (the roundings of two single updates),
 //    and vcg_xfix_k adds the pending term of a component that stopped after an odd number of updates -
 //    22 MB less traffic per iteration on average at C2;
-//  * 1024 workgroup partials instead of 3566 for the ticketed reduction.
+//  * 1024 workgroup partials instead of 3566 for the ticketed reduction;
+//  * write-through and non-temporal stores of d, r, x were tried (no gain) and are gone.
 __device__ __forceinline__ double vcg_ld(const double *base, const unsigned off) { return *(const double *)((const char *)base + off); }
 __device__ __forceinline__ double *vcg_ptr(double *base, const unsigned off) { return (double *)((char *)base + off); }
 
-// ST: 0 plain stores, 1 write-through (sc1, agent-scope atomic store), 2 non-temporal - A/B of what the kernel
-// leaves dirty in the L2s for the end-of-kernel write-back (LGH_K2_STORE)
-template <int ST> __device__ __forceinline__ void vcg_st(double *p, const double v)
-{
-   if (ST == 1) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-   else if (ST == 2) { __builtin_nontemporal_store(v, p); }
-   else { *p = v; }
-}
-template <bool XU, int ST>
+template <bool XU, int U>
 __global__ void __launch_bounds__(512)
 vcg_update_p_k(const VcgArgs a)
 {
-   constexpr int U = 2, NT = 512;
+   constexpr int NT = 512;
    __shared__ double red[16];
    if (a.s->all_done) { return; }
    const int it = a.iter;
@@ -1374,12 +1369,12 @@ vcg_update_p_k(const VcgArgs a)
             const double rnew = ro[u][k] - alpha[k] * z_;
             if (ok[u] && todo[k])
             {
-               vcg_st<ST>(vcg_ptr(a.d, vb), dnew);
-               vcg_st<ST>(vcg_ptr(a.r, vb), rnew);
+               *vcg_ptr(a.d, vb) = dnew;
+               *vcg_ptr(a.r, vb) = rnew;
                if (XU)
                {
                   const double x0 = xload ? xo[u][k] : 0.0;
-                  vcg_st<ST>(vcg_ptr(a.x, vb), fma(alpha[k], dnew, fma(alpha_prev[k], first ? 0.0 : dol[u][k], x0)));
+                  *vcg_ptr(a.x, vb) = fma(alpha[k], dnew, fma(alpha_prev[k], first ? 0.0 : dol[u][k], x0));
                }
                part[k] += rnew * __dmul_rn(rnew, di[u]);
             }
@@ -1603,7 +1598,7 @@ int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
          hipDeviceProp_t prop;
          if (hipGetDeviceProperties(&prop, c->device) == hipSuccess) { ncu = prop.multiProcessorCount; }
          static const char *genv = getenv("LGH_K2_GRID"); // A/B: workgroups (= node ranges) per CU
-         x->grid2 = ((genv && atoi(genv) > 0) ? atoi(genv) : 2) * ncu;
+         x->grid2 = ((genv && atoi(genv) > 0) ? atoi(genv) : 4) * ncu;
          rc = make_ellz(c, &x->ellz);
          if (rc) { return rc; }
          rc = make_essbits(c, &x->essbits);
@@ -1727,11 +1722,11 @@ int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
          if (k2p)
          {
             kt_begin(c, LGH_KERNEL_CG_UPDATE_H1);
-            static const char *stenv = getenv("LGH_K2_STORE");
-            const int st = stenv ? atoi(stenv) : 0;
-#define LGH_K2P_LAUNCH(XU_, ST_) hipLaunchKernelGGL((vcg_update_p_k<XU_, ST_>), dim3(aux->grid2), dim3(512), 0, c->stream, a)
-            if (it & 1) { if (st == 1) { LGH_K2P_LAUNCH(false, 1); } else if (st == 2) { LGH_K2P_LAUNCH(false, 2); } else { LGH_K2P_LAUNCH(false, 0); } }
-            else { if (st == 1) { LGH_K2P_LAUNCH(true, 1); } else if (st == 2) { LGH_K2P_LAUNCH(true, 2); } else { LGH_K2P_LAUNCH(true, 0); } }
+            static const char *uenv = getenv("LGH_K2_U"); // A/B: nodes per thread and pass (2: 182 VGPRs, one workgroup per CU resident)
+            const int u2 = (uenv && uenv[0] == '2') ? 1 : 0;
+#define LGH_K2P_LAUNCH(XU_, U_) hipLaunchKernelGGL((vcg_update_p_k<XU_, U_>), dim3(aux->grid2), dim3(512), 0, c->stream, a)
+            if (it & 1) { if (u2) { LGH_K2P_LAUNCH(false, 2); } else { LGH_K2P_LAUNCH(false, 1); } }
+            else { if (u2) { LGH_K2P_LAUNCH(true, 2); } else { LGH_K2P_LAUNCH(true, 1); } }
 #undef LGH_K2P_LAUNCH
             kt_end(c, LGH_KERNEL_CG_UPDATE_H1);
          }
