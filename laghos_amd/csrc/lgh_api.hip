@@ -298,11 +298,11 @@ static int create_impl(const lgh_config *cfg, lgh_ctx *c, const int kid)
       const char *env = getenv("LGH_FUSED_FTV"); // A/B: 0 = F^T v always by its own kernel
       if (!(env && env[0] == '0')) { LGH_TRY(dev_alloc_zero(&c->erhs_q, (size_t)c->L2V)); }
       env = getenv("LGH_FUSED_F1");              // A/B: 0 = F.1 always by its own kernel
-      if (c->dim == 3 && !(env && env[0] == '0')) { LGH_TRY(dev_alloc_zero(&c->force_e_q, nmap * dim)); }
+      if (c->dim == 3 && !(env && env[0] == '0')) { LGH_TRY(dev_alloc_zero(&c->force_e_q, nmap * dim + (size_t)dim * c->ND)); } // (+ a zero element: vcg_init_force_z_k)
    }
    const size_t ne_nd = nmap * dim;
    LGH_TRY(dev_alloc_zero(&c->XE, std::max<size_t>(ne_nd, (size_t)c->L2V)));
-   LGH_TRY(dev_alloc_zero(&c->YE, ne_nd));
+   LGH_TRY(dev_alloc_zero(&c->YE, ne_nd + (size_t)dim * c->ND)); // (+ a zero element: vcg_init_force_z_k)
    const size_t nv = std::max<size_t>((size_t)c->N, (size_t)c->L2V);
    LGH_TRY(dev_alloc_zero(&c->cg_r, nv));
    LGH_TRY(dev_alloc_zero(&c->cg_z, nv));

@@ -987,6 +987,10 @@ vcg_apply_plane_ho(const VcgArgs a)
    }
 }
 
+// base pointer + 32-bit byte offset: one SGPR pair and one VGPR per address
+__device__ __forceinline__ double vcg_ld(const double *base, const unsigned off) { return *(const double *)((const char *)base + off); }
+__device__ __forceinline__ double *vcg_ptr(double *base, const unsigned off) { return (double *)((char *)base + off); }
+
 // ---- init: r = b (x = 0), z = r/diag, nom_c = (z_c, r_c)
 __global__ void __launch_bounds__(256)
 vcg_init_k(const VcgArgs a)
@@ -1099,6 +1103,92 @@ vcg_init_force_k(const VcgArgs a, const double *__restrict__ FE, const int ND, d
          s->all_done = all;
       }
    }
+}
+// The same kernel over a table of byte offsets into the force E-vector ([e][c][d]; absent contributions point at
+// a zero element behind it - element NE, all components): no index arithmetic, no predicates, and slots no node of the wavefront uses are not
+// fetched (as in vcg_update_p_k).  Same node -> workgroup map and summation orders as above: the same bits.
+__global__ void __launch_bounds__(256)
+vcg_init_force_z_k(const VcgArgs a, const double *__restrict__ FE, const unsigned compb_fe, const unsigned *__restrict__ ellf,
+                   double *__restrict__ bout)
+{
+   __shared__ double red[16];
+   const int n = xcd_swizzle(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
+   const bool ok = n < a.N;
+   const unsigned nn = (unsigned)(ok ? n : a.N - 1);
+   const unsigned rowb = 4u * (unsigned)a.N;
+   unsigned ix[8];
+#pragma unroll
+   for (int j = 0; j < 8; j++) { ix[j] = *(const unsigned *)((const char *)ellf + (4u * nn + (unsigned)j * rowb)); }
+   const double di = vcg_ld(a.dinv, 8u * nn);
+   const unsigned es = a.essbits[nn];
+   const unsigned zoff = 8u * (unsigned)kVC * (unsigned)(a.ye_stride - kYePad); // = 8 * kVC * ND * NE
+   double fe[kVC][8];
+#pragma unroll
+   for (int j = 0; j < 8; j++)
+   {
+      if (j == 0 || __any(ix[j] != zoff))
+      {
+#pragma unroll
+         for (int c = 0; c < kVC; c++) { fe[c][j] = vcg_ld(FE, ix[j] + (unsigned)c * compb_fe); }
+      }
+      else
+      {
+#pragma unroll
+         for (int c = 0; c < kVC; c++) { fe[c][j] = 0.0; }
+      }
+   }
+   double part[kVC];
+#pragma unroll
+   for (int c = 0; c < kVC; c++)
+   {
+      double s = 0.0;
+#pragma unroll
+      for (int j = 0; j < 8; j++) { s += fe[c][j]; }
+      double bv = -s;
+      if ((es >> c) & 1u) { bv = 0.0; }
+      part[c] = ok ? __dmul_rn(bv, di) * bv : 0.0;
+      if (ok)
+      {
+         const size_t i = (size_t)c * a.N + n;
+         bout[i] = bv;
+         a.r[i] = bv;
+         a.x[i] = 0.0;
+      }
+   }
+   double bp[kVC], total[kVC];
+#pragma unroll
+   for (int c = 0; c < kVC; c++)
+   {
+      bp[c] = block_sum(part[c], red);
+      __syncthreads();
+   }
+   if (grid_sum3_last_block(bp, a.partials, a.stride, a.ticket, red, total))
+   {
+      if (threadIdx.x == 0)
+      {
+         VcgScalars *s = a.s;
+         int all = 1;
+         for (int c = 0; c < kVC; c++)
+         {
+            s->rz[c] = s->rz_prev[c] = total[c];
+            s->iters[c] = 0;
+            s->r0[c] = fmax(total[c] * s->rel_tol2, 0.0);
+            s->done[c] = (total[c] < 0.0 || total[c] <= s->r0[c]) ? 1 : 0;
+            all = all && s->done[c];
+         }
+         s->first = 1;
+         s->all_done = all;
+      }
+   }
+}
+__global__ void __launch_bounds__(256)
+vcg_ellf_k(const int *__restrict__ ell, unsigned *__restrict__ ellf, const size_t n_have, const size_t n_all, const int ND, const int NE)
+{
+   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+   if (i >= n_all) { return; }
+   const int p = (i < n_have) ? ell[i] : -1; // e*ND + d
+   const int e = p / ND;
+   ellf[i] = 8u * (unsigned)(p < 0 ? kVC * ND * NE : kVC * ND * e + (p - e * ND));
 }
 __global__ void vcg_init_finish_k(VcgScalars *s)
 {
@@ -1251,8 +1341,6 @@ vcg_update_k(const VcgArgs a)
 //    22 MB less traffic per iteration on average at C2;
 //  * 1024 workgroup partials instead of 3566 for the ticketed reduction;
 //  * write-through and non-temporal stores of d, r, x were tried (no gain) and are gone.
-__device__ __forceinline__ double vcg_ld(const double *base, const unsigned off) { return *(const double *)((const char *)base + off); }
-__device__ __forceinline__ double *vcg_ptr(double *base, const unsigned off) { return (double *)((char *)base + off); }
 
 template <bool XU, int U>
 __global__ void __launch_bounds__(512)
@@ -1473,6 +1561,7 @@ struct VcgAux
    unsigned *ellz = nullptr;
    uint8_t *essbits = nullptr;
    int *nstart = nullptr;    // cost-balanced node ranges of the grid2 workgroups of vcg_update_p_k
+   unsigned *ellf = nullptr; // ELL transpose as byte offsets into a force E-vector ([e][c][d] + zero slot): vcg_init_force_z_k
    int grid2 = 0;
 };
 void vcg_free(lgh_ctx *c)
@@ -1483,6 +1572,7 @@ void vcg_free(lgh_ctx *c)
    (void)hipFree(x->ellz);
    (void)hipFree(x->essbits);
    (void)hipFree(x->nstart);
+   (void)hipFree(x->ellf);
    delete x;
    c->vcg_aux = nullptr;
 }
@@ -1605,6 +1695,14 @@ int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
          if (rc) { return rc; }
          rc = partition_nodes_by_cost(c, x->grid2, &x->nstart);
          if (rc) { return rc; }
+         if ((size_t)kVC * (c->NE + 1) * c->ND * 8 < 0xffffffffull)
+         {
+            const size_t ell_n = (size_t)8 * c->N;
+            LGH_HIP_CHECK(hipMalloc((void **)&x->ellf, ell_n * sizeof(unsigned)));
+            hipLaunchKernelGGL(vcg_ellf_k, dim3((unsigned)((ell_n + 255) / 256)), dim3(256), 0, nullptr, c->t_ell, x->ellf,
+                               (size_t)c->t_deg * c->N, ell_n, c->ND, c->NE);
+            LGH_HIP_CHECK(hipGetLastError());
+         }
       }
       LGH_HIP_CHECK(hipStreamSynchronize(nullptr)); // the fills run asynchronously on the null stream
    }
@@ -1660,7 +1758,11 @@ int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
    if (force_E)
    {
       if (multi || c->t_deg > 8) { set_error("vcg_solve: fused init is single-rank, degree <= 8"); return LGH_ERR_ARG; }
-      hipLaunchKernelGGL(vcg_init_force_k<8>, dim3(nb), dim3(256), 0, c->stream, a, force_E, c->ND, B);
+      if (aux->ellf && aux->essbits)
+      {
+         hipLaunchKernelGGL(vcg_init_force_z_k, dim3(nb), dim3(256), 0, c->stream, a, force_E, 8u * (unsigned)c->ND, aux->ellf, B);
+      }
+      else { hipLaunchKernelGGL(vcg_init_force_k<8>, dim3(nb), dim3(256), 0, c->stream, a, force_E, c->ND, B); }
    }
    else { hipLaunchKernelGGL(vcg_init_k, dim3(nb), dim3(256), 0, c->stream, a); }
    LGH_HIP_CHECK(hipGetLastError());
