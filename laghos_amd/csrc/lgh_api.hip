@@ -238,6 +238,18 @@ static int create_impl(const lgh_config *cfg, lgh_ctx *c, const int kid)
    int rc;
 #define LGH_TRY(x) do { rc = (x); if (rc) { return rc; } } while (0)
    LGH_TRY(dev_alloc_copy(&c->B, cfg->B_h1, (size_t)c->Q1D * c->D1D));
+   {
+      // mirror symmetry of the table (every nodal or Bernstein basis on symmetric points has it); LGH_B_SYM=0: assume not
+      const int QD = c->Q1D * c->D1D;
+      const char *env = getenv("LGH_B_SYM");
+      int sym = !(env && env[0] == '0');
+      for (int i = 0; i < QD && sym; i++)
+      {
+         const double u = cfg->B_h1[i], v = cfg->B_h1[QD - 1 - i];
+         if (std::fabs(u - v) > 8.9e-16 * std::max(1.0, std::max(std::fabs(u), std::fabs(v)))) { sym = 0; }
+      }
+      c->b_h1_sym = sym;
+   }
    LGH_TRY(dev_alloc_copy(&c->G, cfg->G_h1, (size_t)c->Q1D * c->D1D));
    LGH_TRY(dev_alloc_copy(&c->Bl, cfg->B_l2, (size_t)c->Q1D * c->L1D));
    LGH_TRY(dev_alloc_copy(&c->W, cfg->weights, (size_t)c->NQ));

@@ -136,6 +136,7 @@ struct lgh_ctx
    unsigned vcg_stride;
    int vcg_last;
    int vcg_grid;         // persistent grid size of the K1 kernel (one resident wave)
+   int b_h1_sym;         // the 1-D H1 table is mirror symmetric, B[q,d] = B[Q-1-q, D-1-d] (to 4 ulp): kernels may hold half of it
    int vcg_variant;      // LGH_VCG_VARIANT: which K1 form vcg_solve launches (lgh_vcg.hip)
    void *vcg_aux;        // tables of the node kernel K2 (lgh_vcg.hip VcgAux), allocated on first use
    void *pcg;            // state of the persistent solve kernel (lgh_pcg.hip), allocated on first use

@@ -221,7 +221,6 @@ struct VcgArgs
    const uint8_t *essbits;    // bit k: node essential for component k
    const int *nstart;         // node range of block w: [nstart[w], nstart[w+1]), balanced by cost
    int k2_skip;               // vcg_update_p_k: skip ELL slots no node of the wavefront uses (LGH_K2_SKIP=0: fetch all 8)
-   int ye_store;              // K1 (plane form): 0 plain, 1 write-through, 2 non-temporal stores of Y_E (LGH_K1_STORE)
 };
 
 // ---- K1: y_e^c = B^T D_e B d_e^c for the unconverged components, d^c = z^c + beta_c d^c.
@@ -498,7 +497,7 @@ __device__ __forceinline__ double uniform_f64(const double v)
    return __hiloint2double(hi, lo);
 }
 
-template <int D, int Q, int NEB>
+template <int D, int Q, int NEB, bool SYM>
 __global__ void __launch_bounds__(kVC *Q *NEB, 2)
 vcg_apply_plane(const VcgArgs a, const int nbatch)
 {
@@ -530,12 +529,15 @@ vcg_apply_plane(const VcgArgs a, const int nbatch)
 
    int mi[GPT];
    auto load_map = [&](const int b) {
-      const int e0 = b * NEB, nel = min(NEB, a.NE - e0);
+      // (no predicates on the loads of the pipeline: items beyond a ragged last batch read a valid entry, their values
+      // are never written to LDS - predicated loads cost a branch each and cut the loop into 40 basic blocks that the
+      // scheduler cannot interleave with the contractions)
+      const int e0 = b * NEB, last = min(NEB, a.NE - e0) * ND - 1;
 #pragma unroll
       for (int k = 0; k < GPT; k++)
       {
          const int i = tid + k * NT;
-         mi[k] = (i < nel * ND) ? a.map[(size_t)e0 * ND + i] : -1;
+         mi[k] = a.map[(size_t)e0 * ND + min(i, last)];
       }
    };
    int b = xcd_swizzle(blockIdx.x, G);
@@ -553,9 +555,14 @@ vcg_apply_plane(const VcgArgs a, const int nbatch)
    const bool mine = (c == 0) ? todo[0] : (c == 1) ? todo[1] : todo[2];
    // 1-D table: scalar registers for the register-resident contractions, this
    // thread's row / column for the two x contractions
-   double Bs[Q * D];
+   // SYM: the table is mirror symmetric, B[q,d] = B[Q-1-q, D-1-d] (Gauss-Lobatto or Bernstein basis at Gauss-Legendre
+   // points; checked by lgh_create), and half of it serves all indices - 24 scalar registers less, without which
+   // the kernel spills 40 of them to vector lanes and reads them back ~50 times per batch
+   constexpr int QD = Q * D, HB = SYM ? (QD + 1) / 2 : QD;
+   double Bsr[HB];
 #pragma unroll
-   for (int i = 0; i < Q * D; i++) { Bs[i] = uniform_f64(a.B[i]); }
+   for (int i = 0; i < HB; i++) { Bsr[i] = uniform_f64(a.B[i]); }
+   auto Bs = [&](const int idx) -> double { return (SYM && idx >= HB) ? Bsr[QD - 1 - idx] : Bsr[idx]; };
    double bx[D], bt[Q];
 #pragma unroll
    for (int dx = 0; dx < D; dx++) { bx[dx] = a.B[qx + Q * dx]; }
@@ -571,25 +578,25 @@ vcg_apply_plane(const VcgArgs a, const int nbatch)
    double gz[kVC][GPT], gd[kVC][GPT], gi[GPT], dq[DPT];
    auto load_gather = [&]() { // nodes of mi[]: residual r, direction d, 1/diag
 #pragma unroll
-      for (int k = 0; k < GPT; k++) { gi[k] = (mi[k] >= 0) ? a.dinv[mi[k]] : 0.0; }
+      for (int k = 0; k < GPT; k++) { gi[k] = a.dinv[mi[k]]; }
 #pragma unroll
       for (int k2 = 0; k2 < kVC; k2++)
       {
 #pragma unroll
          for (int k = 0; k < GPT; k++)
          {
-            gz[k2][k] = (mi[k] >= 0) ? a.r[(size_t)k2 * a.N + mi[k]] : 0.0;
-            gd[k2][k] = (mi[k] >= 0 && !first) ? a.d[(size_t)k2 * a.N + mi[k]] : 0.0;
+            gz[k2][k] = a.r[(size_t)k2 * a.N + mi[k]];
+            gd[k2][k] = first ? 0.0 : a.d[(size_t)k2 * a.N + mi[k]];
          }
       }
    };
    auto load_dq = [&](const int bb) {
-      const int e = bb * NEB + eb;
+      const int e = min(bb * NEB + eb, a.NE - 1);
 #pragma unroll
       for (int k = 0; k < DPT; k++)
       {
          const int j = lt + k * TE;
-         dq[k] = (e < a.NE && j < NQ) ? a.Dq[(size_t)e * NQ + j] : 0.0;
+         dq[k] = a.Dq[(size_t)e * NQ + ((DPT * TE == NQ) ? j : min(j, NQ - 1))];
       }
    };
 
@@ -626,7 +633,7 @@ vcg_apply_plane(const VcgArgs a, const int nbatch)
       for (int k = 0; k < DPT; k++)
       {
          const int j = lt + k * TE;
-         if (j < NQ) { sD[j] = dq[k]; }
+         if ((DPT * TE == NQ) || j < NQ) { sD[j] = dq[k]; }
       }
       // next batch: gathers and quadrature data now, the map of the one after
       const int bn = b + G;
@@ -657,7 +664,7 @@ vcg_apply_plane(const VcgArgs a, const int nbatch)
          {
             double u = 0.0;
 #pragma unroll
-            for (int dy = 0; dy < D; dy++) { u = fma(Bs[qy + Q * dy], t[dy + D * dz], u); }
+            for (int dy = 0; dy < D; dy++) { u = fma(Bs(qy + Q * dy), t[dy + D * dz], u); }
             w[qy][dz] = u;
          }
       }
@@ -671,7 +678,7 @@ vcg_apply_plane(const VcgArgs a, const int nbatch)
          {
             double u = 0.0;
 #pragma unroll
-            for (int dz = 0; dz < D; dz++) { u = fma(Bs[qz + Q * dz], w[qy][dz], u); }
+            for (int dz = 0; dz < D; dz++) { u = fma(Bs(qz + Q * dz), w[qy][dz], u); }
             cz[qz] = u * sD[qx + Q * (qy + Q * qz)];
          }
 #pragma unroll
@@ -679,7 +686,7 @@ vcg_apply_plane(const VcgArgs a, const int nbatch)
          {
             double u = 0.0;
 #pragma unroll
-            for (int qz = 0; qz < Q; qz++) { u = fma(Bs[qz + Q * dz], cz[qz], u); }
+            for (int qz = 0; qz < Q; qz++) { u = fma(Bs(qz + Q * dz), cz[qz], u); }
             w[qy][dz] = u;
          }
       }
@@ -692,7 +699,7 @@ vcg_apply_plane(const VcgArgs a, const int nbatch)
          {
             double u = 0.0;
 #pragma unroll
-            for (int qy = 0; qy < Q; qy++) { u = fma(Bs[qy + Q * dy], w[qy][dz], u); }
+            for (int qy = 0; qy < Q; qy++) { u = fma(Bs(qy + Q * dy), w[qy][dz], u); }
             sE[qx + Q * (dy + D * dz)] = u;
          }
       }
@@ -707,9 +714,7 @@ vcg_apply_plane(const VcgArgs a, const int nbatch)
             double u = 0.0;
 #pragma unroll
             for (int q = 0; q < Q; q++) { u = fma(bt[q], sE[q + Q * k], u); }
-            if (a.ye_store == 1) { __hip_atomic_store(&yc[qx + D * k], u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-            else if (a.ye_store == 2) { __builtin_nontemporal_store(u, &yc[qx + D * k]); }
-            else { yc[qx + D * k] = u; }
+            yc[qx + D * k] = u;
             dot = fma(sIn[qx + D * k], u, dot);
          }
       }
@@ -1599,14 +1604,15 @@ template <int D, int Q> static void launch_vcg_plane(lgh_ctx *c, const VcgArgs &
       int per_cu = 0, ncu = 256;
       hipDeviceProp_t prop;
       if (hipGetDeviceProperties(&prop, c->device) == hipSuccess) { ncu = prop.multiProcessorCount; }
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, vcg_apply_plane<D, Q, NEB>, kVC * Q * NEB, 0) != hipSuccess || per_cu <= 0)
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, vcg_apply_plane<D, Q, NEB, true>, kVC * Q * NEB, 0) != hipSuccess || per_cu <= 0)
       {
          per_cu = 2;
       }
       c->vcg_grid = per_cu * ncu;
    }
    const int grid = std::min(nbatch, c->vcg_grid);
-   hipLaunchKernelGGL((vcg_apply_plane<D, Q, NEB>), dim3(grid), dim3(kVC * Q * NEB), 0, c->stream, a, nbatch);
+   if (c->b_h1_sym) { hipLaunchKernelGGL((vcg_apply_plane<D, Q, NEB, true>), dim3(grid), dim3(kVC * Q * NEB), 0, c->stream, a, nbatch); }
+   else { hipLaunchKernelGGL((vcg_apply_plane<D, Q, NEB, false>), dim3(grid), dim3(kVC * Q * NEB), 0, c->stream, a, nbatch); }
 }
 
 template <int D, int Q, int HY, int NEB> static void launch_vcg_plane_ho(lgh_ctx *c, const VcgArgs &a)
@@ -1737,8 +1743,6 @@ int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
    {
       static const char *e0 = getenv("LGH_K2_SKIP");
       a.k2_skip = (e0 && e0[0] == '0') ? 0 : 1;
-      static const char *e1 = getenv("LGH_K1_STORE");
-      a.ye_store = e1 ? atoi(e1) : 0;
    }
    a.s = ds;
    a.stride = c->vcg_stride;
@@ -1808,12 +1812,12 @@ int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
             case 0x334: VCG_DISPATCH(3, 4); break;
             case 0x346: VCG_DISPATCH(4, 6); break;
             case 0x358: // LGH_VCG_VARIANT=1: the two-lanes-per-plane split at Q1D = 8 as well (A/B, tests)
-               if (c->vcg_variant == 0) { launch_vcg_apply<5, 8>(c, a); }
+               if (c->vcg_variant == 0 || !c->b_h1_sym) { launch_vcg_apply<5, 8>(c, a); } // (the plane form uses half a table)
                else if (c->vcg_variant == 1) { launch_vcg_plane_ho<5, 8, 2, 5>(c, a); }
                else { launch_vcg_plane_ho<5, 8, 1, 5>(c, a); }
                break;
             case 0x36A:
-               if (c->vcg_variant == 0) { launch_vcg_apply<6, 10>(c, a); }
+               if (c->vcg_variant == 0 || !c->b_h1_sym) { launch_vcg_apply<6, 10>(c, a); }
                else { launch_vcg_plane_ho<6, 10, 2, 4>(c, a); }
                break;
          }
