@@ -267,16 +267,21 @@ qpoint_kernel(const QArgs a)
          // x stage: [k][fl][dz][dy][qx]
          if (NFIELD > 0)
          {
+            // qx = i % Q is the same for every item of a thread (the stride Q^3 is a multiple of Q): its table rows
+            // are read once, not per item - LDS issue, shared by the four SIMDs, is scarcer than FMA issue
+            double bxr[D], gxr[D];
+#pragma unroll
+            for (int dx = 0; dx < D; dx++) { bxr[dx] = sB[tx + Q * dx]; gxr[dx] = sG[tx + Q * dx]; }
             for (int i = lt; i < NF * D * D * Q; i += NTE)
             {
-               const int qx = i % Q, dy = (i / Q) % D, dz = (i / (Q * D)) % D, fl = i / (Q * D * D);
+               const int dy = (i / Q) % D, dz = (i / (Q * D)) % D, fl = i / (Q * D * D);
                double u = 0.0, w = 0.0;
 #pragma unroll
                for (int dx = 0; dx < D; dx++)
                {
                   const double s = sU[dx + D * (dy + D * dz) + ND * fl];
-                  u += sB[qx + Q * dx] * s;
-                  w += sG[qx + Q * dx] * s;
+                  u += bxr[dx] * s;
+                  w += gxr[dx] * s;
                }
                sX[i] = u;
                sX[i + NF * D * D * Q] = w;
@@ -297,18 +302,21 @@ qpoint_kernel(const QArgs a)
          // y stage: BB, GB, BG [k][fl][dz][qy][qx]
          if (NFIELD > 0)
          {
+            double byr[D], gyr[D]; // (qx, qy) = (tx, ty) for every item of a thread: the stride is a multiple of Q^2
+#pragma unroll
+            for (int dy = 0; dy < D; dy++) { byr[dy] = sB[ty + Q * dy]; gyr[dy] = sG[ty + Q * dy]; }
             for (int i = lt; i < NF * D * Q * Q; i += NTE)
             {
-               const int qx = i % Q, qy = (i / Q) % Q, dz = (i / (Q * Q)) % D, fl = i / (Q * Q * D);
+               const int dz = (i / (Q * Q)) % D, fl = i / (Q * Q * D);
                double bb = 0.0, gb = 0.0, bg = 0.0;
 #pragma unroll
                for (int dy = 0; dy < D; dy++)
                {
-                  const int j = qx + Q * (dy + D * (dz + D * fl));
+                  const int j = tx + Q * (dy + D * (dz + D * fl));
                   const double vb = sX[j], vg = sX[j + NF * D * D * Q];
-                  bb += sB[qy + Q * dy] * vb;
-                  gb += sB[qy + Q * dy] * vg;
-                  bg += sG[qy + Q * dy] * vb;
+                  bb += byr[dy] * vb;
+                  gb += byr[dy] * vg;
+                  bg += gyr[dy] * vb;
                }
                sY[i] = bb;
                sY[i + NF * D * Q * Q] = gb;
@@ -506,6 +514,15 @@ qpoint_kernel(const QArgs a)
                // ---- y
                if (do_f)
                {
+                  // (dy is the same for every item of a thread where the stride is a multiple of Q*D: table columns in registers)
+                  constexpr bool YINV = (NTE % (Q * D) == 0);
+                  double byf[YINV ? Q : 1], gyf[YINV ? Q : 1];
+                  if constexpr (YINV)
+                  {
+                     const int dy0 = (lt / Q) % D;
+#pragma unroll
+                     for (int qy = 0; qy < Q; qy++) { byf[qy] = sB[qy + Q * dy0]; gyf[qy] = sG[qy + Q * dy0]; }
+                  }
                   for (int i = lt; i < CP * 2 * D * D * Q; i += NTE)
                   {
                      const int qx = i % Q, dy = (i / Q) % D, dz = (i / (Q * D)) % D, wh = (i / (Q * D * D)) % 2, cc = i / (Q * D * D * 2);
@@ -516,12 +533,15 @@ qpoint_kernel(const QArgs a)
                      if (wh == 0)
                      {
 #pragma unroll
-                        for (int qy = 0; qy < Q; qy++) { u += sB[qy + Q * dy] * a0[Q * qy]; } // gd 0: G in x below
+                        for (int qy = 0; qy < Q; qy++) { u += (YINV ? byf[qy] : sB[qy + Q * dy]) * a0[Q * qy]; } // gd 0: G in x below
                      }
                      else
                      {
 #pragma unroll
-                        for (int qy = 0; qy < Q; qy++) { u += sG[qy + Q * dy] * a1[Q * qy] + sB[qy + Q * dy] * a2[Q * qy]; }
+                        for (int qy = 0; qy < Q; qy++)
+                        {
+                           u += (YINV ? gyf[qy] : sG[qy + Q * dy]) * a1[Q * qy] + (YINV ? byf[qy] : sB[qy + Q * dy]) * a2[Q * qy];
+                        }
                      }
                      sW[i] = u;
                   }
@@ -541,6 +561,13 @@ qpoint_kernel(const QArgs a)
                // ---- x
                if (do_f)
                {
+                  constexpr bool XINV = (NTE % D == 0); // dx = i % D is then the same for every item of a thread
+                  double bxf[XINV ? Q : 1], gxf[XINV ? Q : 1];
+                  if constexpr (XINV)
+                  {
+#pragma unroll
+                     for (int qx = 0; qx < Q; qx++) { bxf[qx] = sB[qx + Q * (lt % D)]; gxf[qx] = sG[qx + Q * (lt % D)]; }
+                  }
                   for (int i = lt; i < CP * ND; i += NTE)
                   {
                      const int dx = i % D, dy = (i / D) % D, dz = (i / (D * D)) % D, cc = i / ND;
@@ -548,7 +575,7 @@ qpoint_kernel(const QArgs a)
                      const double *wb = sW + Q * (dy + D * (dz + D * (1 + 2 * cc)));
                      double r = 0.0;
 #pragma unroll
-                     for (int qx = 0; qx < Q; qx++) { r += sG[qx + Q * dx] * wg[qx] + sB[qx + Q * dx] * wb[qx]; }
+                     for (int qx = 0; qx < Q; qx++) { r += (XINV ? gxf[qx] : sG[qx + Q * dx]) * wg[qx] + (XINV ? bxf[qx] : sB[qx + Q * dx]) * wb[qx]; }
                      if (fabs(r) < eps2) { r = 0.0; } // laghos_assembly.cpp:495-512
                      if (active) { a.force_e[dx + D * (dy + D * dz) + (size_t)ND * ((c0 + cc) + 3 * (size_t)e)] = r; }
                   }
