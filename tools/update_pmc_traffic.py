@@ -24,7 +24,7 @@ def median_of(path, kernel, counter):
 
 
 def main(fsum, wsum):
-    k = "vcg_apply_plane<4, 6, 13>"
+    k = "vcg_apply_plane<4, 6, 13"
     f, n = median_of(fsum, k, "FETCH_SIZE")
     w, _ = median_of(wsum, k, "WRITE_SIZE")
     pj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
