@@ -579,12 +579,13 @@ template <int MODE> static int launch_mass(lgh_ctx *c, int space, const MassArgs
                          dim3(Q_ * Q_ * NEB_), 0, c->stream, a);                              \
    }                                                                                          \
    break
-   if ((MODE == 0 || MODE == 3) && space == LGH_SPACE_L2 && (id == 0x348 || id == 0x35A))
+   if ((MODE == 0 || MODE == 3) && space == LGH_SPACE_L2 && (id == 0x336 || id == 0x348 || id == 0x35A))
    {
       static const char *penv = getenv("LGH_L2_PLANE"); // A/B: 0 = column form
       if (!(penv && penv[0] == '0'))
       {
-         if (id == 0x348) { hipLaunchKernelGGL((mass_apply_l2_plane<4, 8, 1, 32, (MODE == 3 ? 3 : 0)>), dim3(ceil_div(c->NE, 32)), dim3(256), 0, c->stream, a); }
+         if (id == 0x336) { hipLaunchKernelGGL((mass_apply_l2_plane<3, 6, 1, 42, (MODE == 3 ? 3 : 0)>), dim3(ceil_div(c->NE, 42)), dim3(252), 0, c->stream, a); }
+         else if (id == 0x348) { hipLaunchKernelGGL((mass_apply_l2_plane<4, 8, 1, 32, (MODE == 3 ? 3 : 0)>), dim3(ceil_div(c->NE, 32)), dim3(256), 0, c->stream, a); }
          else { hipLaunchKernelGGL((mass_apply_l2_plane<5, 10, 2, 12, (MODE == 3 ? 3 : 0)>), dim3(ceil_div(c->NE, 12)), dim3(240), 0, c->stream, a); }
          LGH_HIP_CHECK(hipGetLastError());
          return LGH_OK;
