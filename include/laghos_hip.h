@@ -230,6 +230,10 @@ int lgh_ktime_end(lgh_ctx *ctx, int *launches, double *mean_seconds);
  * together) executed since the last call; resets the counter.  With lgh_ktime_* on
  * LGH_KERNEL_PCG this gives the time of one fused CG iteration. */
 int lgh_pcg_iterations(lgh_ctx *ctx, long *iterations);
+/* Whether lgh_create found the 1-D H1 / L2 tables mirror symmetric, B[q,d] = B[Q-1-q, D-1-d] (any nodal or
+ * Bernstein basis on symmetric points is): the plane-form mass kernels keep half a table in scalar registers
+ * and are only dispatched then (the column forms run otherwise). */
+int lgh_table_symmetry(lgh_ctx *ctx, int *h1, int *l2);
 
 /* ---- multi-GPU: element blocks per rank, shared H1 nodes summed
  * over RCCL, dot products / dt all-reduced.  unique_id is the 128-byte

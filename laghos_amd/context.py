@@ -221,6 +221,12 @@ class Context:
     def qupdate_set_tiny_grad(self, v):
         check(self.lib.lgh_qupdate_set_tiny_grad(self.h, float(v)))
 
+    def table_symmetry(self):
+        """(h1, l2): whether lgh_create found the 1-D tables mirror symmetric (plane-form mass kernels need it)."""
+        a, b = ctypes.c_int(-1), ctypes.c_int(-1)
+        check(self.lib.lgh_table_symmetry(self.h, ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
+
     def solve_velocity(self, S, dS, one, rhs, work, rel_tol, max_iter):
         it = ctypes.c_int(0)
         check(self.lib.lgh_solve_velocity(self.h, _ptr(S), _ptr(dS), _ptr(one), _ptr(rhs), _ptr(work),

@@ -239,16 +239,19 @@ static int create_impl(const lgh_config *cfg, lgh_ctx *c, const int kid)
 #define LGH_TRY(x) do { rc = (x); if (rc) { return rc; } } while (0)
    LGH_TRY(dev_alloc_copy(&c->B, cfg->B_h1, (size_t)c->Q1D * c->D1D));
    {
-      // mirror symmetry of the table (every nodal or Bernstein basis on symmetric points has it); LGH_B_SYM=0: assume not
-      const int QD = c->Q1D * c->D1D;
+      // mirror symmetry of the tables (every nodal or Bernstein basis on symmetric points has it); LGH_B_SYM=0: assume not
       const char *env = getenv("LGH_B_SYM");
-      int sym = !(env && env[0] == '0');
-      for (int i = 0; i < QD && sym; i++)
-      {
-         const double u = cfg->B_h1[i], v = cfg->B_h1[QD - 1 - i];
-         if (std::fabs(u - v) > 8.9e-16 * std::max(1.0, std::max(std::fabs(u), std::fabs(v)))) { sym = 0; }
-      }
-      c->b_h1_sym = sym;
+      auto mirror = [&](const double *B, const int n) {
+         if (env && env[0] == '0') { return 0; }
+         for (int i = 0; i < n; i++)
+         {
+            const double u = B[i], v = B[n - 1 - i];
+            if (std::fabs(u - v) > 1e-14 * std::max(1.0, std::max(std::fabs(u), std::fabs(v)))) { return 0; } // (1e-15 at order 5)
+         }
+         return 1;
+      };
+      c->b_h1_sym = mirror(cfg->B_h1, c->Q1D * c->D1D);
+      c->b_l2_sym = mirror(cfg->B_l2, c->Q1D * c->L1D);
    }
    LGH_TRY(dev_alloc_copy(&c->G, cfg->G_h1, (size_t)c->Q1D * c->D1D));
    LGH_TRY(dev_alloc_copy(&c->Bl, cfg->B_l2, (size_t)c->Q1D * c->L1D));
@@ -837,6 +840,13 @@ int lgh_qupdate_set_tiny_grad(lgh_ctx *c, double tiny_grad)
    return LGH_OK;
 }
 
+int lgh_table_symmetry(lgh_ctx *c, int *h1, int *l2)
+{
+   LGH_CHECK_ARG(c && h1 && l2);
+   *h1 = c->b_h1_sym;
+   *l2 = c->b_l2_sym;
+   return LGH_OK;
+}
 int lgh_pcg_iterations(lgh_ctx *c, long *iterations)
 {
    LGH_CHECK_ARG(c && iterations);

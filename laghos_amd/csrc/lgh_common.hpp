@@ -136,7 +136,7 @@ struct lgh_ctx
    unsigned vcg_stride;
    int vcg_last;
    int vcg_grid;         // persistent grid size of the K1 kernel (one resident wave)
-   int b_h1_sym;         // the 1-D H1 table is mirror symmetric, B[q,d] = B[Q-1-q, D-1-d] (to 4 ulp): kernels may hold half of it
+   int b_h1_sym, b_l2_sym; // the 1-D H1 / L2 table is mirror symmetric, B[q,d] = B[Q-1-q, D-1-d] (to 1e-14: the round-off of its evaluation): kernels may hold half of it
    int vcg_variant;      // LGH_VCG_VARIANT: which K1 form vcg_solve launches (lgh_vcg.hip)
    void *vcg_aux;        // tables of the node kernel K2 (lgh_vcg.hip VcgAux), allocated on first use
    void *pcg;            // state of the persistent solve kernel (lgh_pcg.hip), allocated on first use
@@ -176,6 +176,14 @@ __device__ __forceinline__ double wave_min(double v, const int lane, const int n
       if (lane + off < nact) { v = fmin(v, o); }
    }
    return v;
+}
+
+// a value that is the same in every lane, moved to scalar registers (an FMA can take it as its SGPR operand)
+__device__ __forceinline__ double uniform_f64(const double v)
+{
+   const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+   const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+   return __hiloint2double(hi, lo);
 }
 
 // Sum over the block; result valid in thread 0.  `red` = LDS scratch of >= 16 doubles.

@@ -340,10 +340,13 @@ mass_apply_l2_plane(const MassArgs a)
    for (int qz = 0; qz < Q; qz++) { dq[qz] = Dp[Q * Q * qz]; }
    __syncthreads();
    const double *sI = sIn + eb * CS;
-   // the 1-D table in registers (every lane holds the same values; the scalar file has no room for them)
-   double Bt[Q * L];
+   // the 1-D table in scalar registers, in half: the Bernstein basis at Gauss-Legendre points is mirror symmetric,
+   // B[q,l] = B[Q-1-q, L-1-l] (checked by lgh_create; the column form runs otherwise)
+   constexpr int QL = Q * L, HB = (QL + 1) / 2;
+   double Bh[HB];
 #pragma unroll
-   for (int i = 0; i < Q * L; i++) { Bt[i] = sB[i]; }
+   for (int i = 0; i < HB; i++) { Bh[i] = uniform_f64(a.B[i]); }
+   auto Bt = [&](const int idx) -> double { return idx < HB ? Bh[idx] : Bh[QL - 1 - idx]; };
    // forward x: t[dy,dz] = sum_dx B[qx,dx] d[dx,dy,dz]   (the HY threads of a plane each form it)
    double t[LL];
    {
@@ -377,9 +380,9 @@ mass_apply_l2_plane(const MassArgs a)
 #pragma unroll
       for (int dy = 0; dy < L; dy++)
       {
-         double v = Bt[r + Q * dy];
+         double v = Bt(r + Q * dy);
 #pragma unroll
-         for (int hh = 1; hh < HY; hh++) { v = (h == hh) ? Bt[hh * QH + r + Q * dy] : v; }
+         for (int hh = 1; hh < HY; hh++) { v = (h == hh) ? Bt(hh * QH + r + Q * dy) : v; }
          by[dy] = v;
       }
       double wr[L];
@@ -397,7 +400,7 @@ mass_apply_l2_plane(const MassArgs a)
       {
          double u = 0.0;
 #pragma unroll
-         for (int dz = 0; dz < L; dz++) { u = fma(Bt[qz + Q * dz], wr[dz], u); }
+         for (int dz = 0; dz < L; dz++) { u = fma(Bt(qz + Q * dz), wr[dz], u); }
          cz[qz] = u * dq[qz];
       }
 #pragma unroll
@@ -405,7 +408,7 @@ mass_apply_l2_plane(const MassArgs a)
       {
          double u = 0.0;
 #pragma unroll
-         for (int qz = 0; qz < Q; qz++) { u = fma(Bt[qz + Q * dz], cz[qz], u); }
+         for (int qz = 0; qz < Q; qz++) { u = fma(Bt(qz + Q * dz), cz[qz], u); }
 #pragma unroll
          for (int dy = 0; dy < L; dy++) { acc[dy + L * dz] = fma(by[dy], u, acc[dy + L * dz]); }
       }
@@ -579,14 +582,15 @@ template <int MODE> static int launch_mass(lgh_ctx *c, int space, const MassArgs
                          dim3(Q_ * Q_ * NEB_), 0, c->stream, a);                              \
    }                                                                                          \
    break
-   if ((MODE == 0 || MODE == 3) && space == LGH_SPACE_L2 && (id == 0x336 || id == 0x348 || id == 0x35A))
+   if ((MODE == 0 || MODE == 3) && space == LGH_SPACE_L2 && c->b_l2_sym && (id == 0x336 || id == 0x348 || id == 0x35A))
    {
       static const char *penv = getenv("LGH_L2_PLANE"); // A/B: 0 = column form
+      constexpr int M = (MODE == 3 ? 3 : 0);
       if (!(penv && penv[0] == '0'))
       {
-         if (id == 0x336) { hipLaunchKernelGGL((mass_apply_l2_plane<3, 6, 1, 42, (MODE == 3 ? 3 : 0)>), dim3(ceil_div(c->NE, 42)), dim3(252), 0, c->stream, a); }
-         else if (id == 0x348) { hipLaunchKernelGGL((mass_apply_l2_plane<4, 8, 1, 32, (MODE == 3 ? 3 : 0)>), dim3(ceil_div(c->NE, 32)), dim3(256), 0, c->stream, a); }
-         else { hipLaunchKernelGGL((mass_apply_l2_plane<5, 10, 2, 12, (MODE == 3 ? 3 : 0)>), dim3(ceil_div(c->NE, 12)), dim3(240), 0, c->stream, a); }
+         if (id == 0x336) { hipLaunchKernelGGL((mass_apply_l2_plane<3, 6, 1, 42, M>), dim3(ceil_div(c->NE, 42)), dim3(252), 0, c->stream, a); }
+         else if (id == 0x348) { hipLaunchKernelGGL((mass_apply_l2_plane<4, 8, 1, 32, M>), dim3(ceil_div(c->NE, 32)), dim3(256), 0, c->stream, a); }
+         else { hipLaunchKernelGGL((mass_apply_l2_plane<5, 10, 2, 12, M>), dim3(ceil_div(c->NE, 12)), dim3(240), 0, c->stream, a); }
          LGH_HIP_CHECK(hipGetLastError());
          return LGH_OK;
       }

@@ -173,6 +173,7 @@ qpoint_kernel(const QArgs a)
    constexpr int NQ = (DIM == 3) ? Q * Q * Q : Q * Q;
    constexpr int NL = (DIM == 3) ? L * L * L : L * L;
    constexpr int NTE = NQ; // threads per element
+   constexpr bool HOIST = (NQ * NEB <= 256); // per-thread-constant table rows kept in registers (below)
    constexpr bool NEED_X = (MODE == QMODE_UPDATE || MODE == QMODE_SETUP);
    constexpr bool NEED_V = (MODE == QMODE_UPDATE || MODE == QMODE_KE);
    constexpr bool NEED_E = (MODE != QMODE_KE);
@@ -269,19 +270,23 @@ qpoint_kernel(const QArgs a)
          {
             // qx = i % Q is the same for every item of a thread (the stride Q^3 is a multiple of Q): its table rows
             // are read once, not per item - LDS issue, shared by the four SIMDs, is scarcer than FMA issue
-            double bxr[D], gxr[D];
+            // (only where registers are to spare: the 512- and 1000-thread workgroups of Q4Q3 / Q5Q4 are capped)
+            double bxr[HOIST ? D : 1], gxr[HOIST ? D : 1];
+            if constexpr (HOIST)
+            {
 #pragma unroll
-            for (int dx = 0; dx < D; dx++) { bxr[dx] = sB[tx + Q * dx]; gxr[dx] = sG[tx + Q * dx]; }
+               for (int dx = 0; dx < D; dx++) { bxr[dx] = sB[tx + Q * dx]; gxr[dx] = sG[tx + Q * dx]; }
+            }
             for (int i = lt; i < NF * D * D * Q; i += NTE)
             {
-               const int dy = (i / Q) % D, dz = (i / (Q * D)) % D, fl = i / (Q * D * D);
+               const int qx = i % Q, dy = (i / Q) % D, dz = (i / (Q * D)) % D, fl = i / (Q * D * D);
                double u = 0.0, w = 0.0;
 #pragma unroll
                for (int dx = 0; dx < D; dx++)
                {
                   const double s = sU[dx + D * (dy + D * dz) + ND * fl];
-                  u += bxr[dx] * s;
-                  w += gxr[dx] * s;
+                  u += (HOIST ? bxr[HOIST ? dx : 0] : sB[qx + Q * dx]) * s;
+                  w += (HOIST ? gxr[HOIST ? dx : 0] : sG[qx + Q * dx]) * s;
                }
                sX[i] = u;
                sX[i + NF * D * D * Q] = w;
@@ -302,21 +307,25 @@ qpoint_kernel(const QArgs a)
          // y stage: BB, GB, BG [k][fl][dz][qy][qx]
          if (NFIELD > 0)
          {
-            double byr[D], gyr[D]; // (qx, qy) = (tx, ty) for every item of a thread: the stride is a multiple of Q^2
+            double byr[HOIST ? D : 1], gyr[HOIST ? D : 1]; // (qx, qy) = (tx, ty) for every item of a thread: the stride is a multiple of Q^2
+            if constexpr (HOIST)
+            {
 #pragma unroll
-            for (int dy = 0; dy < D; dy++) { byr[dy] = sB[ty + Q * dy]; gyr[dy] = sG[ty + Q * dy]; }
+               for (int dy = 0; dy < D; dy++) { byr[dy] = sB[ty + Q * dy]; gyr[dy] = sG[ty + Q * dy]; }
+            }
             for (int i = lt; i < NF * D * Q * Q; i += NTE)
             {
-               const int dz = (i / (Q * Q)) % D, fl = i / (Q * Q * D);
+               const int qx = i % Q, qy = (i / Q) % Q, dz = (i / (Q * Q)) % D, fl = i / (Q * Q * D);
                double bb = 0.0, gb = 0.0, bg = 0.0;
 #pragma unroll
                for (int dy = 0; dy < D; dy++)
                {
-                  const int j = tx + Q * (dy + D * (dz + D * fl));
+                  const int j = qx + Q * (dy + D * (dz + D * fl));
                   const double vb = sX[j], vg = sX[j + NF * D * D * Q];
-                  bb += byr[dy] * vb;
-                  gb += byr[dy] * vg;
-                  bg += gyr[dy] * vb;
+                  const double tb = HOIST ? byr[HOIST ? dy : 0] : sB[qy + Q * dy], tg = HOIST ? gyr[HOIST ? dy : 0] : sG[qy + Q * dy];
+                  bb += tb * vb;
+                  gb += tb * vg;
+                  bg += tg * vb;
                }
                sY[i] = bb;
                sY[i + NF * D * Q * Q] = gb;
@@ -515,7 +524,7 @@ qpoint_kernel(const QArgs a)
                if (do_f)
                {
                   // (dy is the same for every item of a thread where the stride is a multiple of Q*D: table columns in registers)
-                  constexpr bool YINV = (NTE % (Q * D) == 0);
+                  constexpr bool YINV = HOIST && (NTE % (Q * D) == 0);
                   double byf[YINV ? Q : 1], gyf[YINV ? Q : 1];
                   if constexpr (YINV)
                   {
@@ -561,7 +570,7 @@ qpoint_kernel(const QArgs a)
                // ---- x
                if (do_f)
                {
-                  constexpr bool XINV = (NTE % D == 0); // dx = i % D is then the same for every item of a thread
+                  constexpr bool XINV = HOIST && (NTE % D == 0); // dx = i % D is then the same for every item of a thread
                   double bxf[XINV ? Q : 1], gxf[XINV ? Q : 1];
                   if constexpr (XINV)
                   {

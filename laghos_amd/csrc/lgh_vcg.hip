@@ -490,12 +490,6 @@ vcg_apply_3d(const VcgArgs a, const int nbatch)
 // enough for two workgroups per CU.
 // Software pipeline: the element->node map runs two batches ahead, the gathers and
 // the quadrature data one batch ahead.
-__device__ __forceinline__ double uniform_f64(const double v)
-{
-   const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
-   const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
-   return __hiloint2double(hi, lo);
-}
 
 template <int D, int Q, int NEB, bool SYM>
 __global__ void __launch_bounds__(kVC *Q *NEB, 2)

@@ -39,6 +39,14 @@ def pair(request):
     o.close()
 
 
+def test_tables_are_found_symmetric(pair):
+    """The plane-form mass kernels (lockstep K1, L2 mass at Q3Q2 and above) hold half of the 1-D table and are only
+    dispatched when lgh_create finds it mirror symmetric to round-off - which every order in use must be, or the
+    solves silently run the slower column forms."""
+    prob, g, o = pair
+    assert g.ctx.table_symmetry() == (1, 1)
+
+
 def test_setup_data(pair):
     """Rho0DetJ0Vol + mass PA data + Jacobi diagonal (laghos_solver.cpp:1170-1261)"""
     prob, g, o = pair

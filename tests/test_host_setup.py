@@ -27,6 +27,16 @@ CASES = [("cube01_hex", 1, 2, 1, 1), ("cube01_hex", 1, 3, 2, 0), ("square01_quad
          ("square01_quad", 2, 2, 1, 5), ("cube01_hex", 1, 2, 1, 6), ("cube01_hex", 1, 2, 1, 7)]
 
 
+def test_tables_mirror_symmetry_within_the_library_threshold():
+    """B[q,d] = B[Q-1-q, D-1-d] for the H1 (Gauss-Lobatto) and L2 (Bernstein) tables at Gauss-Legendre points, to the
+    1e-14 lgh_create accepts (measured: 1e-15 at order 5); the gradient table is antisymmetric."""
+    for ok, ot in ((1, 0), (2, 1), (3, 2), (4, 3), (5, 4)):
+        t = host_lib.host_tables(ok, ot)
+        assert np.max(np.abs(t["B"] - t["B"][::-1, ::-1])) < 4e-15
+        assert np.max(np.abs(t["Bl"] - t["Bl"][::-1, ::-1])) < 4e-15
+        assert np.max(np.abs(t["G"] + t["G"][::-1, ::-1])) < 1e-13
+
+
 @pytest.mark.parametrize("mesh,rs,ok,ot,prob", CASES)
 def test_discretization_single_rank(mesh, rs, ok, ot, prob):
     d = host_lib.host_disc(mesh, rs, ok, ot, prob, blast_energy=2.0)
