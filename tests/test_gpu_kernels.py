@@ -391,3 +391,38 @@ def test_lockstep_k1_forms_agree_at_high_order(order, monkeypatch):
         finally:
             g.close()
         assert rel_err(dS[H1V:2 * H1V], dS_o[H1V:2 * H1V]) < 1e-10, variant
+
+
+@pytest.mark.parametrize("order", [(3, 2), (4, 3)], ids=["Q3Q2", "Q4Q3"])
+def test_mass_kernels_without_table_symmetry(order, monkeypatch):
+    """LGH_B_SYM=0: lgh_create treats the 1-D tables as not mirror symmetric, as it would for a basis on asymmetric
+    points - the lockstep K1 then keeps the whole table in scalar registers (Q3Q2) or runs in column form (Q4Q3) and
+    the L2 mass apply runs in column form.  One RHS evaluation on a distorted state (both CGs to 1e-14) against the
+    oracle, as for the default dispatch."""
+    from oracle.fem import Problem
+    prob = Problem(mesh="box01_hex", rs=0, order_v=order[0], order_e=order[1], problem=1)
+    S = deformed_state(prob, seed=35)
+    o = make_oracle(prob)
+    try:
+        o.cg_tol = 1e-14
+        dS_o = np.empty_like(S)
+        o.qdata_is_current = False
+        o.mult(S, dS_o)
+    finally:
+        o.close()
+    monkeypatch.setenv("LGH_B_SYM", "0")
+    g = make_gpu(prob)
+    try:
+        assert g.ctx.table_symmetry() == (0, 0)
+        g.cg_tol = 1e-14
+        Sd = g.ctx.to_dev(S)
+        dS = g.ctx.zeros(S.size)
+        g.reset_quadrature_data()
+        g.mult(Sd, dS)
+        g.ctx.sync()
+        dS = dS.cpu().numpy()
+    finally:
+        g.close()
+    H1V = prob.H1V
+    assert rel_err(dS[H1V:2 * H1V], dS_o[H1V:2 * H1V]) < 1e-10
+    assert rel_err(dS[2 * H1V:], dS_o[2 * H1V:]) < 1e-10
