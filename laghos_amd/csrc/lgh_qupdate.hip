@@ -734,8 +734,12 @@ template <int MODE> static int launch_q(lgh_ctx *c, const QArgs &a)
       case 0x322: LGH_Q3(2, 2, 1, 6);
       case 0x334: LGH_Q3(3, 4, 2, 6);
       case 0x346: LGH_Q3(4, 6, 3, 6);
-      case 0x358: LGH_Q3(5, 8, 4, 3);
-      case 0x36A: LGH_Q3(6, 10, 5, 1); // extension: not in the reference table
+      // all six H1 fields in one LDS pass at every order: only one workgroup of 512 / 1000 threads fits a CU at Q4Q3 /
+      // Q5Q4 anyway, so its 76 / 140 KB of LDS cost nothing, and one pass needs fewer registers than several (the
+      // gradients do not have to survive across passes): 234 -> 158 VGPRs at Q4Q3, 70 -> 41 spilled registers under
+      // the 128-register cap of the 1000-thread workgroup at Q5Q4, where the update takes 10.4 instead of 17 ms
+      case 0x358: LGH_Q3(5, 8, 4, 6);
+      case 0x36A: LGH_Q3(6, 10, 5, 6); // extension: not in the reference table
       default: return unknown_kernel(c->kid);
    }
 #undef LGH_Q3
