@@ -133,6 +133,9 @@ int lgh_qupdate_set_tiny_grad(lgh_ctx *ctx, double tiny_grad);
  * lgh_solve_energy with that velocity; `one_l2` is checked to be all ones).  on = 0 switches that off: the
  * force products then always come from the ForcePAOperator kernels (per-kernel timing, A/B).  Default on. */
 int lgh_set_fused_forces(lgh_ctx *ctx, int on);
+/* *f1 / *ftv = 1 when lgh_qupdate forms F.1 / F^T v (what the region timers then see: the "Forces" region of
+ * lgh_get_timers only holds the E->L sum and right-hand-side set-up, the products are inside "UpdateQuadData") */
+int lgh_get_fused_forces(lgh_ctx *ctx, int *f1, int *ftv);
 
 /* ---- LagrangianHydroOperator pieces kept together for launch efficiency
  * (laghos_solver.cpp:329-399, :442-490).  dS_dt = [dx|dv|de]; one_l2 is the

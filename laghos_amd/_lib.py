@@ -88,6 +88,7 @@ SYMBOLS = {
     "lgh_table_symmetry": (_I, [_P, c_int_p, c_int_p]),
     "lgh_qupdate_set_tiny_grad": (_I, [_P, _D]),
     "lgh_set_fused_forces": (_I, [_P, _I]),
+    "lgh_get_fused_forces": (_I, [_P, c_int_p, c_int_p]),
     "lgh_comm_unique_id": (_I, [ctypes.c_char_p]),
     "lgh_comm_init": (_I, [_P, _I, _I, ctypes.c_char_p]),
     "lgh_comm_set_neighbors": (_I, [_P, _I, c_int_p, c_int_p, ctypes.POINTER(c_int_p)]),

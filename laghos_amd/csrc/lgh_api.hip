@@ -833,6 +833,14 @@ int lgh_set_fused_forces(lgh_ctx *c, int on)
    return LGH_OK;
 }
 
+int lgh_get_fused_forces(lgh_ctx *c, int *f1, int *ftv)
+{
+   LGH_CHECK_ARG(c && f1 && ftv);
+   *f1 = (c->force_e_q && !c->fused_forces_off) ? 1 : 0;
+   *ftv = (c->erhs_q && !c->fused_forces_off) ? 1 : 0;
+   return LGH_OK;
+}
+
 int lgh_qupdate_set_tiny_grad(lgh_ctx *c, double tiny_grad)
 {
    LGH_CHECK_ARG(c);

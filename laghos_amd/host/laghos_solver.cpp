@@ -289,6 +289,14 @@ void LagrangianHydroOperator::PrintTimingData(bool IamRoot, int steps, bool fom)
    cout << endl;
    cout << "Forces total time: " << T[2] << endl;
    cout << "Forces rate (megadofs x timesteps / second): " << FOM2 << endl;
+   {
+      int f1 = 0, ftv = 0;
+      if (lgh_get_fused_forces(ctx, &f1, &ftv) == LGH_OK && (f1 || ftv))
+      {
+         cout << "(the force products" << (f1 && ftv ? "" : (f1 ? " F.1" : " F^T v"))
+              << " are formed inside UpdateQuadData: this region holds their E->L sum / right-hand-side set-up only)" << endl;
+      }
+   }
    cout << endl;
    cout << "UpdateQuadData total time: " << T[3] << endl;
    cout << "UpdateQuadData rate (megaquads x timesteps / second): " << FOM3 << endl;
