@@ -285,6 +285,8 @@ int lgh_test_halo_combine(lgh_ctx *ctx, const double *recvbuf_in, double *v_h1, 
 int lgh_test_rccl_self_sendrecv(lgh_ctx *ctx, int n, double *max_abs_diff);
 /* device small-matrix probes: n matrices (column-major, 9 or 4 doubles each) */
 int lgh_test_eig(lgh_ctx *ctx, int dim, int n, const double *A, double *lambda, double *vec);
+/* y[i] = the device square root the small-matrix routines use (rsq + Goldschmidt step + correction), n device doubles */
+int lgh_test_sqrt(lgh_ctx *ctx, int n, const double *x, double *y);
 int lgh_test_singular(lgh_ctx *ctx, int dim, int n, const double *A, double *sv_min);
 
 #ifdef __cplusplus

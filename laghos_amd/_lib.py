@@ -105,6 +105,7 @@ SYMBOLS = {
     "lgh_test_rccl_self_sendrecv": (_I, [_P, _I, c_dbl_p]),
     "lgh_test_eig": (_I, [_P, _I, _I, _P, _P, _P]),
     "lgh_test_singular": (_I, [_P, _I, _I, _P, _P]),
+    "lgh_test_sqrt": (_I, [_P, _I, _P, _P]),
 }
 
 _lib = None

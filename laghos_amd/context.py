@@ -329,6 +329,9 @@ class Context:
     def test_singular(self, dim, A, sv):
         check(self.lib.lgh_test_singular(self.h, dim, sv.numel(), _ptr(A), _ptr(sv)))
 
+    def test_sqrt(self, x, y):
+        check(self.lib.lgh_test_sqrt(self.h, y.numel(), _ptr(x), _ptr(y)))
+
     # multi-GPU
     def comm_init(self, nranks, rank, unique_id):
         check(self.lib.lgh_comm_init(self.h, nranks, rank, unique_id))

@@ -883,6 +883,11 @@ int lgh_test_eig(lgh_ctx *c, int dim, int n, const double *A, double *lambda, do
    LGH_CHECK_ARG(c && A && lambda && vec && (dim == 2 || dim == 3));
    return test_eig(c, dim, n, A, lambda, vec);
 }
+int lgh_test_sqrt(lgh_ctx *c, int n, const double *x, double *y)
+{
+   LGH_CHECK_ARG(c && x && y && n >= 0);
+   return test_sqrt(c, n, x, y);
+}
 int lgh_test_singular(lgh_ctx *c, int dim, int n, const double *A, double *sv)
 {
    LGH_CHECK_ARG(c && A && sv && (dim == 2 || dim == 3));

@@ -381,6 +381,7 @@ int interp_energy(lgh_ctx *c, int which, const double *vec, double *result);
 int tg_source_2d(lgh_ctx *c, const double *S, double *out);
 int test_eig(lgh_ctx *c, int dim, int n, const double *A, double *lambda, double *vec);
 int test_singular(lgh_ctx *c, int dim, int n, const double *A, double *sv);
+int test_sqrt(lgh_ctx *c, int n, const double *x, double *y);
 int vec_set(lgh_ctx *c, double *y, double a, long n);
 int vec_axpby(lgh_ctx *c, double *z, double a, const double *x, double b, const double *y, long n);
 int vec_neg_inplace(lgh_ctx *c, double *y, long n);

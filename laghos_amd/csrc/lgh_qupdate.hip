@@ -74,7 +74,7 @@ __device__ __forceinline__ double qpoint_body(const QArgs &a, const int e, const
    const double R = inv_weight * rho0DetJ0w / detJ;
    const double E = fmax(0.0, e_val);
    const double P = (gamma - 1.0) * R * E;
-   const double S = sqrt(gamma * (gamma - 1.0) * E);
+   const double S = sm::fsqrt(gamma * (gamma - 1.0) * E);
 #pragma unroll
    for (int k = 0; k < DIM2; k++) { stress[k] = 0.0; }
 #pragma unroll
@@ -922,6 +922,17 @@ __global__ void test_sv_k(int n, const double *A, double *sv)
    double a[DIM * DIM];
    for (int k = 0; k < DIM * DIM; k++) { a[k] = A[(size_t)i * DIM * DIM + k]; }
    sv[i] = sm::min_singular<DIM>(a);
+}
+__global__ void test_sqrt_k(int n, const double *x, double *y)
+{
+   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+   if (i < n) { y[i] = sm::fsqrt(x[i]); }
+}
+int test_sqrt(lgh_ctx *c, int n, const double *x, double *y)
+{
+   hipLaunchKernelGGL(test_sqrt_k, dim3(ceil_div(n, 256)), dim3(256), 0, c->stream, n, x, y);
+   LGH_HIP_CHECK(hipGetLastError());
+   return LGH_OK;
 }
 int test_eig(lgh_ctx *c, int dim, int n, const double *A, double *lambda, double *vec)
 {
