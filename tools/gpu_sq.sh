@@ -1,7 +1,7 @@
 cd /root/repo
 export TMPDIR=/tmp
 O=gpurun_out/sq; mkdir -p $O
-timeout 1500 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_pipeline.py -m gpu -q -x > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -4 $O/pytest.log
+timeout 1500 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_pipeline.py -m gpu -q -x -k "not readme_run9" > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -4 $O/pytest.log
 APP="./laghos_amd/laghos -p 3 -m data/box01_hex.mesh -rs 4 -ok 5 -ot 4 -ms 2 -pa -f"
 timeout 600 $APP > $O/c5.log 2>&1; echo "c5 rc=$?"
 grep -i "UpdateQuadData total" $O/c5.log
