@@ -277,9 +277,7 @@ qpoint_kernel(const QArgs a)
 #pragma unroll
                for (int dx = 0; dx < D; dx++) { bxr[dx] = sB[tx + Q * dx]; gxr[dx] = sG[tx + Q * dx]; }
             }
-            for (int i = lt; i < NF * D * D * Q; i += NTE)
-            {
-               const int qx = i % Q, dy = (i / Q) % D, dz = (i / (Q * D)) % D, fl = i / (Q * D * D);
+            auto xitem = [&](const int i, const int qx, const int dy, const int dz, const int fl) {
                double u = 0.0, w = 0.0;
 #pragma unroll
                for (int dx = 0; dx < D; dx++)
@@ -290,6 +288,15 @@ qpoint_kernel(const QArgs a)
                }
                sX[i] = u;
                sX[i + NF * D * D * Q] = w;
+            };
+            if constexpr (HOIST)
+            {
+               // the items of a thread are i = tx + Q * r, r = ty + Q * tz + k * Q^2: no division by Q per item
+               for (int r = ty + Q * tz; r < NF * D * D; r += Q * Q) { xitem(tx + Q * r, tx, r % D, (r / D) % D, r / (D * D)); }
+            }
+            else
+            {
+               for (int i = lt; i < NF * D * D * Q; i += NTE) { xitem(i, i % Q, (i / Q) % D, (i / (Q * D)) % D, i / (Q * D * D)); }
             }
          }
          if (NEED_E && first_pass)
@@ -313,9 +320,7 @@ qpoint_kernel(const QArgs a)
 #pragma unroll
                for (int dy = 0; dy < D; dy++) { byr[dy] = sB[ty + Q * dy]; gyr[dy] = sG[ty + Q * dy]; }
             }
-            for (int i = lt; i < NF * D * Q * Q; i += NTE)
-            {
-               const int qx = i % Q, qy = (i / Q) % Q, dz = (i / (Q * Q)) % D, fl = i / (Q * Q * D);
+            auto yitem = [&](const int i, const int qx, const int qy, const int dz, const int fl) {
                double bb = 0.0, gb = 0.0, bg = 0.0;
 #pragma unroll
                for (int dy = 0; dy < D; dy++)
@@ -330,6 +335,15 @@ qpoint_kernel(const QArgs a)
                sY[i] = bb;
                sY[i + NF * D * Q * Q] = gb;
                sY[i + 2 * NF * D * Q * Q] = bg;
+            };
+            if constexpr (HOIST)
+            {
+               // i = tx + Q * ty + Q^2 * m, m = dz + D * fl = tz + k * Q
+               for (int m = tz; m < NF * D; m += Q) { yitem(tx + Q * (ty + Q * m), tx, ty, m % D, m / D); }
+            }
+            else
+            {
+               for (int i = lt; i < NF * D * Q * Q; i += NTE) { yitem(i, i % Q, (i / Q) % Q, (i / (Q * Q)) % D, i / (Q * Q * D)); }
             }
          }
          if (NEED_E && first_pass)
@@ -498,14 +512,20 @@ qpoint_kernel(const QArgs a)
                // ---- z
                if (do_f)
                {
-                  for (int i = lt; i < CP * 3 * D * Q * Q; i += NTE)
-                  {
-                     const int qx = i % Q, qy = (i / Q) % Q, dz = (i / (Q * Q)) % D, k = i / (Q * Q * D); // k = gd + 3 cc
+                  auto fzitem = [&](const int i, const int qx, const int qy, const int dz, const int k) { // k = gd + 3 cc
                      const double *tab = ((k % 3) == 2) ? sG : sB;
                      double u = 0.0;
 #pragma unroll
                      for (int qz = 0; qz < Q; qz++) { u += tab[qz + Q * dz] * sF[qx + Q * (qy + Q * qz) + NQ * k]; }
                      sA[i] = u;
+                  };
+                  if constexpr (HOIST)
+                  {
+                     for (int m = tz; m < CP * 3 * D; m += Q) { fzitem(tx + Q * (ty + Q * m), tx, ty, m % D, m / D); } // as the y stage above
+                  }
+                  else
+                  {
+                     for (int i = lt; i < CP * 3 * D * Q * Q; i += NTE) { fzitem(i, i % Q, (i / Q) % Q, (i / (Q * Q)) % D, i / (Q * Q * D)); }
                   }
                }
                if (t_now)
@@ -532,9 +552,7 @@ qpoint_kernel(const QArgs a)
 #pragma unroll
                      for (int qy = 0; qy < Q; qy++) { byf[qy] = sB[qy + Q * dy0]; gyf[qy] = sG[qy + Q * dy0]; }
                   }
-                  for (int i = lt; i < CP * 2 * D * D * Q; i += NTE)
-                  {
-                     const int qx = i % Q, dy = (i / Q) % D, dz = (i / (Q * D)) % D, wh = (i / (Q * D * D)) % 2, cc = i / (Q * D * D * 2);
+                  auto fyitem = [&](const int i, const int qx, const int dy, const int dz, const int wh, const int cc) {
                      const double *a0 = sA + D * Q * Q * (0 + 3 * cc) + Q * Q * dz + qx;
                      const double *a1 = sA + D * Q * Q * (1 + 3 * cc) + Q * Q * dz + qx;
                      const double *a2 = sA + D * Q * Q * (2 + 3 * cc) + Q * Q * dz + qx;
@@ -553,6 +571,20 @@ qpoint_kernel(const QArgs a)
                         }
                      }
                      sW[i] = u;
+                  };
+                  if constexpr (HOIST)
+                  {
+                     for (int r = ty + Q * tz; r < CP * 2 * D * D; r += Q * Q) // as the x stage above
+                     {
+                        fyitem(tx + Q * r, tx, r % D, (r / D) % D, (r / (D * D)) % 2, r / (D * D * 2));
+                     }
+                  }
+                  else
+                  {
+                     for (int i = lt; i < CP * 2 * D * D * Q; i += NTE)
+                     {
+                        fyitem(i, i % Q, (i / Q) % D, (i / (Q * D)) % D, (i / (Q * D * D)) % 2, i / (Q * D * D * 2));
+                     }
                   }
                }
                if (t_now)
