@@ -860,11 +860,15 @@ struct PcgHost
 };
 
 __global__ void __launch_bounds__(256)
-pcg_essbits_k(const uint8_t *e0, const uint8_t *e1, const uint8_t *e2, uint8_t *bits, const int N)
+pcg_essbits_k(const uint8_t *e0, const uint8_t *e1, const uint8_t *e2, const uint8_t *hmask, const double *owner, uint8_t *bits,
+              const int N)
 {
    const int n = blockIdx.x * blockDim.x + threadIdx.x;
    if (n >= N) { return; }
-   bits[n] = (uint8_t)(((e0 && e0[n]) ? 1 : 0) | ((e1 && e1[n]) ? 2 : 0) | ((e2 && e2[n]) ? 4 : 0));
+   // bits 0-2: essential for component k; several ranks: bit 3 = shared with another rank (its A d comes halo-summed
+   // from the L-vector), bit 4 = owned by another rank (weight 0 in the dot products)
+   bits[n] = (uint8_t)(((e0 && e0[n]) ? 1 : 0) | ((e1 && e1[n]) ? 2 : 0) | ((e2 && e2[n]) ? 4 : 0) | ((hmask && hmask[n]) ? 8 : 0) |
+                       ((owner && owner[n] == 0.0) ? 16 : 0));
 }
 __global__ void __launch_bounds__(256)
 pcg_ellz_k(const int *__restrict__ ell, unsigned *__restrict__ ellz, const size_t n_have, const size_t n_all, const int zslot)
@@ -944,8 +948,12 @@ int make_ellz(lgh_ctx *c, unsigned **out)
 int make_essbits(lgh_ctx *c, uint8_t **out)
 {
    LGH_HIP_CHECK(hipMalloc((void **)out, (size_t)c->N));
+   const uint8_t *hmask = nullptr;
+   const int *sh_node = nullptr;
+   int n_shared = 0;
+   if (c->multi) { comm_shared_nodes(c, &hmask, &sh_node, &n_shared); }
    hipLaunchKernelGGL(pcg_essbits_k, dim3((unsigned)((c->N + 255) / 256)), dim3(256), 0, nullptr, c->essmask[0], c->essmask[1],
-                      c->essmask[2], *out, c->N);
+                      c->essmask[2], hmask, c->multi ? c->owner : nullptr, *out, c->N);
    LGH_HIP_CHECK(hipGetLastError());
    return LGH_OK;
 }

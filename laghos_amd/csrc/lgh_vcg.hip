@@ -1359,6 +1359,8 @@ vcg_update_p_k(const VcgArgs a)
    for (int k = 0; k < kVC; k++)
    {
       todo[k] = a.s->done[k] == 0;
+      // (several ranks: breakdown is looked at here, after the sum of (d, A d) over the ranks - vcg_pending_den)
+      if (a.multi && todo[k] && vcg_pending_den(a.s, k, blockIdx.x == 0 && tid == 0)) { todo[k] = false; }
       alpha[k] = todo[k] ? a.s->rz[k] / a.s->den[k] : 0.0;
       alpha_prev[k] = todo[k] ? a.s->alpha_last[k] : 0.0;
       beta[k] = (first || !todo[k]) ? 0.0 : a.s->rz[k] / a.s->rz_prev[k];
@@ -1440,9 +1442,22 @@ vcg_update_p_k(const VcgArgs a)
             }
          }
       }
+      // several ranks: a node shared with another rank takes its A d from the L-vector the halo exchange has summed
+      double ysh[U][kVC];
+      bool anysh = false;
+#pragma unroll
+      for (int u = 0; u < U; u++) { anysh = anysh || ((es[u] >> 3) & 1u); }
+      anysh = a.multi && __any(anysh);
 #pragma unroll
       for (int u = 0; u < U; u++)
       {
+#pragma unroll
+         for (int k = 0; k < kVC; k++) { ysh[u][k] = anysh ? vcg_ld(a.yL, 8u * nn[u] + (unsigned)k * compb) : 0.0; }
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++)
+      {
+         const double ow = ((es[u] >> 4) & 1u) ? 0.0 : 1.0; // (1 on one rank)
 #pragma unroll
          for (int k = 0; k < kVC; k++)
          {
@@ -1450,6 +1465,7 @@ vcg_update_p_k(const VcgArgs a)
             double zs = 0.0; // ascending contribution order (absent slots add 0.0 at the end): the sum of vcg_update_k
 #pragma unroll
             for (int j = 0; j < 8; j++) { zs += ye[u][k][j]; }
+            if (anysh && ((es[u] >> 3) & 1u)) { zs = ysh[u][k]; }
             const double z_ = ((es[u] >> k) & 1u) ? 0.0 : zs;
             const double zold = __dmul_rn(ro[u][k], di[u]); // z of the previous iterate, not stored
             const double dnew = first ? zold : fma(beta[k], dol[u][k], zold);
@@ -1463,7 +1479,7 @@ vcg_update_p_k(const VcgArgs a)
                   const double x0 = xload ? xo[u][k] : 0.0;
                   *vcg_ptr(a.x, vb) = fma(alpha[k], dnew, fma(alpha_prev[k], first ? 0.0 : dol[u][k], x0));
                }
-               part[k] += rnew * __dmul_rn(rnew, di[u]);
+               part[k] += (a.multi ? ow : 1.0) * rnew * __dmul_rn(rnew, di[u]);
             }
          }
       }
@@ -1483,18 +1499,21 @@ vcg_update_p_k(const VcgArgs a)
          int all = 1;
          for (int k = 0; k < kVC; k++)
          {
-            if (!s->done[k])
+            if (!s->done[k] && !(a.multi && s->den[k] == 0.0)) // (several ranks: breakdown found by this launch)
             {
                s->alpha_last[k] = s->rz[k] / s->den[k]; // the alpha this launch used
                s->nupd[k] = it;
                s->rz_prev[k] = s->rz[k];
-               s->rz[k] = total[k]; // betanom
-               s->iters[k] = it;
-               if (total[k] < 0.0 || total[k] <= s->r0[k]) { s->done[k] = 1; }
+               s->rz[k] = total[k]; // betanom: on several ranks the local part, summed and looked at by the next K1
+               if (!a.multi)
+               {
+                  s->iters[k] = it;
+                  if (total[k] < 0.0 || total[k] <= s->r0[k]) { s->done[k] = 1; }
+               }
             }
             all = all && s->done[k];
          }
-         s->all_done = all;
+         if (!a.multi) { s->all_done = all; }
       }
    }
 }
@@ -1682,7 +1701,7 @@ int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
       const size_t ye_n = (size_t)kVC * ((size_t)c->NE * c->ND + kYePad);
       LGH_HIP_CHECK(hipMalloc((void **)&x->ye, ye_n * sizeof(double)));
       LGH_HIP_CHECK(hipMemset(x->ye, 0, ye_n * sizeof(double)));
-      if (!multi && c->t_deg <= 8 && (size_t)c->N * 8 * kVC < 0xffffffffull && ((size_t)c->NE * c->ND + kYePad) * 8 < 0xffffffffull)
+      if (c->t_deg <= 8 && (size_t)c->N * 8 * kVC < 0xffffffffull && ((size_t)c->NE * c->ND + kYePad) * 8 < 0xffffffffull)
       {
          int ncu = 256;
          hipDeviceProp_t prop;
@@ -1708,7 +1727,7 @@ int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
    }
    VcgAux *aux = (VcgAux *)c->vcg_aux;
    static const char *k2env = getenv("LGH_K2P"); // A/B: 0 = vcg_update_k (one node per thread, x every iteration)
-   const bool k2p = aux->ellz != nullptr && !multi && !(k2env && k2env[0] == '0');
+   const bool k2p = aux->ellz != nullptr && !(k2env && k2env[0] == '0');
    VcgScalars *ds = (VcgScalars *)c->vcg_s;
    hipLaunchKernelGGL(vcg_set_tol_k, dim3(1), dim3(1), 0, c->stream, ds, rel_tol * rel_tol);
 
@@ -1819,8 +1838,7 @@ int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
          LGH_HIP_CHECK(hipGetLastError());
          a.partials = c->vcg_partials;
          a.ticket = c->vcg_tickets;
-         if (k2p)
-         {
+         auto launch_k2p = [&]() {
             kt_begin(c, LGH_KERNEL_CG_UPDATE_H1);
             static const char *uenv = getenv("LGH_K2_U"); // A/B: nodes per thread and pass (2: 182 VGPRs, one workgroup per CU resident)
             const int u2 = (uenv && uenv[0] == '2') ? 1 : 0;
@@ -1829,7 +1847,8 @@ int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
             else { if (u2) { LGH_K2P_LAUNCH(true, 2); } else { LGH_K2P_LAUNCH(true, 1); } }
 #undef LGH_K2P_LAUNCH
             kt_end(c, LGH_KERNEL_CG_UPDATE_H1);
-         }
+         };
+         if (k2p && !multi) { launch_k2p(); }
          else if (!multi && c->t_deg <= 8)
          {
             kt_begin(c, LGH_KERNEL_CG_UPDATE_H1);
@@ -1840,7 +1859,7 @@ int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
          {
             // A d as L-vectors: only at the nodes shared with other ranks when K2 can
             // gather the rest itself; sum shared nodes across ranks, all-reduce the scalars
-            const bool mixed = multi && c->t_deg <= 8 && a.hmask != nullptr;
+            const bool mixed = multi && c->t_deg <= 8;
             if (mixed)
             {
                if (a.n_shared > 0)
@@ -1867,7 +1886,9 @@ int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
                   if (rc) { return rc; }
                }
             }
-            if (mixed) { hipLaunchKernelGGL((vcg_update_k<true, 8>), dim3(nb), dim3(256), 0, c->stream, a); }
+            // (the bounded-grid K2 knows the shared nodes and the owner weights from its flag bytes)
+            if (mixed && k2p) { launch_k2p(); }
+            else if (mixed) { hipLaunchKernelGGL((vcg_update_k<true, 8>), dim3(nb), dim3(256), 0, c->stream, a); }
             else { hipLaunchKernelGGL((vcg_update_k<false, 0>), dim3(nb), dim3(256), 0, c->stream, a); }
             if (multi)
             {
