@@ -1326,7 +1326,7 @@ vcg_update_k(const VcgArgs a)
 // ---- K2, bounded-grid form (one rank) ---------------------------------------------------------------
 // The same node update as vcg_update_k, organised the way the node phase of the persistent kernel
 // (lgh_pcg.hip) turned out to run fastest - its measurements carry over to a kernel of its own:
-//  * four workgroups of 512 threads per CU, each with a contiguous node range of equal COST (a node costs a
+//  * four workgroups of 512 threads per CU (more on large meshes: ranges of at most ~1000 nodes), each with a contiguous node range of equal COST (a node costs a
 //    fixed part plus a part per element contribution; with equal counts the ranges that cover
 //    element-boundary planes take 40 % longer), all ~35 loads of a node issued before the first use,
 //    straight-line code.  One node per thread and pass (U = 1: 106 VGPRs, two workgroups resident per CU)
@@ -1706,8 +1706,12 @@ int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
          int ncu = 256;
          hipDeviceProp_t prop;
          if (hipGetDeviceProperties(&prop, c->device) == hipSuccess) { ncu = prop.multiProcessorCount; }
-         static const char *genv = getenv("LGH_K2_GRID"); // A/B: workgroups (= node ranges) per CU
-         x->grid2 = ((genv && atoi(genv) > 0) ? atoi(genv) : 4) * ncu;
+         // node ranges (= workgroups) of vcg_update_p_k: four per CU, and not more than ~1000 nodes (two passes) each -
+         // on large meshes long static ranges lose to the hardware's dynamic distribution of many short ones
+         // (64^3 zones: 367 vs 424 us; 128^3: H1 CG 2.72 vs 3.04 s).  LGH_K2_GRID=<ranges per CU> for A/B.
+         static const char *genv = getenv("LGH_K2_GRID");
+         if (genv && atoi(genv) > 0) { x->grid2 = atoi(genv) * ncu; }
+         else { x->grid2 = (int)std::max<long>(4L * ncu, (((long)c->N + 1023) / 1024 + 7) & ~7L); }
          rc = make_ellz(c, &x->ellz);
          if (rc) { return rc; }
          rc = make_essbits(c, &x->essbits);
