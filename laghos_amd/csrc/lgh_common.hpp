@@ -153,29 +153,48 @@ struct lgh_ctx
 namespace lgh
 {
 
-// ---- wave / block reductions (wave64 shuffles) ------------------------------
-// Workgroups here are Q*Q*NEB threads, not always a multiple of 64, so the last
-// wave may be partial: a shuffle from a lane beyond `nact` (the number of live
-// lanes of this wave) returns garbage and must not be folded in.
+// ---- wave / block reductions (wave64, DPP) ----------------------------------
+// Workgroups here are Q*Q*NEB threads, not always a multiple of 64, so the last wave may be partial (`nact` live
+// lanes, wave-uniform).  The reduction runs on the DPP data path: row_shr 1, 2, 4, 8 inside the rows of 16 lanes,
+// then row_bcast 15 / 31 across them - 3 instructions per step instead of the ~13 of a ds_bpermute shuffle with
+// its lane guard (these trees are ~80 of the QUpdate's ~2100 vector instructions per wave, and the tail of every
+// CG kernel).  A lane whose source lies outside its row, in a masked row or in the dead part of a partial wave takes
+// the neutral `old` operand instead, so no guard is needed; the total forms in the last live lane and is read
+// from there into every lane.  Fixed order: bit-reproducible.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(const double old, const double src)
+{
+   const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(src), CTRL, ROW_MASK, 0xF, false);
+   const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(src), CTRL, ROW_MASK, 0xF, false);
+   return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_bcast_f64(const double v, const int src_lane /* uniform */)
+{
+   const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+   return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_sum(double v, const int lane, const int nact)
 {
-#pragma unroll
-   for (int off = 32; off > 0; off >>= 1)
-   {
-      const double o = __shfl_down(v, off, 64);
-      if (lane + off < nact) { v += o; }
-   }
-   return v;
+   (void)lane;
+   v += dpp_f64<0x111, 0xF>(0.0, v); // row_shr:1
+   v += dpp_f64<0x112, 0xF>(0.0, v); // row_shr:2
+   v += dpp_f64<0x114, 0xF>(0.0, v); // row_shr:4
+   v += dpp_f64<0x118, 0xF>(0.0, v); // row_shr:8
+   v += dpp_f64<0x142, 0xA>(0.0, v); // row_bcast:15 into rows 1 and 3
+   v += dpp_f64<0x143, 0xC>(0.0, v); // row_bcast:31 into rows 2 and 3
+   return wave_bcast_f64(v, nact - 1);
 }
 __device__ __forceinline__ double wave_min(double v, const int lane, const int nact)
 {
-#pragma unroll
-   for (int off = 32; off > 0; off >>= 1)
-   {
-      const double o = __shfl_down(v, off, 64);
-      if (lane + off < nact) { v = fmin(v, o); }
-   }
-   return v;
+   (void)lane;
+   v = fmin(v, dpp_f64<0x111, 0xF>(v, v));
+   v = fmin(v, dpp_f64<0x112, 0xF>(v, v));
+   v = fmin(v, dpp_f64<0x114, 0xF>(v, v));
+   v = fmin(v, dpp_f64<0x118, 0xF>(v, v));
+   v = fmin(v, dpp_f64<0x142, 0xA>(v, v));
+   v = fmin(v, dpp_f64<0x143, 0xC>(v, v));
+   return wave_bcast_f64(v, nact - 1);
 }
 
 // a value that is the same in every lane, moved to scalar registers (an FMA can take it as its SGPR operand)
