@@ -223,6 +223,36 @@ __device__ __forceinline__ double block_sum(double v, double *red)
    }
    return s;
 }
+// Three sums at once (the three velocity components of the lockstep CG): one pair of barriers instead of three
+// pairs plus separators; the same wave sums added in the same order as three block_sum calls - the same bits.
+// `red` = LDS scratch of >= 48 doubles; results valid in thread 0.
+__device__ __forceinline__ void block_sum3(const double v0, const double v1, const double v2, double *red, double out[3])
+{
+   const int tid = threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z);
+   const int nthr = blockDim.x * blockDim.y * blockDim.z;
+   const int lane = tid & 63, wid = tid >> 6, nw = (nthr + 63) >> 6;
+   const int nact = min(64, nthr - (wid << 6));
+   const double a0 = wave_sum(v0, lane, nact), a1 = wave_sum(v1, lane, nact), a2 = wave_sum(v2, lane, nact);
+   __syncthreads();
+   if (lane == 0)
+   {
+      red[3 * wid + 0] = a0;
+      red[3 * wid + 1] = a1;
+      red[3 * wid + 2] = a2;
+   }
+   __syncthreads();
+   out[0] = out[1] = out[2] = 0.0;
+   if (tid == 0)
+   {
+      for (int w = 0; w < nw; w++)
+      {
+         out[0] += red[3 * w + 0];
+         out[1] += red[3 * w + 1];
+         out[2] += red[3 * w + 2];
+      }
+   }
+   __syncthreads(); // red is free again (the grid reductions that follow reuse it)
+}
 __device__ __forceinline__ double block_min(double v, double *red)
 {
    const int tid = threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z);

@@ -244,7 +244,7 @@ vcg_apply_3d(const VcgArgs a, const int nbatch)
    constexpr int NT = Q * Q * NEB;
    constexpr int GPT = (NEB * ND + NT - 1) / NT; // gather items per thread
    __shared__ double smem[NEB * PER];
-   __shared__ double red[16];
+   __shared__ double red[48];
 
    if (a.s->all_done) { return; }
    const int tid = threadIdx.x;
@@ -453,12 +453,7 @@ vcg_apply_3d(const VcgArgs a, const int nbatch)
       }
    }
    double bp[kVC];
-#pragma unroll
-   for (int c = 0; c < kVC; c++)
-   {
-      bp[c] = block_sum(dots[c], red);
-      __syncthreads();
-   }
+   block_sum3(dots[0], dots[1], dots[2], red, bp);
    double total[kVC];
    if (grid_sum3_last_block(bp, a.partials, a.stride, a.ticket, red, total))
    {
@@ -508,7 +503,7 @@ vcg_apply_plane(const VcgArgs a, const int nbatch)
    constexpr int DPT = (NQ + TE - 1) / TE;       // quadrature values staged per thread
    constexpr int DSTR = (NQ + 7) & ~1;
    __shared__ double smem[NEB * (PER + DSTR)];
-   __shared__ double red[16];
+   __shared__ double red[48];
 
    const int tid = threadIdx.x;
    unsigned long long t_start = 0, t_loop = 0;
@@ -715,12 +710,7 @@ vcg_apply_plane(const VcgArgs a, const int nbatch)
    }
    if (a.trace) { t_loop = wall_clock64(); }
    double bp[kVC];
-#pragma unroll
-   for (int k = 0; k < kVC; k++)
-   {
-      bp[k] = block_sum(c == k ? dot : 0.0, red);
-      __syncthreads();
-   }
+   block_sum3(c == 0 ? dot : 0.0, c == 1 ? dot : 0.0, c == 2 ? dot : 0.0, red, bp);
    double total[kVC];
    if (grid_sum3_last_block_flat(bp, a.partials, a.stride, a.ticket, red, total))
    {
@@ -783,7 +773,7 @@ vcg_apply_plane_ho(const VcgArgs a)
    static_assert(kVC * CE >= NQ, "the quadrature data of an element is staged where its x-contracted planes go later");
    __shared__ double smem[NEB * PER];
    __shared__ double sB[QD];
-   __shared__ double red[16];
+   __shared__ double red[48];
 
    const int tid = threadIdx.x;
    const int eb = tid / TE, lt = tid - eb * TE;
@@ -963,12 +953,7 @@ vcg_apply_plane_ho(const VcgArgs a)
       }
    }
    double bp[kVC];
-#pragma unroll
-   for (int k = 0; k < kVC; k++)
-   {
-      bp[k] = block_sum(c == k ? dot : 0.0, red);
-      __syncthreads();
-   }
+   block_sum3(c == 0 ? dot : 0.0, c == 1 ? dot : 0.0, c == 2 ? dot : 0.0, red, bp);
    double total[kVC];
    if (grid_sum3_last_block(bp, a.partials, a.stride, a.ticket, red, total))
    {
@@ -994,7 +979,7 @@ __device__ __forceinline__ double *vcg_ptr(double *base, const unsigned off) { r
 __global__ void __launch_bounds__(256)
 vcg_init_k(const VcgArgs a)
 {
-   __shared__ double red[16];
+   __shared__ double red[48];
    const int n = xcd_swizzle(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x; // as K2 and vcg_init_force_k
    double part[kVC] = {0.0, 0.0, 0.0};
    if (n < a.N)
@@ -1011,12 +996,7 @@ vcg_init_k(const VcgArgs a)
       }
    }
    double bp[kVC], total[kVC];
-#pragma unroll
-   for (int c = 0; c < kVC; c++)
-   {
-      bp[c] = block_sum(part[c], red);
-      __syncthreads();
-   }
+   block_sum3(part[0], part[1], part[2], red, bp);
    if (grid_sum3_last_block(bp, a.partials, a.stride, a.ticket, red, total))
    {
       if (threadIdx.x == 0)
@@ -1048,7 +1028,7 @@ template <int DEG>
 __global__ void __launch_bounds__(256)
 vcg_init_force_k(const VcgArgs a, const double *__restrict__ FE, const int ND, double *__restrict__ bout)
 {
-   __shared__ double red[16];
+   __shared__ double red[48];
    const int n = xcd_swizzle(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x; // node ranges of vcg_init_k: same partial sums
    double part[kVC] = {0.0, 0.0, 0.0};
    if (n < a.N)
@@ -1078,12 +1058,7 @@ vcg_init_force_k(const VcgArgs a, const double *__restrict__ FE, const int ND, d
       }
    }
    double bp[kVC], total[kVC];
-#pragma unroll
-   for (int c = 0; c < kVC; c++)
-   {
-      bp[c] = block_sum(part[c], red);
-      __syncthreads();
-   }
+   block_sum3(part[0], part[1], part[2], red, bp);
    if (grid_sum3_last_block(bp, a.partials, a.stride, a.ticket, red, total))
    {
       if (threadIdx.x == 0)
@@ -1110,7 +1085,7 @@ __global__ void __launch_bounds__(256)
 vcg_init_force_z_k(const VcgArgs a, const double *__restrict__ FE, const unsigned compb_fe, const unsigned *__restrict__ ellf,
                    double *__restrict__ bout)
 {
-   __shared__ double red[16];
+   __shared__ double red[48];
    const int n = xcd_swizzle(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
    const bool ok = n < a.N;
    const unsigned nn = (unsigned)(ok ? n : a.N - 1);
@@ -1155,12 +1130,7 @@ vcg_init_force_z_k(const VcgArgs a, const double *__restrict__ FE, const unsigne
       }
    }
    double bp[kVC], total[kVC];
-#pragma unroll
-   for (int c = 0; c < kVC; c++)
-   {
-      bp[c] = block_sum(part[c], red);
-      __syncthreads();
-   }
+   block_sum3(part[0], part[1], part[2], red, bp);
    if (grid_sum3_last_block(bp, a.partials, a.stride, a.ticket, red, total))
    {
       if (threadIdx.x == 0)
@@ -1239,7 +1209,7 @@ template <bool FUSED_GATHER, int DEG>
 __global__ void __launch_bounds__(256)
 vcg_update_k(const VcgArgs a)
 {
-   __shared__ double red[16];
+   __shared__ double red[48];
    if (a.s->all_done) { return; }
    const bool it1 = (a.iter == 1);
    const int n = xcd_swizzle(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
@@ -1292,12 +1262,7 @@ vcg_update_k(const VcgArgs a)
       }
    }
    double bp[kVC], total[kVC];
-#pragma unroll
-   for (int c = 0; c < kVC; c++)
-   {
-      bp[c] = block_sum(part[c], red);
-      __syncthreads();
-   }
+   block_sum3(part[0], part[1], part[2], red, bp);
    if (grid_sum3_last_block(bp, a.partials, a.stride, a.ticket, red, total))
    {
       if (threadIdx.x == 0)
@@ -1346,7 +1311,7 @@ __global__ void __launch_bounds__(512)
 vcg_update_p_k(const VcgArgs a)
 {
    constexpr int NT = 512;
-   __shared__ double red[16];
+   __shared__ double red[48];
    if (a.s->all_done) { return; }
    const int it = a.iter;
    const bool first = (it == 1);
@@ -1485,12 +1450,7 @@ vcg_update_p_k(const VcgArgs a)
       }
    }
    double bp[kVC], total[kVC];
-#pragma unroll
-   for (int k = 0; k < kVC; k++)
-   {
-      bp[k] = block_sum(part[k], red);
-      __syncthreads();
-   }
+   block_sum3(part[0], part[1], part[2], red, bp);
    if (grid_sum3_last_block(bp, a.partials, a.stride, a.ticket, red, total))
    {
       if (tid == 0)
