@@ -237,6 +237,12 @@ int lgh_pcg_iterations(lgh_ctx *ctx, long *iterations);
  * Bernstein basis on symmetric points is): the plane-form mass kernels keep half a table in scalar registers
  * and are only dispatched then (the column forms run otherwise). */
 int lgh_table_symmetry(lgh_ctx *ctx, int *h1, int *l2);
+/* Which form of the mass-apply kernel K1 the lockstep velocity solve (lgh_solve_velocity) launches for this
+ * context: 0 = column form, 2 = plane form, 3 = x contractions on the matrix cores (v_mfma_f64_16x16x4_f64, Q3Q2
+ * only), 4 = slab form (sum factorisation in registers, lane-group transposes by v_permlane swaps, Q3Q2 only),
+ * -1 = no lockstep solve for this kernel id (the scalar CG runs).  Tests use it to make sure a requested
+ * form (LGH_VCG_VARIANT) is the one that ran. */
+int lgh_k1_form(lgh_ctx *ctx, int *form);
 
 /* ---- multi-GPU: element blocks per rank, shared H1 nodes summed
  * over RCCL, dot products / dt all-reduced.  unique_id is the 128-byte

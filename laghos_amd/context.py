@@ -227,6 +227,12 @@ class Context:
         check(self.lib.lgh_table_symmetry(self.h, ctypes.byref(a), ctypes.byref(b)))
         return a.value, b.value
 
+    def k1_form(self):
+        """Form of the lockstep velocity solve's mass-apply kernel: 'column', 'plane', 'mfma', 'slab' or None."""
+        f = ctypes.c_int(-2)
+        check(self.lib.lgh_k1_form(self.h, ctypes.byref(f)))
+        return {0: "column", 2: "plane", 3: "mfma", 4: "slab"}.get(f.value)
+
     def solve_velocity(self, S, dS, one, rhs, work, rel_tol, max_iter):
         it = ctypes.c_int(0)
         check(self.lib.lgh_solve_velocity(self.h, _ptr(S), _ptr(dS), _ptr(one), _ptr(rhs), _ptr(work),

@@ -331,7 +331,7 @@ static int create_impl(const lgh_config *cfg, lgh_ctx *c, const int kid)
    LGH_TRY(dev_alloc_zero(&c->Jac0inv, nq * dim * dim));
    LGH_TRY(dev_alloc_zero(&c->Jac0inv_soa, nq * dim * dim));
    LGH_TRY(dev_alloc_zero(&c->rho0DetJ0w, nq));
-   LGH_TRY(dev_alloc_zero(&c->massD, nq));
+   LGH_TRY(dev_alloc_zero(&c->massD, nq + 2048)); // (one set of the matrix-core K1 behind the last element: its pipeline prefetches without predicates)
    LGH_TRY(dev_alloc_zero(&c->diagV, (size_t)c->N));
    LGH_TRY(dev_alloc_zero(&c->dinvV, (size_t)c->N));
    LGH_TRY(dev_alloc_zero(&c->dt_est_dev, 1));
@@ -879,6 +879,12 @@ int lgh_table_symmetry(lgh_ctx *c, int *h1, int *l2)
    LGH_CHECK_ARG(c && h1 && l2);
    *h1 = c->b_h1_sym;
    *l2 = c->b_l2_sym;
+   return LGH_OK;
+}
+int lgh_k1_form(lgh_ctx *c, int *form)
+{
+   LGH_CHECK_ARG(c && form);
+   *form = vcg_k1_form(c);
    return LGH_OK;
 }
 int lgh_pcg_iterations(lgh_ctx *c, long *iterations)

@@ -416,6 +416,7 @@ int make_essbits(lgh_ctx *c, uint8_t **out);
 void vcg_free(lgh_ctx *c);
 constexpr int kYePad = 16; // doubles behind every Y_E plane of the CG; the first one (slot NE*ND) stays 0.0
 bool vcg_available(const lgh_ctx *c);
+int vcg_k1_form(lgh_ctx *c); // 0 column, 2 plane, 3 matrix cores, 4 slab, -1 none
 // multi-rank: flags / list of the nodes shared with other ranks (nullptr / 0 without neighbours)
 void comm_shared_nodes(const lgh_ctx *c, const uint8_t **hmask, const int **sh_node, int *n_shared);
 int cg_l2_begin(lgh_ctx *c, const double *b, double *x, double rel_tol, int max_iter);

@@ -13,215 +13,10 @@
 // apply and the element->node maps are another 10 %; applying the operator to the
 // three directions in one pass reads them once instead of three times, halves the
 // launches, and amortises the grid reduction (one ticket, three sums).
-#include "lgh_common.hpp"
+#include "lgh_vcg.hpp"
 
 namespace lgh
 {
-
-constexpr int kVC = 3; // velocity components handled in lockstep
-
-struct VcgScalars
-{
-   double rz[kVC], rz_prev[kVC], den[kVC], r0[kVC];
-   double rel_tol2;
-   double alpha_last[kVC]; // vcg_update_p_k: alpha of the latest completed update of component c
-   int done[kVC], iters[kVC], first;
-   int all_done, pad;
-   int nupd[kVC], pad2;    // vcg_update_p_k: iteration of that update (x lags one update behind when it is odd)
-};
-
-// Several ranks (see cg_pending_update, lgh_mass.hip): the sums of den and (r, z) over the ranks complete between
-// the kernels, and the decisions they feed are taken by the next kernel of the sequence - every workgroup evaluates
-// the same predicate on the same reduced values, thread 0 of workgroup 0 also commits the outcome (write-through
-// stores; a commit only writes values under which the predicate stays true).
-// K1 of iteration iter >= 2: outcome of the update of iteration iter - 1.  live[c]: component c still iterates.
-// Returns false when none does.
-__device__ __forceinline__ bool vcg_pending_update(VcgScalars *s, const int iter, const bool commit, bool live[kVC])
-{
-   bool any = false;
-#pragma unroll
-   for (int c = 0; c < kVC; c++)
-   {
-      bool dn = s->done[c] != 0;
-      if (!dn)
-      {
-         const double rz = s->rz[c];
-         dn = rz < 0.0 || rz <= s->r0[c];
-         if (commit)
-         {
-            __hip_atomic_store(&s->iters[c], iter - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (dn)
-            {
-               __hip_atomic_store(&s->done[c], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-               __hip_atomic_store(&s->rz[c], 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-               __hip_atomic_store(&s->den[c], 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-         }
-      }
-      live[c] = !dn;
-      any = any || !dn;
-   }
-   if (!any && commit) { __hip_atomic_store(&s->all_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-   return any;
-}
-// K2: breakdown of component c (den == 0 after the sum over the ranks), as upstream
-__device__ __forceinline__ bool vcg_pending_den(VcgScalars *s, const int c, const bool commit)
-{
-   const bool brk = s->den[c] == 0.0;
-   if (brk && commit)
-   {
-      __hip_atomic_store(&s->done[c], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(&s->rz[c], 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-   }
-   return brk;
-}
-
-// three-value variant of grid_reduce_last_block (sum): partials[v*stride + i]
-__device__ __forceinline__ bool grid_sum3_last_block(const double bp[kVC], double *partials,
-                                                     const unsigned stride, unsigned int *ticket,
-                                                     double *red, double total[kVC])
-{
-   const int tid = threadIdx.x;
-   const int nthr = blockDim.x;
-   const unsigned int nblk = gridDim.x, bid = blockIdx.x;
-   const unsigned s = bid % kShards;
-   const unsigned cnt = nblk / kShards + ((s < nblk % kShards) ? 1u : 0u);
-   const unsigned nsh = nblk < kShards ? nblk : kShards;
-   unsigned int *t1 = ticket + s * kTicketStride;
-   unsigned int *t2 = ticket + kShards * kTicketStride;
-   __shared__ unsigned int s_flag;
-   if (tid == 0)
-   {
-#pragma unroll
-      for (int v = 0; v < kVC; v++)
-      {
-         __hip_atomic_store(&partials[(size_t)v * stride + bid], bp[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      const unsigned a = __hip_atomic_fetch_add(t1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      s_flag = (a == cnt - 1) ? 1u : 0u;
-   }
-   __syncthreads();
-   if (!s_flag) { return false; }
-   double ssum[kVC];
-#pragma unroll
-   for (int v = 0; v < kVC; v++)
-   {
-      double acc = 0.0;
-      for (unsigned int i = tid; i < cnt; i += nthr)
-      {
-         acc += __hip_atomic_load(&partials[(size_t)v * stride + s + kShards * i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      ssum[v] = block_sum(acc, red);
-      __syncthreads();
-   }
-   const unsigned shard_off = nblk; // shard sums follow the block partials of each value
-   if (tid == 0)
-   {
-#pragma unroll
-      for (int v = 0; v < kVC; v++)
-      {
-         __hip_atomic_store(&partials[(size_t)v * stride + shard_off + s], ssum[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __hip_atomic_store(t1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned b = __hip_atomic_fetch_add(t2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      s_flag = (b == nsh - 1) ? 1u : 0u;
-      if (s_flag) { __hip_atomic_store(t2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-   }
-   __syncthreads();
-   if (!s_flag) { return false; }
-#pragma unroll
-   for (int v = 0; v < kVC; v++)
-   {
-      double acc = 0.0;
-      for (unsigned int i = tid; i < nsh; i += nthr)
-      {
-         acc += __hip_atomic_load(&partials[(size_t)v * stride + shard_off + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      total[v] = block_sum(acc, red);
-      __syncthreads();
-   }
-   return true;
-}
-
-// Single-level variant for the persistent K1: its <= 1024 workgroups leave their
-// loops spread over ~15 us (profiles/r1_k1_block_timestamps.txt), so one ticket word
-// is not contended, and the last arrival sums all partials in one pass.  Saves the
-// second store / ticket / reload round trip of the sharded form at the kernel's tail.
-__device__ __forceinline__ bool grid_sum3_last_block_flat(const double bp[kVC], double *partials,
-                                                          const unsigned stride, unsigned int *ticket,
-                                                          double *red, double total[kVC])
-{
-   const int tid = threadIdx.x;
-   const int nthr = blockDim.x;
-   const unsigned int nblk = gridDim.x, bid = blockIdx.x;
-   unsigned int *t2 = ticket + kShards * kTicketStride; // the top word of the slot
-   __shared__ unsigned int s_flag;
-   if (tid == 0)
-   {
-#pragma unroll
-      for (int v = 0; v < kVC; v++)
-      {
-         __hip_atomic_store(&partials[(size_t)v * stride + bid], bp[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      const unsigned a = __hip_atomic_fetch_add(t2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      s_flag = (a == nblk - 1) ? 1u : 0u;
-      if (s_flag) { __hip_atomic_store(t2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-   }
-   __syncthreads();
-   if (!s_flag) { return false; }
-   double acc[kVC] = {0.0, 0.0, 0.0};
-   for (unsigned int i = tid; i < nblk; i += nthr)
-   {
-#pragma unroll
-      for (int v = 0; v < kVC; v++)
-      {
-         acc[v] += __hip_atomic_load(&partials[(size_t)v * stride + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-   }
-#pragma unroll
-   for (int v = 0; v < kVC; v++)
-   {
-      total[v] = block_sum(acc[v], red);
-      __syncthreads();
-   }
-   return true;
-}
-
-struct VcgArgs
-{
-   int NE, N;
-   const double *B, *Dq;
-   const int *map;
-   const int *ell;
-   int deg;
-   const uint8_t *ess[kVC];
-   const double *dinv, *owner;
-   const double *b;       // kVC*N right-hand sides (byNODES)
-   double *x;             // kVC*N solutions
-   double *r, *d;         // kVC*N each (z = r/diag is recomputed where it is used)
-   double *YE;            // kVC * NE*ND
-   size_t ye_stride;      // NE*ND
-   double *yL;            // kVC*N (unfused path)
-   VcgScalars *s;
-   double *partials;
-   unsigned stride;
-   unsigned int *ticket;
-   int iter, multi;
-   unsigned long long *trace; // debug (LGH_VCG_TRACE=file): per-workgroup time stamps of K1
-   // multi-rank: nodes shared with other ranks take their (halo-summed) A d from yL,
-   // all others gather it from the E-vector as on one rank
-   const uint8_t *hmask;      // N flags, or nullptr
-   const int *sh_node;        // the shared nodes
-   int n_shared;
-   // vcg_update_p_k
-   const unsigned *ellz;      // ell as byte offsets into a Y_E plane, absent entries -> its zero slot NE*ND
-   const uint8_t *essbits;    // bit k: node essential for component k
-   const int *nstart;         // node range of block w: [nstart[w], nstart[w+1]), balanced by cost
-   int k2_skip;               // vcg_update_p_k: skip ELL slots no node of the wavefront uses (LGH_K2_SKIP=0: fetch all 8)
-};
 
 // ---- K1: y_e^c = B^T D_e B d_e^c for the unconverged components, d^c = z^c + beta_c d^c.
 // Persistent workgroups: the grid is one resident wave of workgroups; each walks
@@ -731,10 +526,10 @@ vcg_apply_plane(const VcgArgs a, const int nbatch)
       unsigned xcc = 0, hwid = 0;
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-      a.trace[4 * blockIdx.x + 0] = t_start;
-      a.trace[4 * blockIdx.x + 1] = t_loop;
-      a.trace[4 * blockIdx.x + 2] = wall_clock64();
-      a.trace[4 * blockIdx.x + 3] = clock64() - c_start; // shader cycles between the two wall-clock stamps 0 and 2
+      a.trace[kTraceRec * blockIdx.x + 0] = t_start;
+      a.trace[kTraceRec * blockIdx.x + 1] = t_loop;
+      a.trace[kTraceRec * blockIdx.x + 2] = wall_clock64();
+      a.trace[kTraceRec * blockIdx.x + 3] = clock64() - c_start; // shader cycles between the two wall-clock stamps 0 and 2
    }
 }
 
@@ -1159,6 +954,23 @@ vcg_ellf_k(const int *__restrict__ ell, unsigned *__restrict__ ellf, const size_
    const int e = p / ND;
    ellf[i] = 8u * (unsigned)(p < 0 ? kVC * ND * NE : kVC * ND * e + (p - e * ND));
 }
+__global__ void __launch_bounds__(256)
+vcg_mapb_k(const int *__restrict__ map, unsigned *__restrict__ mapb, const size_t n)
+{
+   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+   if (i < n) { mapb[i] = 8u * (unsigned)map[i]; }
+}
+// flag = 1 unless the D nodes of every x-row of every element are consecutive node numbers
+__global__ void __launch_bounds__(256)
+vcg_map_xrows_k(const int *__restrict__ map, const size_t nrows, const int D, int *flag)
+{
+   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+   if (i >= nrows) { return; }
+   const int *p = map + i * D;
+   bool ok = true;
+   for (int k = 1; k < D; k++) { ok = ok && p[k] == p[0] + k; }
+   if (!ok) { *flag = 1; }
+}
 __global__ void vcg_init_finish_k(VcgScalars *s)
 {
    int all = 1;
@@ -1540,6 +1352,8 @@ struct VcgAux
    uint8_t *essbits = nullptr;
    int *nstart = nullptr;    // cost-balanced node ranges of the grid2 workgroups of vcg_update_p_k
    unsigned *ellf = nullptr; // ELL transpose as byte offsets into a force E-vector ([e][c][d] + zero slot): vcg_init_force_z_k
+   unsigned *mapb = nullptr; // element -> node map as byte offsets into a node vector: vcg_apply_mfma346
+   int map_xrows = 0;        // the nodes of every x-row of every element are consecutive (vcg_apply_slab346 then loads rows, not nodes)
    int grid2 = 0;
 };
 void vcg_free(lgh_ctx *c)
@@ -1551,6 +1365,7 @@ void vcg_free(lgh_ctx *c)
    (void)hipFree(x->essbits);
    (void)hipFree(x->nstart);
    (void)hipFree(x->ellf);
+   (void)hipFree(x->mapb);
    delete x;
    c->vcg_aux = nullptr;
 }
@@ -1621,6 +1436,16 @@ template <int D, int Q> static void launch_vcg_apply(lgh_ctx *c, const VcgArgs &
    } while (0)
 
 bool vcg_available(const lgh_ctx *c) { return vcg_supported(c); }
+// the form of K1 that vcg_solve launches (kept in one place: the dispatch below asks the same questions)
+int vcg_k1_form(lgh_ctx *c)
+{
+   if (!vcg_supported(c)) { return -1; }
+   if (c->kid == 0x346 && c->vcg_variant == 3 && vcg_mfma_available(c)) { return 3; }
+   if (c->kid == 0x346 && c->vcg_variant == 4 && vcg_slab_available(c)) { return 4; }
+   if (c->vcg_variant == 0) { return 0; }
+   if ((c->kid == 0x358 || c->kid == 0x36A) && !c->b_h1_sym) { return 0; }
+   return 2;
+}
 bool vcg_fused_init_ok(const lgh_ctx *c)
 {
    static const char *env = getenv("LGH_FUSED_INIT"); // A/B switch
@@ -1687,6 +1512,18 @@ int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
             LGH_HIP_CHECK(hipGetLastError());
          }
       }
+      if (vcg_k1_form(c) >= 3)
+      {
+         const size_t nm = (size_t)c->NE * c->ND;
+         LGH_HIP_CHECK(hipMalloc((void **)&x->mapb, nm * sizeof(unsigned)));
+         hipLaunchKernelGGL(vcg_mapb_k, dim3((unsigned)((nm + 255) / 256)), dim3(256), 0, nullptr, c->h1map, x->mapb, nm);
+         LGH_HIP_CHECK(hipGetLastError());
+         int *flag = (int *)c->scal, h = 1;
+         LGH_HIP_CHECK(hipMemset(flag, 0, sizeof(int)));
+         hipLaunchKernelGGL(vcg_map_xrows_k, dim3((unsigned)((nm / c->D1D + 255) / 256)), dim3(256), 0, nullptr, c->h1map, nm / c->D1D, c->D1D, flag);
+         LGH_HIP_CHECK(hipMemcpy(&h, flag, sizeof(int), hipMemcpyDeviceToHost));
+         x->map_xrows = (h == 0) ? 1 : 0;
+      }
       LGH_HIP_CHECK(hipStreamSynchronize(nullptr)); // the fills run asynchronously on the null stream
    }
    VcgAux *aux = (VcgAux *)c->vcg_aux;
@@ -1717,6 +1554,8 @@ int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
    a.ellz = aux->ellz;
    a.essbits = aux->essbits;
    a.nstart = aux->nstart;
+   a.mapb = aux->mapb;
+   a.map_xrows = aux->map_xrows;
    {
       static const char *e0 = getenv("LGH_K2_SKIP");
       a.k2_skip = (e0 && e0[0] == '0') ? 0 : 1;
@@ -1728,8 +1567,9 @@ int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
    // last K1 launch of every solve, in 10 ns ticks
    static const char *trace_path = getenv("LGH_VCG_TRACE");
    static unsigned long long *trace_dev = nullptr;
-   if (trace_path && !trace_dev) { (void)hipMalloc((void **)&trace_dev, 4 * 4096 * sizeof(unsigned long long)); }
+   if (trace_path && !trace_dev) { (void)hipMalloc((void **)&trace_dev, kTraceRec * 4096 * sizeof(unsigned long long)); (void)hipMemset(trace_dev, 0, kTraceRec * 4096 * sizeof(unsigned long long)); }
    a.trace = trace_dev;
+   if (trace_dev) { (void)hipMemsetAsync(trace_dev, 0, kTraceRec * 4096 * sizeof(unsigned long long), c->stream); }
    if (multi) { comm_shared_nodes(c, &a.hmask, &a.sh_node, &a.n_shared); }
    const int nb = ceil_div((long)N, 256);
 
@@ -1787,7 +1627,11 @@ int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
          {
             case 0x322: VCG_DISPATCH(2, 2); break;
             case 0x334: VCG_DISPATCH(3, 4); break;
-            case 0x346: VCG_DISPATCH(4, 6); break;
+            case 0x346:
+               if (aux->mapb && c->vcg_variant == 4) { launch_vcg_slab(c, a); } // slab form: all in registers (lgh_vcg_slab.hip)
+               else if (aux->mapb) { launch_vcg_mfma(c, a); } // LGH_VCG_VARIANT=3: x contractions on the matrix cores (lgh_vcg_mfma.hip)
+               else { VCG_DISPATCH(4, 6); }
+               break;
             case 0x358: // LGH_VCG_VARIANT=1: the two-lanes-per-plane split at Q1D = 8 as well (A/B, tests)
                if (c->vcg_variant == 0 || !c->b_h1_sym) { launch_vcg_apply<5, 8>(c, a); } // (the plane form uses half a table)
                else if (c->vcg_variant == 1) { launch_vcg_plane_ho<5, 8, 2, 5>(c, a); }
@@ -1871,14 +1715,17 @@ int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
    }
    if (trace_dev)
    {
-      std::vector<unsigned long long> h(4 * 4096);
+      std::vector<unsigned long long> h(kTraceRec * 4096);
       (void)hipMemcpy(h.data(), trace_dev, h.size() * 8, hipMemcpyDeviceToHost);
       FILE *f = fopen(trace_path, "w");
       if (f)
       {
-         for (int i = 0; i < c->vcg_grid && i < 4096; i++)
+         for (int i = 0; i < 4096; i++)
          {
-            fprintf(f, "%d %llu %llu %llu %llu\n", i, h[4 * i], h[4 * i + 1], h[4 * i + 2], h[4 * i + 3]);
+            if (h[(size_t)kTraceRec * i] == 0) { continue; } // (no such workgroup in the last launch)
+            fprintf(f, "%d", i);
+            for (int k = 0; k < kTraceRec; k++) { fprintf(f, " %llu", h[(size_t)kTraceRec * i + k]); }
+            fprintf(f, "\n");
          }
          fclose(f);
       }

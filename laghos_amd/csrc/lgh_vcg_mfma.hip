@@ -1,0 +1,388 @@
+// lgh_vcg_mfma.hip — K1 of the lockstep velocity solve (y_e = B^T D_e B d_e for the three
+// velocity components, Q3Q2 = kernel id 0x346) with the two x contractions on the matrix cores.
+//
+// Reference math: MassPAOperator::Mult, /root/reference/laghos_assembly.cpp:117-121 (the contraction
+// itself is upstream MFEM's MassIntegrator::AddMultPA; restated in amr/laghos_assembly.cpp:878-963).
+//
+// Why this shape (MI355X): at Q3Q2 the x contraction of one (element, component) is
+// (Q x D)(D x D^2) = 6x4 . 4x16: K = 4 is the K of v_mfma_f64_16x16x4_f64.  fp64 MFMA has the rate of the fp64
+// vector pipe on gfx950, so it buys no flops - what it buys is the data movement.  In the plane form
+// (lgh_vcg.hip: thread = one x-index of one (element, component), its (y, z) plane in registers) every thread of
+// an (element, component) needs all 64 dofs for the forward x contraction, and the backward one needs all six
+// planes: that exchange goes through LDS there (768 doubles read and 160 written per (element, component),
+// ~19 of the ~33 us of its loop are LDS issue).  Here the exchange IS the matrix instruction:
+//   * a wavefront works on a SET of 5 consecutive elements = 15 (element, component) items; item n is column n of
+//     the MFMA tile (column 15 idles).  Lane (g, n) = (lane >> 4, lane & 15) gathers the 16 dofs
+//     d[dx = g][j = dy + 4 dz] of item n straight from the node vectors into registers: that register j is the
+//     B operand (k = dx = lane >> 4, n = lane & 15) of forward MFMA j, the A operand holds the 1-D table in the
+//     rows that the C/D layout hands to this lane.  After the 16 MFMAs lane (g, n) owns the WHOLE (dy, dz) plane
+//     of x-index qx = g of item n in registers (and lanes g < 2 the plane qx = 4 + g as well): the plane form's
+//     layout, with no LDS traffic and no barrier.
+//   * y and z contractions, the scaling by the quadrature data and the transposed z and y contractions run per
+//     plane on registers with the (half) 1-D table in scalar registers, exactly as in vcg_apply_plane.
+//   * backward x: the plane value u[j] is the B operand (k = qx) of backward MFMA j, the A operand holds B^T in
+//     rows 4 dx + (j & 3), so four MFMAs accumulate into one tile and lane (g, n) ends up with
+//     out[dx = 0..3][j = 4 jq + g]: 32 contiguous bytes of the E-vector per tile, stored from registers.
+//   * (d, A d) is taken at the quadrature points, sum_q D_q (B d)_q^2 - the same number up to round-off, all
+//     terms non-negative, and d need not be kept.
+//   LDS only stages the quadrature data (coalesced global read, wave-private region, no barrier in the loop).
+// One wavefront per SIMD (512 registers): the software pipeline keeps the map of set i+2 and the gathers and
+// quadrature data of set i+1 in flight while set i is contracted.
+#include "lgh_vcg.hpp"
+
+namespace lgh
+{
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ double mfma_ld(const double *base, const unsigned off) { return *(const double *)((const char *)base + off); }
+
+// ---- layout probe ------------------------------------------------------------------------------------------
+// MI355X guide: v_mfma_f64_16x16x4_f64 takes A[i = lane & 15][k = lane >> 4], B[k = lane >> 4][n = lane & 15]
+// (one double per lane) and returns D[row = (lane >> 4) + 4 reg][col = lane & 15], reg = 0..3 - unlike the f32
+// forms (row = 4 (lane >> 4) + reg).  The kernel below is built for either row map; which one the hardware has
+// is measured once per process by this probe (three products of small integers, exact in fp64), and a layout
+// that is neither makes the MFMA form unavailable (vcg_solve then keeps the plane form).
+__global__ void mfma_f64_probe_k(double *out)
+{
+   const int lane = threadIdx.x, i = lane & 15, k = lane >> 4;
+   const v4d z = {0.0, 0.0, 0.0, 0.0};
+   // 1: D[i][n] = i + 1, 2: D[i][n] = n + 1, 3: asymmetric integers
+   v4d r1 = __builtin_amdgcn_mfma_f64_16x16x4f64((k == 1) ? (double)(i + 1) : 0.0, (k == 1) ? 1.0 : 0.0, z, 0, 0, 0);
+   v4d r2 = __builtin_amdgcn_mfma_f64_16x16x4f64((k == 2) ? 1.0 : 0.0, (k == 2) ? (double)(i + 1) : 0.0, z, 0, 0, 0);
+   v4d r3 = __builtin_amdgcn_mfma_f64_16x16x4f64((double)(i + 16 * k + 1), (double)(3 * i + 7 * k + 2), z, 0, 0, 0);
+   for (int r = 0; r < 4; r++)
+   {
+      out[0 * 256 + 4 * lane + r] = r1[r];
+      out[1 * 256 + 4 * lane + r] = r2[r];
+      out[2 * 256 + 4 * lane + r] = r3[r];
+   }
+}
+
+// returns the row map (0: row = g + 4 reg, 1: row = 4 g + reg) or -1
+static int mfma_f64_row_map(lgh_ctx *c)
+{
+   static int cached = -2;
+   if (cached != -2) { return cached; }
+   cached = -1;
+   double *dev = nullptr;
+   if (hipMalloc((void **)&dev, 3 * 256 * sizeof(double)) != hipSuccess) { return cached; }
+   hipLaunchKernelGGL(mfma_f64_probe_k, dim3(1), dim3(64), 0, c->stream, dev);
+   std::vector<double> h(3 * 256);
+   const bool ok = hipMemcpyAsync(h.data(), dev, h.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
+                   hipStreamSynchronize(c->stream) == hipSuccess;
+   (void)hipFree(dev);
+   if (!ok) { return cached; }
+   for (int rm = 0; rm < 2 && cached < 0; rm++)
+   {
+      bool good = true;
+      for (int lane = 0; lane < 64 && good; lane++)
+      {
+         const int g = lane >> 4, n = lane & 15;
+         for (int r = 0; r < 4; r++)
+         {
+            const int row = rm == 0 ? g + 4 * r : 4 * g + r;
+            double e3 = 0.0;
+            for (int k = 0; k < 4; k++) { e3 += (double)(row + 16 * k + 1) * (double)(3 * n + 7 * k + 2); }
+            good = good && h[4 * lane + r] == (double)(row + 1) && h[256 + 4 * lane + r] == (double)(n + 1) &&
+                   h[512 + 4 * lane + r] == e3;
+         }
+      }
+      if (good) { cached = rm; }
+   }
+   return cached;
+}
+
+// ---- one (y, z) plane: forward y, forward z, quadrature data, backward z, backward y --------------------------
+// t[dy + 4 dz] -> u[dy + 4 dz]; sDp = this plane's quadrature data in LDS, sDp[6 (qy + 6 qz)]; returns the plane's
+// share of sum_q D_q (B d)_q^2.  The same operations in the same order as the middle part of vcg_apply_plane.
+template <bool SYM, int HB>
+__device__ __forceinline__ double mfma_plane(const double (&t)[16], const double *sDp, const double (&Bsr)[HB], double (&u)[16])
+{
+   constexpr int D = 4, Q = 6, QD = Q * D;
+   auto Bs = [&](const int idx) -> double { return (SYM && idx >= HB) ? Bsr[QD - 1 - idx] : Bsr[idx]; };
+   double w[Q][D];
+#pragma unroll
+   for (int qy = 0; qy < Q; qy++)
+   {
+#pragma unroll
+      for (int dz = 0; dz < D; dz++)
+      {
+         double s = 0.0;
+#pragma unroll
+         for (int dy = 0; dy < D; dy++) { s = fma(Bs(qy + Q * dy), t[dy + D * dz], s); }
+         w[qy][dz] = s;
+      }
+   }
+   double dot = 0.0;
+#pragma unroll
+   for (int qy = 0; qy < Q; qy++)
+   {
+      double cz[Q];
+#pragma unroll
+      for (int qz = 0; qz < Q; qz++)
+      {
+         double s = 0.0;
+#pragma unroll
+         for (int dz = 0; dz < D; dz++) { s = fma(Bs(qz + Q * dz), w[qy][dz], s); }
+         cz[qz] = s * sDp[Q * (qy + Q * qz)];
+         dot = fma(s, cz[qz], dot);
+      }
+#pragma unroll
+      for (int dz = 0; dz < D; dz++)
+      {
+         double s = 0.0;
+#pragma unroll
+         for (int qz = 0; qz < Q; qz++) { s = fma(Bs(qz + Q * dz), cz[qz], s); }
+         w[qy][dz] = s;
+      }
+   }
+#pragma unroll
+   for (int dz = 0; dz < D; dz++)
+   {
+#pragma unroll
+      for (int dy = 0; dy < D; dy++)
+      {
+         double s = 0.0;
+#pragma unroll
+         for (int qy = 0; qy < Q; qy++) { s = fma(Bs(qy + Q * dy), w[qy][dz], s); }
+         u[dy + D * dz] = s;
+      }
+   }
+   return dot;
+}
+
+// RM: row map of the MFMA result (see the probe).  Lane group gg = lane >> 4 and result register r of a tile
+// belong to tile row ROW(gg, r); the A operands are built so that the wanted quantity lands in (gg, r).
+template <int RM, bool SYM>
+__global__ void __launch_bounds__(256, 1)
+vcg_apply_mfma346(const VcgArgs a, const int nset)
+{
+   constexpr int D = 4, Q = 6, NQ = Q * Q * Q, ND = D * D * D, QD = Q * D, HB = SYM ? (QD + 1) / 2 : QD;
+   constexpr int ES = 5;                     // elements of a set: 15 of the 16 tile columns
+   constexpr int NW = 4;                     // wavefronts of a workgroup, each on its own sets
+   constexpr int SDS = 230;                  // LDS doubles per element: 1840 B = 48 mod 256, so the 5 elements x 2..4
+                                             // x-indices a half-wave reads sit in different banks
+   constexpr int DPT = (ES * NQ + 63) / 64;  // quadrature values staged per lane and set
+   __shared__ double sDall[NW * ES * SDS];
+   __shared__ double red[48];
+
+   const int tid = threadIdx.x, lane = tid & 63;
+   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6); // wave-uniform: set indices and their base addresses stay in scalar registers
+   const int g = lane >> 4, n = lane & 15;
+   const int ni = min(n, 14), el = ni / 3, c = ni - 3 * el;
+   double *sD = sDall + wid * (ES * SDS);
+   const int W = gridDim.x * NW;
+   int s = xcd_swizzle(blockIdx.x, gridDim.x) * NW + wid;
+
+   // No predicates on the loads of the pipeline (as in vcg_apply_plane): sets past the end re-read the last set, elements
+   // past the end the last element, and the quadrature data is padded by one set behind its last element (lgh_create);
+   // nothing of that is stored or summed.  The loop body is straight-line code up to the second plane of lanes 0-31.
+   unsigned mo[16]; // byte offsets of this lane's 16 nodes (dx = g; j = dy + 4 dz) into a node vector
+   auto load_map = [&](const int ss) {
+      const int e = min(ES * min(ss, nset - 1) + el, a.NE - 1);
+      const unsigned *p = a.mapb + (size_t)e * ND + g;
+#pragma unroll
+      for (int j = 0; j < 16; j++) { mo[j] = p[4 * j]; }
+   };
+   load_map(s); // in flight while the scalars are read
+
+   if (a.s->all_done) { return; }
+   const bool first = a.s->first != 0;
+   bool todo[kVC];
+   double beta[kVC];
+#pragma unroll
+   for (int k = 0; k < kVC; k++) { todo[k] = a.s->done[k] == 0; }
+   if (a.multi && !first && !vcg_pending_update(a.s, a.iter, blockIdx.x == 0 && tid == 0, todo)) { return; }
+#pragma unroll
+   for (int k = 0; k < kVC; k++) { beta[k] = (first || !todo[k]) ? 0.0 : a.s->rz[k] / a.s->rz_prev[k]; }
+   const bool mine = (c == 0) ? todo[0] : (c == 1) ? todo[1] : todo[2];
+   const double betac = (c == 0) ? beta[0] : (c == 1) ? beta[1] : beta[2];
+
+   double Bsr[HB];
+#pragma unroll
+   for (int i = 0; i < HB; i++) { Bsr[i] = uniform_f64(a.B[i]); }
+   // A operands: lane (i = lane & 15, k = lane >> 4) holds A[i][k]; row i belongs to lane group gi, register ri
+   const int ai = lane & 15, ak = lane >> 4;
+   const int gi = (RM == 0) ? (ai & 3) : (ai >> 2), ri = (RM == 0) ? (ai >> 2) : (ai & 3);
+   // forward: registers (0, 1) of a tile take the planes qx = gg and qx = 4 + gg (gg < 2) of an even j, registers
+   // (2, 3) those of the odd j that accumulates into the same tile
+   const double bf_lo = a.B[gi + Q * ak], bf_hi = (gi < 2) ? a.B[4 + gi + Q * ak] : 0.0;
+   const double afe = (ri == 0) ? bf_lo : (ri == 1) ? bf_hi : 0.0;
+   const double afo = (ri == 2) ? bf_lo : (ri == 3) ? bf_hi : 0.0;
+   // backward: tile row (gg, r) = out[dx = r][j = 4 jq + gg]; MFMA jr of a tile fills the rows of lane group jr
+   // k step 0: qx = k; k step 1: qx = 4 + k (k < 2)
+   const double bb0 = a.B[ak + Q * ri], bb1 = (ak < 2) ? a.B[4 + ak + Q * ri] : 0.0;
+   double ab0[4], ab1[4];
+#pragma unroll
+   for (int jr = 0; jr < 4; jr++)
+   {
+      ab0[jr] = (gi == jr) ? bb0 : 0.0;
+      ab1[jr] = (gi == jr) ? bb1 : 0.0;
+   }
+   // node vectors: one scalar base + 32-bit byte offsets (vcg_mfma_available checks kVC * N * 8 < 2^32).  In the first
+   // iteration (beta = 0) the old direction is not defined: r is read in its place and multiplied by zero.
+   const unsigned coff = 8u * (unsigned)c * (unsigned)a.N;
+   const double *dsrc = first ? a.r : a.d;
+   __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): the one-time loads are complete before the pipelined loop (see vcg_apply_plane)
+
+   double gz[16], gd[16], gv[16], dq[DPT];
+   auto load_gather = [&]() {
+#pragma unroll
+      for (int j = 0; j < 16; j++) { gv[j] = mfma_ld(a.dinv, mo[j]); }
+#pragma unroll
+      for (int j = 0; j < 16; j++)
+      {
+         gz[j] = mfma_ld(a.r, mo[j] + coff);
+         gd[j] = mfma_ld(dsrc, mo[j] + coff);
+      }
+   };
+   auto load_dq = [&](const int ss) {
+      const double *p = a.Dq + (size_t)min(ss, nset - 1) * (ES * NQ); // (scalar)
+#pragma unroll
+      for (int k = 0; k < DPT; k++) { dq[k] = mfma_ld(p, 8u * (unsigned)(lane + 64 * k)); }
+   };
+
+   double dot = 0.0;
+   load_gather();
+   load_dq(s);
+   load_map(s + W);
+   const double *sD0 = sD + el * SDS + g;
+   // debug (LGH_VCG_TRACE): wall-clock stamps of wave 0 and the shader cycles it spends waiting for the loads of a set
+   unsigned long long t_start = 0, t_loop = 0, c_wait = 0, c_loop = 0;
+   if (a.trace) { t_start = wall_clock64(); c_loop = clock64(); }
+   for (; s < nset; s += W)
+   {
+      if (a.trace)
+      {
+         const unsigned long long c0 = clock64();
+         __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
+         c_wait += clock64() - c0;
+      }
+      const int e = ES * s + el;
+      const bool act = (n < 15) && (e < a.NE) && mine;
+      // direction d = z + beta d (K2 stores the same values)
+      double dd[16];
+#pragma unroll
+      for (int j = 0; j < 16; j++) { dd[j] = fma(betac, gd[j], __dmul_rn(gz[j], gv[j])); }
+      // quadrature data of this set -> LDS (wave-private; the planes of the previous set have been read:
+      // the LDS operations of a wave complete in order)
+#pragma unroll
+      for (int k = 0; k < DPT; k++)
+      {
+         const int t = lane + 64 * k, eq = t / NQ;
+         if ((k + 1) * 64 <= ES * NQ || t < ES * NQ) { sD[eq * SDS + (t - eq * NQ)] = dq[k]; }
+      }
+      // next set: gathers and quadrature data now, the map of the one after
+      load_gather();
+      load_dq(s + W);
+      load_map(s + 2 * W);
+      // forward x on the matrix cores
+      v4d T[8];
+#pragma unroll
+      for (int jp = 0; jp < 8; jp++)
+      {
+         const v4d z = {0.0, 0.0, 0.0, 0.0};
+         T[jp] = __builtin_amdgcn_mfma_f64_16x16x4f64(afe, dd[2 * jp], z, 0, 0, 0);
+         T[jp] = __builtin_amdgcn_mfma_f64_16x16x4f64(afo, dd[2 * jp + 1], T[jp], 0, 0, 0);
+      }
+      double t1[16], u1[16], u2[16];
+#pragma unroll
+      for (int jp = 0; jp < 8; jp++)
+      {
+         t1[2 * jp] = T[jp][0];
+         t1[2 * jp + 1] = T[jp][2];
+      }
+      double dset = mfma_plane<SYM, HB>(t1, sD0, Bsr, u1);
+      if (g < 2)
+      {
+         double t2[16];
+#pragma unroll
+         for (int jp = 0; jp < 8; jp++)
+         {
+            t2[2 * jp] = T[jp][1];
+            t2[2 * jp + 1] = T[jp][3];
+         }
+         dset += mfma_plane<SYM, HB>(t2, sD0 + 4, Bsr, u2);
+      }
+      else
+      {
+#pragma unroll
+         for (int j = 0; j < 16; j++) { u2[j] = 0.0; }
+      }
+      // backward x on the matrix cores
+      v4d O[4];
+#pragma unroll
+      for (int jq = 0; jq < 4; jq++) { O[jq] = v4d{0.0, 0.0, 0.0, 0.0}; }
+#pragma unroll
+      for (int jr = 0; jr < 4; jr++)
+      {
+#pragma unroll
+         for (int jq = 0; jq < 4; jq++) { O[jq] = __builtin_amdgcn_mfma_f64_16x16x4f64(ab0[jr], u1[4 * jq + jr], O[jq], 0, 0, 0); }
+      }
+#pragma unroll
+      for (int jr = 0; jr < 4; jr++)
+      {
+#pragma unroll
+         for (int jq = 0; jq < 4; jq++) { O[jq] = __builtin_amdgcn_mfma_f64_16x16x4f64(ab1[jr], u2[4 * jq + jr], O[jq], 0, 0, 0); }
+      }
+      if (act)
+      {
+         double *yc = a.YE + (size_t)c * a.ye_stride + (size_t)ND * e + 4 * g;
+#pragma unroll
+         for (int jq = 0; jq < 4; jq++) { *(v4d *)(yc + 16 * jq) = O[jq]; }
+      }
+      dot += act ? dset : 0.0;
+   }
+   if (a.trace) { t_loop = wall_clock64(); c_loop = clock64() - c_loop; }
+   double bp[kVC];
+   block_sum3(c == 0 ? dot : 0.0, c == 1 ? dot : 0.0, c == 2 ? dot : 0.0, red, bp);
+   double total[kVC];
+   const bool last = grid_sum3_last_block_flat(bp, a.partials, a.stride, a.ticket, red, total);
+   if (a.trace && tid == 0)
+   {
+      a.trace[kTraceRec * blockIdx.x + 0] = t_start;
+      a.trace[kTraceRec * blockIdx.x + 1] = t_loop;
+      a.trace[kTraceRec * blockIdx.x + 2] = wall_clock64();
+      a.trace[kTraceRec * blockIdx.x + 3] = (c_wait << 32) | (c_loop & 0xffffffffull); // cycles waiting | cycles in the loop
+   }
+   if (last)
+   {
+      if (tid == 0)
+      {
+         VcgScalars *sc = a.s;
+         for (int k = 0; k < kVC; k++)
+         {
+            if (!todo[k]) { continue; }
+            sc->den[k] = total[k];
+            if (total[k] == 0.0 && !a.multi) { sc->done[k] = 1; } // breakdown, as upstream
+         }
+         sc->first = 0;
+      }
+   }
+}
+
+bool vcg_mfma_available(lgh_ctx *c)
+{
+   // (node vectors are addressed by one scalar base + a 32-bit byte offset)
+   return c->dim == 3 && c->kid == 0x346 && (size_t)c->N * 8 * kVC < 0xffffffffull && mfma_f64_row_map(c) >= 0;
+}
+
+void launch_vcg_mfma(lgh_ctx *c, const VcgArgs &a)
+{
+   static int ncu = 0;
+   if (ncu == 0)
+   {
+      hipDeviceProp_t prop;
+      ncu = (hipGetDeviceProperties(&prop, c->device) == hipSuccess) ? prop.multiProcessorCount : 256;
+   }
+   const int nset = ceil_div(c->NE, 5);
+   const int grid = std::min(ceil_div(nset, 4), ncu);
+   const int rm = mfma_f64_row_map(c);
+#define LGH_MFMA_LAUNCH(RM_, SYM_) hipLaunchKernelGGL((vcg_apply_mfma346<RM_, SYM_>), dim3(grid), dim3(256), 0, c->stream, a, nset)
+   if (rm == 0) { if (c->b_h1_sym) { LGH_MFMA_LAUNCH(0, true); } else { LGH_MFMA_LAUNCH(0, false); } }
+   else { if (c->b_h1_sym) { LGH_MFMA_LAUNCH(1, true); } else { LGH_MFMA_LAUNCH(1, false); } }
+#undef LGH_MFMA_LAUNCH
+}
+
+} // namespace lgh

@@ -416,6 +416,46 @@ def test_lockstep_k1_forms_agree_at_high_order(order, monkeypatch):
         assert rel_err(dS[H1V:2 * H1V], dS_o[H1V:2 * H1V]) < 1e-10, variant
 
 
+@pytest.mark.parametrize("mesh,rs", [("box01_hex", 0), ("cube01_hex", 1)], ids=["16zones", "64zones"])
+def test_lockstep_k1_forms_agree_at_q3q2(mesh, rs, monkeypatch):
+    """The lockstep velocity solve at Q3Q2 (kernel id 0x346, the headline configuration) through each form of its
+    mass-apply kernel (LGH_VCG_VARIANT: 0 = column form, 2 = plane form, 3 = x contractions on the matrix cores,
+    lgh_vcg_mfma.hip, 4 = slab form, lgh_vcg_slab.hip; default = as dispatched).  16 and 64 zones: ragged last sets for the sets of 5 elements of the
+    matrix-core form and the batches of 13 of the plane form.  Distorted state, CG to 1e-14: the velocity part of
+    dS/dt agrees with the oracle to the operator tolerance in every form."""
+    from oracle.fem import Problem
+    prob = Problem(mesh=mesh, rs=rs, order_v=3, order_e=2, problem=1)
+    S = deformed_state(prob, seed=37)
+    o = make_oracle(prob)
+    try:
+        o.cg_tol = 1e-14
+        dS_o = np.empty_like(S)
+        o.qdata_is_current = False
+        o.mult(S, dS_o)
+    finally:
+        o.close()
+    H1V = prob.H1V
+    for variant in ("0", "2", "3", "4", None):
+        if variant is None:
+            monkeypatch.delenv("LGH_VCG_VARIANT", raising=False)
+        else:
+            monkeypatch.setenv("LGH_VCG_VARIANT", variant)
+        g = make_gpu(prob)
+        try:
+            if variant in ("3", "4"):
+                assert g.ctx.k1_form() == {"3": "mfma", "4": "slab"}[variant]
+            g.cg_tol = 1e-14
+            Sd = g.ctx.to_dev(S)
+            dS = g.ctx.zeros(S.size)
+            g.reset_quadrature_data()
+            g.mult(Sd, dS)
+            g.ctx.sync()
+            dS = dS.cpu().numpy()
+        finally:
+            g.close()
+        assert rel_err(dS[H1V:2 * H1V], dS_o[H1V:2 * H1V]) < 1e-10, variant
+
+
 @pytest.mark.parametrize("order", [(3, 2), (4, 3)], ids=["Q3Q2", "Q4Q3"])
 def test_mass_kernels_without_table_symmetry(order, monkeypatch):
     """LGH_B_SYM=0: lgh_create treats the 1-D tables as not mirror symmetric, as it would for a basis on asymmetric
