@@ -309,7 +309,16 @@ static int create_impl(const lgh_config *cfg, lgh_ctx *c, const int kid)
       const char *env = getenv("LGH_ATOMIC_SCATTER");
       c->atomic_scatter = (env && env[0] == '1') ? 1 : 0;
       env = getenv("LGH_VCG_VARIANT"); // A/B switch of the lockstep K1 (lgh_vcg.hip)
-      c->vcg_variant = (env && env[0] >= '0' && env[0] <= '9') ? env[0] - '0' : 2;
+      c->vcg_variant = (env && env[0] >= '0' && env[0] <= '9') ? env[0] - '0' : -1; // -1: by kernel id and mesh size (vcg_k1_form)
+      // slab-form K1 (lgh_vcg_slab.hip), A/B: wavefronts per SIMD (default 2), row loads, exact sum of (d, A d), sets drawn from a workgroup queue
+      env = getenv("LGH_SLAB_WPS");
+      c->slab_wps = (env && env[0] == '1') ? 1 : 2;
+      env = getenv("LGH_SLAB_WIDE");
+      c->slab_wide = (env && env[0] == '0') ? 0 : 1;
+      env = getenv("LGH_SLAB_EXACT");
+      c->slab_exact = (env && env[0] == '0') ? 0 : 1;
+      env = getenv("LGH_SLAB_DYN");
+      c->slab_dyn = (env && env[0] == '0') ? 0 : 1;
    }
    for (int k = 0; k < 3; k++)
    {

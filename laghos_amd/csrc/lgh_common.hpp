@@ -137,7 +137,8 @@ struct lgh_ctx
    int vcg_last;
    int vcg_grid;         // persistent grid size of the K1 kernel (one resident wave)
    int b_h1_sym, b_l2_sym; // the 1-D H1 / L2 table is mirror symmetric, B[q,d] = B[Q-1-q, D-1-d] (to 1e-14: the round-off of its evaluation): kernels may hold half of it
-   int vcg_variant;      // LGH_VCG_VARIANT: which K1 form vcg_solve launches (lgh_vcg.hip)
+   int vcg_variant;      // LGH_VCG_VARIANT: which K1 form vcg_solve launches (lgh_vcg.hip); -1: by kernel id and mesh size
+   int slab_wps, slab_wide, slab_exact, slab_dyn; // A/B switches of the slab-form K1 (LGH_SLAB_WPS / _WIDE / _EXACT / _DYN, read by lgh_create)
    void *vcg_aux;        // tables of the node kernel K2 (lgh_vcg.hip VcgAux), allocated on first use
    void *pcg;            // state of the persistent solve kernel (lgh_pcg.hip), allocated on first use
    long pcg_iterations;  // loop trips of the persistent solve kernel since lgh_pcg_iterations()

@@ -983,8 +983,9 @@ __global__ void vcg_init_finish_k(VcgScalars *s)
    }
    s->all_done = all;
 }
-__global__ void vcg_set_tol_k(VcgScalars *s, double rel_tol2)
+__global__ void vcg_set_tol_k(VcgScalars *s, double rel_tol2, long long *limbs)
 {
+   if (limbs) { for (int i = 0; i < 2 * kLimbWords + 8 * 16; i++) { limbs[i] = 0; } } // accumulators and the set counters behind them
    s->rel_tol2 = rel_tol2;
    s->all_done = 0;
    s->first = 1;
@@ -1131,14 +1132,16 @@ vcg_update_p_k(const VcgArgs a)
    const int w = xcd_swizzle(blockIdx.x, gridDim.x);
    const int n0 = a.nstart[w], n1 = a.nstart[w + 1];
    bool todo[kVC];
-   double alpha[kVC], alpha_prev[kVC], beta[kVC];
+   double alpha[kVC], alpha_prev[kVC], beta[kVC], den[kVC];
+#pragma unroll
+   for (int k = 0; k < kVC; k++) { den[k] = a.s->den[k]; }
 #pragma unroll
    for (int k = 0; k < kVC; k++)
    {
       todo[k] = a.s->done[k] == 0;
       // (several ranks: breakdown is looked at here, after the sum of (d, A d) over the ranks - vcg_pending_den)
       if (a.multi && todo[k] && vcg_pending_den(a.s, k, blockIdx.x == 0 && tid == 0)) { todo[k] = false; }
-      alpha[k] = todo[k] ? a.s->rz[k] / a.s->den[k] : 0.0;
+      alpha[k] = todo[k] ? a.s->rz[k] / den[k] : 0.0;
       alpha_prev[k] = todo[k] ? a.s->alpha_last[k] : 0.0;
       beta[k] = (first || !todo[k]) ? 0.0 : a.s->rz[k] / a.s->rz_prev[k];
    }
@@ -1273,7 +1276,7 @@ vcg_update_p_k(const VcgArgs a)
          {
             if (!s->done[k] && !(a.multi && s->den[k] == 0.0)) // (several ranks: breakdown found by this launch)
             {
-               s->alpha_last[k] = s->rz[k] / s->den[k]; // the alpha this launch used
+               s->alpha_last[k] = s->rz[k] / den[k]; // the alpha this launch used
                s->nupd[k] = it;
                s->rz_prev[k] = s->rz[k];
                s->rz[k] = total[k]; // betanom: on several ranks the local part, summed and looked at by the next K1
@@ -1354,6 +1357,7 @@ struct VcgAux
    unsigned *ellf = nullptr; // ELL transpose as byte offsets into a force E-vector ([e][c][d] + zero slot): vcg_init_force_z_k
    unsigned *mapb = nullptr; // element -> node map as byte offsets into a node vector: vcg_apply_mfma346
    int map_xrows = 0;        // the nodes of every x-row of every element are consecutive (vcg_apply_slab346 then loads rows, not nodes)
+   long long *limbs = nullptr; // exact accumulators of (d, A d), 2 parities (lgh_vcg.hpp)
    int grid2 = 0;
 };
 void vcg_free(lgh_ctx *c)
@@ -1366,6 +1370,7 @@ void vcg_free(lgh_ctx *c)
    (void)hipFree(x->nstart);
    (void)hipFree(x->ellf);
    (void)hipFree(x->mapb);
+   (void)hipFree(x->limbs);
    delete x;
    c->vcg_aux = nullptr;
 }
@@ -1442,6 +1447,10 @@ int vcg_k1_form(lgh_ctx *c)
    if (!vcg_supported(c)) { return -1; }
    if (c->kid == 0x346 && c->vcg_variant == 3 && vcg_mfma_available(c)) { return 3; }
    if (c->kid == 0x346 && c->vcg_variant == 4 && vcg_slab_available(c)) { return 4; }
+   // Default at Q3Q2: the slab form where the mesh does not fit the Infinity Cache - measured (profiles/README.md): 64^3
+   // zones 309 vs 375 us per launch, 32^3 zones 56 vs 50 us (there its longer tail outweighs its shorter loop).  One rank
+   // only: its exact sum of (d, A d) and its schedule have no multi-rank path.
+   if (c->kid == 0x346 && c->vcg_variant < 0 && c->multi == 0 && c->NE >= kSlabMinElements && vcg_slab_available(c)) { return 4; }
    if (c->vcg_variant == 0) { return 0; }
    if ((c->kid == 0x358 || c->kid == 0x36A) && !c->b_h1_sym) { return 0; }
    return 2;
@@ -1523,14 +1532,19 @@ int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
          hipLaunchKernelGGL(vcg_map_xrows_k, dim3((unsigned)((nm / c->D1D + 255) / 256)), dim3(256), 0, nullptr, c->h1map, nm / c->D1D, c->D1D, flag);
          LGH_HIP_CHECK(hipMemcpy(&h, flag, sizeof(int), hipMemcpyDeviceToHost));
          x->map_xrows = (h == 0) ? 1 : 0;
+         LGH_HIP_CHECK(hipMalloc((void **)&x->limbs, (2 * kLimbWords + 8 * 16 + 32 * 4096) * sizeof(long long)));
+         LGH_HIP_CHECK(hipMemset(x->limbs, 0, (2 * kLimbWords + 8 * 16 + 32 * 4096) * sizeof(long long)));
       }
       LGH_HIP_CHECK(hipStreamSynchronize(nullptr)); // the fills run asynchronously on the null stream
    }
    VcgAux *aux = (VcgAux *)c->vcg_aux;
+   const int k1form = vcg_k1_form(c);
    static const char *k2env = getenv("LGH_K2P"); // A/B: 0 = vcg_update_k (one node per thread, x every iteration)
    const bool k2p = aux->ellz != nullptr && !(k2env && k2env[0] == '0');
    VcgScalars *ds = (VcgScalars *)c->vcg_s;
-   hipLaunchKernelGGL(vcg_set_tol_k, dim3(1), dim3(1), 0, c->stream, ds, rel_tol * rel_tol);
+   // exact accumulators of (d, A d): slab-form K1 on one rank with the bounded-grid K2 (LGH_SLAB_EXACT=0: ticketed fold)
+   long long *limbs = (c->slab_exact && k2p && !multi && k1form == 4) ? aux->limbs : nullptr;
+   hipLaunchKernelGGL(vcg_set_tol_k, dim3(1), dim3(1), 0, c->stream, ds, rel_tol * rel_tol, limbs);
 
    VcgArgs a;
    memset(&a, 0, sizeof(a));
@@ -1556,6 +1570,8 @@ int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
    a.nstart = aux->nstart;
    a.mapb = aux->mapb;
    a.map_xrows = aux->map_xrows;
+   a.limbs = limbs;
+   a.queue = limbs ? (unsigned *)(limbs + 2 * kLimbWords) : nullptr;
    {
       static const char *e0 = getenv("LGH_K2_SKIP");
       a.k2_skip = (e0 && e0[0] == '0') ? 0 : 1;
@@ -1628,8 +1644,8 @@ int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
             case 0x322: VCG_DISPATCH(2, 2); break;
             case 0x334: VCG_DISPATCH(3, 4); break;
             case 0x346:
-               if (aux->mapb && c->vcg_variant == 4) { launch_vcg_slab(c, a); } // slab form: all in registers (lgh_vcg_slab.hip)
-               else if (aux->mapb) { launch_vcg_mfma(c, a); } // LGH_VCG_VARIANT=3: x contractions on the matrix cores (lgh_vcg_mfma.hip)
+               if (aux->mapb && k1form == 4) { launch_vcg_slab(c, a); } // slab form: all in registers (lgh_vcg_slab.hip)
+               else if (aux->mapb && k1form == 3) { launch_vcg_mfma(c, a); } // LGH_VCG_VARIANT=3: x contractions on the matrix cores (lgh_vcg_mfma.hip)
                else { VCG_DISPATCH(4, 6); }
                break;
             case 0x358: // LGH_VCG_VARIANT=1: the two-lanes-per-plane split at Q1D = 8 as well (A/B, tests)

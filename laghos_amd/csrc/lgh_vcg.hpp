@@ -7,6 +7,7 @@ namespace lgh
 {
 
 constexpr int kVC = 3; // velocity components handled in lockstep
+constexpr int kSlabMinElements = 100000; // default dispatch of the slab-form K1 (vcg_k1_form)
 constexpr int kTraceRec = 16; // debug (LGH_VCG_TRACE): 64-bit words per workgroup record of K1
 
 struct VcgScalars
@@ -186,6 +187,8 @@ struct VcgArgs
    const int *map;
    const unsigned *mapb;  // map as byte offsets into a node vector (8 * node): the matrix-core K1 (lgh_vcg_mfma.hip)
    int map_xrows;         // 1: the D1D nodes of every x-row of every element are consecutive node numbers (checked at set-up)
+   unsigned *queue;       // slab-form K1, dynamic schedule: one set counter per XCD range, 128 bytes apart (zero between launches)
+   long long *limbs;      // exact accumulators of (d, A d): kLimbWords words (slab-form K1), or nullptr (ticketed fold of workgroup partials)
    const int *ell;
    int deg;
    const uint8_t *ess[kVC];
@@ -213,6 +216,86 @@ struct VcgArgs
    const int *nstart;         // node range of block w: [nstart[w], nstart[w+1]), balanced by cost
    int k2_skip;               // vcg_update_p_k: skip ELL slots no node of the wavefront uses (LGH_K2_SKIP=0: fetch all 8)
 };
+
+// ---- exact, order-independent sums of doubles (the (d, A d) of the slab-form K1) -------------------------------
+// Why: a ticketed last-workgroup fold puts ~4 us of dependent memory round trips behind the slowest workgroup of
+// K1, and a sum whose bits must not depend on which wavefront took which set of elements rules out scheduling the
+// sets dynamically.  Integer addition is associative: every addend v, known to lie in (-2^(E-1), 2^(E-1)), is split
+// into kLimbs signed pieces of 32 bits - limb j weighs 2^(E - 32 (j + 1)) - which are added into 64-bit integer
+// accumulators (registers, LDS, finally fire-and-forget device atomics: no ticket, no fold, nobody is "last").
+// The window of 128 bits below 2^E loses at most 2^(E-128) per addend; up to 2^31 addends fit the accumulators.
+// E comes from a quantity every workgroup of the producing and of the consuming kernel reads alike (rz of the
+// iteration: (d, A d) <= lambda_max(D^-1 M) (r, z) <= 64 (r, z) for the Jacobi-preconditioned mass matrix), a
+// non-finite or out-of-window addend sets a sticky flag that turns the sum into NaN.
+constexpr int kLimbs = 4;      // 64-bit accumulators per sum
+constexpr int kLimbShards = 4; // copies of the accumulators (workgroup b adds to shard b % kLimbShards): ~64 atomics per word and launch
+constexpr int kLimbWords = kLimbShards * kVC * kLimbs + 8; // the accumulators, then the flag word (padded)
+__device__ __forceinline__ int exact_scale(const double rz) // E for sums bounded by 64 rz (margin 2^5)
+{
+   int e;
+   (void)frexp(rz, &e); // rz = m 2^e, m in [0.5, 1)
+   return e + 12;
+}
+// returns false when v does not fit the window (|v| >= 2^(E-1), NaN, inf); acc is then left alone
+__device__ __forceinline__ bool exact_add(long long (&acc)[kLimbs], const double v, const int E)
+{
+   double x = ldexp(v, 32 - E); // exact; |x| < 2^31 required
+   if (!(fabs(x) < 2147483648.0)) { return false; }
+   double f = floor(x);
+   acc[0] += (long long)(int)f; // signed top limb
+   x = (x - f) * 4294967296.0;  // exact: fractional part, scaled by 2^32
+#pragma unroll
+   for (int j = 1; j < kLimbs; j++)
+   {
+      f = floor(x);
+      acc[j] += (long long)(unsigned)f;
+      x = (x - f) * 4294967296.0;
+   }
+   return true;
+}
+// the value of the accumulators: carries first (integers), then one deterministic chain of fp operations
+__device__ __forceinline__ double exact_value(const long long (&L)[kLimbs], const int E)
+{
+   long long l[kLimbs];
+#pragma unroll
+   for (int j = 0; j < kLimbs; j++) { l[j] = L[j]; }
+#pragma unroll
+   for (int j = kLimbs - 1; j > 0; j--)
+   {
+      const long long carry = l[j] >> 32; // arithmetic shift: floor division by 2^32
+      l[j] -= carry * 4294967296LL;       // now in [0, 2^32)
+      l[j - 1] += carry;
+   }
+   // l[0] may need more than 53 bits on very large meshes: split it so that every piece converts exactly
+   const long long h = l[0] >> 26;
+   const long long m = l[0] - h * 67108864LL; // [0, 2^26)
+   double s = 0.0;
+#pragma unroll
+   for (int j = kLimbs - 1; j > 0; j--) { s += ldexp((double)l[j], E - 32 * (j + 1)); }
+   s += ldexp((double)m, E - 32);
+   s += ldexp((double)h, E - 32 + 26);
+   return s;
+}
+// 64-bit integer sum over the 64 lanes of a full wavefront (DPP, as wave_sum); the total is returned in every lane
+__device__ __forceinline__ long long wave_sum_i64(long long v)
+{
+#define LGH_I64_STEP(CTRL_, MASK_)                                                                             \
+   {                                                                                                            \
+      const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(v & 0xffffffffLL), CTRL_, MASK_, 0xF, false); \
+      const int hi = __builtin_amdgcn_update_dpp(0, (int)(v >> 32), CTRL_, MASK_, 0xF, false);                   \
+      v += (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo);            \
+   }
+   LGH_I64_STEP(0x111, 0xF) // row_shr:1
+   LGH_I64_STEP(0x112, 0xF) // row_shr:2
+   LGH_I64_STEP(0x114, 0xF) // row_shr:4
+   LGH_I64_STEP(0x118, 0xF) // row_shr:8
+   LGH_I64_STEP(0x142, 0xA) // row_bcast:15 into rows 1 and 3
+   LGH_I64_STEP(0x143, 0xC) // row_bcast:31 into rows 2 and 3
+#undef LGH_I64_STEP
+   const int lo = __builtin_amdgcn_readlane((int)(unsigned)(v & 0xffffffffLL), 63);
+   const int hi = __builtin_amdgcn_readlane((int)(v >> 32), 63);
+   return (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo);
+}
 
 // lgh_vcg_mfma.hip
 bool vcg_mfma_available(lgh_ctx *c);

@@ -145,32 +145,72 @@ static bool slab_swaps_ok(lgh_ctx *c)
    return good;
 }
 
-template <bool SYM, int WPS, bool TRACE, bool WIDE>
-__global__ void __launch_bounds__(256, WPS)
+template <bool SYM, int WPS, int TRACE, bool WIDE, bool EXACT, bool DYN>
+__global__ void __launch_bounds__(256 * WPS, WPS)
 vcg_apply_slab346(const VcgArgs a, const int nset)
 {
    constexpr int D = 4, Q = 6, NQ = Q * Q * Q, ND = D * D * D, QD = Q * D, HB = SYM ? (QD + 1) / 2 : QD;
    constexpr int ES = 5;                     // elements of a set: 15 items on the 16 lanes of a lane group
-   constexpr int NW = 4;                     // wavefronts of a workgroup, each on its own sets
+   constexpr int NW = 4 * WPS;               // wavefronts of the workgroup (one workgroup per CU), each on its own sets: WPS per SIMD
    constexpr int NDMA = (ES * NQ * 8 + 1023) / 1024; // 1 KB LDS-DMA pieces per set of quadrature data (9)
    constexpr int SBUF = NDMA * 128;          // doubles per LDS buffer (the last piece runs past the set's 1080 values)
-   __shared__ double sDall[NW * 2 * SBUF];   // per wave: two buffers (the set being contracted, the set in flight)
+   // per wave two buffers: the set being contracted, the set in flight.  The loop body takes them as __restrict__
+   // pointers: that is what tells the compiler that the LDS-DMA in flight does not write what the body reads - without
+   // it, it waits for ALL outstanding loads (the gathers of the next set) before the first LDS read of an iteration
+   __shared__ double sDa[NW * SBUF], sDb[NW * SBUF];
    __shared__ double red[48];
 
    const int tid = threadIdx.x, lane = tid & 63;
    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6); // wave-uniform: set indices and their base addresses stay in scalar registers
    const int g = lane >> 4, n = lane & 15;
    const int ni = min(n, 14), el = ni / 3, c = ni - 3 * el;
-   double *sD = sDall + wid * (2 * SBUF);
    const int W = gridDim.x * NW;
-   int s = xcd_swizzle(blockIdx.x, gridDim.x) * NW + wid;
+   // The sets of a wavefront.  Static: s, s + W, ... from its place in the grid.  DYN (needs EXACT: the sum must not
+   // depend on who contracts what): the workgroup owns one contiguous range of sets (neighbouring sets share nodes) and
+   // its wavefronts draw them one at a time from a counter in LDS.  Why: the two wavefronts of a SIMD do not run at the
+   // same speed - the older one wins the arbitration for issue slots and memory requests - and with equal shares the
+   // first wavefront of a workgroup leaves its loop at 20 us, the last at 35 us (profiles/r3_k1_slab_*).
+   // Pipeline: set s0 is contracted while the gathers of s1 and the map of s2 are in flight; -1 = no set.
+   __shared__ unsigned s_next;
+   const int wg = xcd_swizzle(blockIdx.x, gridDim.x);
+   const int wg_base = (int)(((long)nset * wg) / gridDim.x), wg_len = (int)(((long)nset * (wg + 1)) / gridDim.x) - wg_base;
+   auto draw = [&]() -> int {
+      unsigned t = 0;
+      if (lane == 0) { t = atomicAdd(&s_next, 1u); }
+      const int ti = (int)__builtin_amdgcn_readfirstlane(t);
+      return (ti < wg_len) ? wg_base + ti : -1;
+   };
+   int s0, s1, s2;
+   if (DYN)
+   {
+      if (tid == 0) { s_next = 0; }
+      __syncthreads();
+      s0 = draw();
+      s1 = draw();
+      s2 = draw();
+   }
+   else
+   {
+      s0 = xcd_swizzle(blockIdx.x, gridDim.x) * NW + wid;
+      s1 = s0 + W;
+      s2 = s0 + 2 * W;
+      if (s0 >= nset) { s0 = -1; }
+   }
+   const int s = (s0 >= 0) ? s0 : 0; // (first set, for the prologue loads)
 
    // No predicates on the loads of the pipeline (as in vcg_apply_plane): sets past the end re-read the last set, elements
    // past the end the last element, and the quadrature data is padded by one set behind its last element (lgh_create);
    // nothing of that is stored or summed.  The loop body is straight-line code.
-   unsigned mo[16]; // byte offsets of this lane's 16 nodes (dx + 4 dy; dz = g) into a node vector
+   unsigned mo[16]; // byte offsets of this lane's 16 nodes (dx + 4 dy; dz = g) into a node vector (WIDE: of the first node of each x-row, mo[4 dy])
    auto load_map = [&](const int ss) {
       const int e = min(ES * min(ss, nset - 1) + el, a.NE - 1);
+      if (WIDE)
+      {
+         const unsigned *p = a.mapb + (size_t)e * ND + 16 * g;
+#pragma unroll
+         for (int dy = 0; dy < 4; dy++) { mo[4 * dy] = p[4 * dy]; }
+         return;
+      }
       const v4u *p = (const v4u *)(a.mapb + (size_t)e * ND + 16 * g);
 #pragma unroll
       for (int dy = 0; dy < 4; dy++)
@@ -238,9 +278,8 @@ vcg_apply_slab346(const VcgArgs a, const int nset)
       }
    };
    // quadrature data of a set: LDS-DMA, 16 bytes per lane and piece, straight into the wave's buffer `buf` (no registers)
-   auto load_dq = [&](const int ss, const int buf) {
+   auto load_dq = [&](const int ss, double *__restrict__ l) {
       const double *p = a.Dq + (size_t)min(ss, nset - 1) * (ES * NQ) + 2 * lane;
-      double *l = sD + buf * SBUF;
 #pragma unroll
       for (int k = 0; k < NDMA; k++)
       {
@@ -255,28 +294,36 @@ vcg_apply_slab346(const VcgArgs a, const int nset)
    };
 
    double dot = 0.0;
+   // EXACT: (d, A d) in integer accumulators (lgh_vcg.hpp): no ticket, no last workgroup; vcg_update_p_k forms the value
+   long long acc[kLimbs] = {0, 0, 0, 0};
+   bool acc_bad = false;
+   const int accE = exact_scale((c == 0) ? a.s->rz[0] : (c == 1) ? a.s->rz[1] : a.s->rz[2]);
    load_gather();
-   load_dq(s, 0);
-   load_map(s + W);
+   load_dq(s, sDa + wid * SBUF);
+   load_map(DYN ? max(s1, 0) : s1);
    __builtin_amdgcn_s_waitcnt(0x0F70);
    convert();
    // debug (LGH_VCG_TRACE): wall-clock stamps of wave 0 and the shader cycles it spends waiting for the loads of a set
    unsigned long long t_start = 0, t_loop = 0, c_wait = 0, c_loop = 0;
    unsigned long long c_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, c_prev = 0; // shader cycles per phase of the loop body (wave 0)
-   if (TRACE) { t_start = wall_clock64(); c_loop = clock64(); c_prev = c_loop; }
-#define LGH_SLAB_STAMP(K_) do { if (TRACE) { const unsigned long long c_now = clock64(); c_ph[K_] += c_now - c_prev; c_prev = c_now; } } while (0)
-   int buf = 0;
-   for (; s < nset; s += W, buf ^= 1)
-   {
-      const int e = ES * s + el;
-      const bool act = (n < 15) && (e < a.NE) && mine;
+   if (TRACE) { t_start = wall_clock64(); }
+   if (TRACE == 2) { c_loop = clock64(); c_prev = c_loop; }
+#define LGH_SLAB_STAMP(K_) do { if (TRACE == 2) { const unsigned long long c_now = clock64(); c_ph[K_] += c_now - c_prev; c_prev = c_now; } } while (0)
+   auto body = [&](const double *__restrict__ sDcur, double *__restrict__ sDnxt) __attribute__((always_inline)) {
+      const int e = ES * max(s0, 0) + el;
+      const bool act = (n < 15) && (e < a.NE) && mine && (!DYN || s0 >= 0);
       const double actf = act ? 1.0 : 0.0;
-      const double *sDp = sD + buf * SBUF + el * NQ + 9 * g; // this lane's nine (qx, qy) pairs: sDp[i + 36 qz]
+      const double *sDp = sDcur + el * NQ + 9 * g; // this lane's nine (qx, qy) pairs: sDp[i + 36 qz]
       // next set: gathers and quadrature data now, the map of the one after
+      // (DYN: an empty pipeline slot - at most three per wavefront, at the end - re-reads set 0: no branch around the
+      // LDS-DMA, or the compiler loses track of what it writes and drains every load before the first LDS read)
       load_gather();
-      load_dq(s + W, buf ^ 1);
-      load_map(s + 2 * W);
+      load_dq(DYN ? max(s1, 0) : s1, sDnxt);
+      load_map(DYN ? max(s2, 0) : s2);
       LGH_SLAB_STAMP(0); // issue of the loads
+      double o[16], dset = 0.0;
+      if (!DYN || s0 >= 0)
+      {
       // Phase order is pinned (sched_barrier): with few wavefronts per SIMD the compiler would otherwise hoist every LDS
       // read and half the next phase above the current one and pay for it in register moves.
       __builtin_amdgcn_sched_barrier(0);
@@ -310,14 +357,16 @@ vcg_apply_slab346(const VcgArgs a, const int nset)
       __builtin_amdgcn_sched_barrier(0);
       LGH_SLAB_STAMP(2); // transpose
       // forward z, quadrature data, (d, A d), backward z; the quadrature data of pair i + 1 is read while pair i is contracted
-      double dset = 0.0;
+      // (one wavefront per SIMD: the data of pair i + 1 is read while pair i is contracted; with two the other wavefront
+      // covers the LDS latency and the 12 registers of the look-ahead are worth more)
+      constexpr bool AHEAD = (WPS == 1);
       double dcur[Q], dnxt[Q];
 #pragma unroll
       for (int qz = 0; qz < Q; qz++) { dcur[qz] = sDp[36 * qz]; }
 #pragma unroll
       for (int i = 0; i < 9; i++)
       {
-         if (i < 8)
+         if (AHEAD && i < 8)
          {
 #pragma unroll
             for (int qz = 0; qz < Q; qz++) { dnxt[qz] = sDp[i + 1 + 36 * qz]; }
@@ -340,8 +389,16 @@ vcg_apply_slab346(const VcgArgs a, const int nset)
             for (int qz = 0; qz < Q; qz++) { u = fma(Bs(qz + Q * dz), cz[qz], u); }
             w[9 * dz + i] = u;
          }
+         if (AHEAD)
+         {
 #pragma unroll
-         for (int qz = 0; qz < Q; qz++) { dcur[qz] = dnxt[qz]; }
+            for (int qz = 0; qz < Q; qz++) { dcur[qz] = dnxt[qz]; }
+         }
+         else if (i < 8)
+         {
+#pragma unroll
+            for (int qz = 0; qz < Q; qz++) { dcur[qz] = sDp[i + 1 + 36 * qz]; }
+         }
          asm volatile("" : "+v"(dset)); // the partial sum exists HERE: left alone, the compiler keeps all 54 factor pairs alive (216 registers) and forms the sum after the loop body
          __builtin_amdgcn_sched_barrier(0);
       }
@@ -351,7 +408,6 @@ vcg_apply_slab346(const VcgArgs a, const int nset)
       __builtin_amdgcn_sched_barrier(0);
       LGH_SLAB_STAMP(4); // transpose back
       // backward y and x, one x-index at a time: t[dy] = sum_qy B[qy,dy] w[qx + 6 qy]; out[dx + 4 dy] += B[qx,dx] t[dy]
-      double o[16];
 #pragma unroll
       for (int qx = 0; qx < Q; qx++)
       {
@@ -375,14 +431,15 @@ vcg_apply_slab346(const VcgArgs a, const int nset)
       // the loads of the next set are complete by now (wave 0 counts what is left of their latency): its direction;
       // the stores of this set go out behind them, so that no wait ever covers a store that has just been issued
       LGH_SLAB_STAMP(5); // backward y, x
-      if (TRACE)
+      } // (s0)
+      if (TRACE == 2)
       {
          const unsigned long long c0 = clock64();
          __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
          c_wait += clock64() - c0;
       }
-      __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): gathers, LDS-DMA and map of the next set
-      convert();
+      __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): gathers, LDS-DMA and map of the next set (and the ticket)
+      if (!DYN || s1 >= 0) { convert(); }
       __builtin_amdgcn_sched_barrier(0);
       LGH_SLAB_STAMP(6); // wait + direction of the next set
       // the slab of the E-vector: 16 contiguous doubles
@@ -393,9 +450,119 @@ vcg_apply_slab346(const VcgArgs a, const int nset)
          for (int dy = 0; dy < D; dy++) { *(v4d *)(yc + 4 * dy) = v4d{o[4 * dy], o[4 * dy + 1], o[4 * dy + 2], o[4 * dy + 3]}; }
       }
       LGH_SLAB_STAMP(7); // stores
-      dot = fma(dset, actf, dot); // (a select would let the compiler sink all 54 products of dset behind the branch: 216 live registers)
+      // (a select would let the compiler sink all 54 products of dset behind the branch: 216 live registers)
+      if (EXACT) { acc_bad = acc_bad || !exact_add(acc, dset * actf, accE); }
+      else { dot = fma(dset, actf, dot); }
+      // the pipeline moves on
+      if (DYN)
+      {
+         s0 = s1;
+         s1 = s2;
+         s2 = draw();
+      }
+      else
+      {
+         s0 = (s1 < nset) ? s1 : -1;
+         s1 = s2;
+         s2 += W;
+      }
+   };
+   auto more = [&]() -> bool { return DYN ? (s0 >= 0 || s1 >= 0 || s2 >= 0) : (s0 >= 0); };
+   double *bcur = sDa + wid * SBUF, *bnxt = sDb + wid * SBUF;
+   while (more())
+   {
+      body(bcur, bnxt);
+      double *const tmp = bcur;
+      bcur = bnxt;
+      bnxt = tmp;
    }
-   if (TRACE) { t_loop = wall_clock64(); c_loop = clock64() - c_loop; }
+   if (TRACE) { t_loop = wall_clock64(); }
+   if (TRACE == 2) { c_loop = clock64() - c_loop; }
+   if (EXACT)
+   {
+      // integer sums over the workgroup, then kVC * kLimbs fire-and-forget atomics into this workgroup's shard
+      __shared__ long long redi[NW][kVC * kLimbs];
+      __shared__ int redbad[NW];
+#pragma unroll
+      for (int k = 0; k < kVC; k++)
+      {
+#pragma unroll
+         for (int j = 0; j < kLimbs; j++)
+         {
+            const long long tot = wave_sum_i64((c == k && n < 15) ? acc[j] : 0LL);
+            if (lane == 0) { redi[wid][kLimbs * k + j] = tot; }
+         }
+      }
+      const bool anybad = __any(acc_bad && n < 15 && mine);
+      if (lane == 0) { redbad[wid] = anybad ? 1 : 0; }
+      __syncthreads();
+      long long *L = a.limbs;
+      __shared__ unsigned int s_last;
+      if (tid < kVC * kLimbs)
+      {
+         long long sum = 0;
+#pragma unroll
+         for (int w = 0; w < NW; w++) { sum += redi[w][tid]; }
+         if (sum != 0) { (void)__hip_atomic_fetch_add(&L[(blockIdx.x % kLimbShards) * (kVC * kLimbs) + tid], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+      }
+      if (tid == kVC * kLimbs)
+      {
+         int bad = 0;
+#pragma unroll
+         for (int w = 0; w < NW; w++) { bad |= redbad[w]; }
+         if (bad) { (void)__hip_atomic_fetch_or(&L[kLimbShards * kVC * kLimbs], 1LL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the atomics have been performed (gfx9: vmcnt counts them) ...
+      __syncthreads();
+      if (tid == 0)
+      {
+         // ... before this workgroup is counted.  Only the count needs a returning atomic; whoever is last reads the
+         // accumulators (a dozen words, not one partial per workgroup), leaves them cleared and commits the result.
+         unsigned int *tk = a.ticket + kShards * kTicketStride;
+         const unsigned arrived = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+         s_last = (arrived == gridDim.x - 1) ? 1u : 0u;
+         if (s_last) { __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+      }
+      __syncthreads();
+      if (s_last && tid < kVC)
+      {
+         long long l4[kLimbs] = {0, 0, 0, 0};
+#pragma unroll
+         for (int sh = 0; sh < kLimbShards; sh++)
+         {
+#pragma unroll
+            for (int j = 0; j < kLimbs; j++)
+            {
+               long long *w = &L[sh * (kVC * kLimbs) + kLimbs * tid + j];
+               l4[j] += __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+               __hip_atomic_store(w, 0LL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+         }
+         const long long bad = __hip_atomic_load(&L[kLimbShards * kVC * kLimbs], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+         VcgScalars *sc = a.s;
+         const bool td = (tid == 0) ? todo[0] : (tid == 1) ? todo[1] : todo[2];
+         if (td)
+         {
+            const double den = bad ? __builtin_nan("") : exact_value(l4, exact_scale(sc->rz[tid]));
+            sc->den[tid] = den;
+            if (den == 0.0 && !a.multi) { sc->done[tid] = 1; } // breakdown, as upstream
+         }
+         if (tid == 0)
+         {
+            sc->first = 0;
+            if (bad) { __hip_atomic_store(&L[kLimbShards * kVC * kLimbs], 0LL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+         }
+      }
+      if (TRACE && tid == 0)
+      {
+         a.trace[kTraceRec * blockIdx.x + 0] = t_start;
+         a.trace[kTraceRec * blockIdx.x + 1] = t_loop;
+         a.trace[kTraceRec * blockIdx.x + 2] = wall_clock64();
+         a.trace[kTraceRec * blockIdx.x + 3] = (c_wait << 32) | (c_loop & 0xffffffffull);
+         for (int k = 0; k < 8; k++) { a.trace[kTraceRec * blockIdx.x + 4 + k] = c_ph[k]; }
+      }
+      return;
+   }
    double bp[kVC];
    block_sum3(c == 0 ? dot : 0.0, c == 1 ? dot : 0.0, c == 2 ? dot : 0.0, red, bp);
    double total[kVC];
@@ -432,23 +599,27 @@ bool vcg_slab_available(lgh_ctx *c)
 
 void launch_vcg_slab(lgh_ctx *c, const VcgArgs &a)
 {
-   static int ncu = 0, wps = 0;
+   static int ncu = 0;
    if (ncu == 0)
    {
       hipDeviceProp_t prop;
       ncu = (hipGetDeviceProperties(&prop, c->device) == hipSuccess) ? prop.multiProcessorCount : 256;
-      const char *env = getenv("LGH_SLAB_WPS"); // A/B: workgroups (of four wavefronts) per CU
-      wps = (env && env[0] == '2') ? 2 : 1;
    }
+   const int wps = c->slab_wps; // wavefronts per SIMD (workgroup of 256 or 512 threads, one per CU)
    const int nset = ceil_div(c->NE, 5);
-   const int grid = std::min(ceil_div(nset, 4), wps * ncu);
-   static const bool wide_env = !(getenv("LGH_SLAB_WIDE") && getenv("LGH_SLAB_WIDE")[0] == '0'); // A/B
-   const bool wide = wide_env && a.map_xrows != 0;
-#define LGH_SLAB_LAUNCH(SYM_, WPS_, TR_, WIDE_) hipLaunchKernelGGL((vcg_apply_slab346<SYM_, WPS_, TR_, WIDE_>), dim3(grid), dim3(256), 0, c->stream, a, nset)
-#define LGH_SLAB_LAUNCH2(SYM_, WPS_, TR_) do { if (wide) { LGH_SLAB_LAUNCH(SYM_, WPS_, TR_, true); } else { LGH_SLAB_LAUNCH(SYM_, WPS_, TR_, false); } } while (0)
-   if (a.trace) { if (wps == 2) { LGH_SLAB_LAUNCH2(true, 2, true); } else { LGH_SLAB_LAUNCH2(true, 1, true); } } // debug (LGH_VCG_TRACE): per-phase cycle counters
-   else if (wps == 2) { if (c->b_h1_sym) { LGH_SLAB_LAUNCH2(true, 2, false); } else { LGH_SLAB_LAUNCH2(false, 2, false); } }
-   else { if (c->b_h1_sym) { LGH_SLAB_LAUNCH2(true, 1, false); } else { LGH_SLAB_LAUNCH2(false, 1, false); } }
+   const int grid = std::min(ceil_div(nset, 4 * wps), ncu); // one workgroup of 4 wps wavefronts per CU
+   const bool wide = c->slab_wide && a.map_xrows != 0;
+   const bool exact = a.limbs != nullptr;
+   const bool dyn = exact && c->slab_dyn;
+#define LGH_SLAB_LAUNCH(SYM_, WPS_, TR_, WIDE_, EX_, DYN_) hipLaunchKernelGGL((vcg_apply_slab346<SYM_, WPS_, TR_, WIDE_, EX_, DYN_>), dim3(grid), dim3(256 * WPS_), 0, c->stream, a, nset)
+#define LGH_SLAB_LAUNCH2(SYM_, WPS_, TR_) do { if (wide && dyn) { LGH_SLAB_LAUNCH(SYM_, WPS_, TR_, true, true, true); } else if (wide && exact) { LGH_SLAB_LAUNCH(SYM_, WPS_, TR_, true, true, false); } \
+                                               else if (wide) { LGH_SLAB_LAUNCH(SYM_, WPS_, TR_, true, false, false); } \
+                                               else if (exact) { LGH_SLAB_LAUNCH(SYM_, WPS_, TR_, false, true, false); } else { LGH_SLAB_LAUNCH(SYM_, WPS_, TR_, false, false, false); } } while (0)
+   static const bool trace_full = getenv("LGH_VCG_TRACE_PHASES") != nullptr; // per-phase cycle counters as well (more registers: not the shipped schedule)
+   if (a.trace && trace_full) { if (wps == 2) { LGH_SLAB_LAUNCH2(true, 2, 2); } else { LGH_SLAB_LAUNCH2(true, 1, 2); } }
+   else if (a.trace) { if (wps == 2) { LGH_SLAB_LAUNCH2(true, 2, 1); } else { LGH_SLAB_LAUNCH2(true, 1, 1); } } // debug (LGH_VCG_TRACE): wall-clock stamps per workgroup
+   else if (wps == 2) { if (c->b_h1_sym) { LGH_SLAB_LAUNCH2(true, 2, 0); } else { LGH_SLAB_LAUNCH2(false, 2, 0); } }
+   else { if (c->b_h1_sym) { LGH_SLAB_LAUNCH2(true, 1, 0); } else { LGH_SLAB_LAUNCH2(false, 1, 0); } }
 #undef LGH_SLAB_LAUNCH2
 #undef LGH_SLAB_LAUNCH
 }

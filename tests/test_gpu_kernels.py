@@ -456,6 +456,57 @@ def test_lockstep_k1_forms_agree_at_q3q2(mesh, rs, monkeypatch):
         assert rel_err(dS[H1V:2 * H1V], dS_o[H1V:2 * H1V]) < 1e-10, variant
 
 
+SLAB_SWITCHES = [
+    {"LGH_SLAB_WPS": "1"},
+    {"LGH_SLAB_WPS": "2"},
+    {"LGH_SLAB_DYN": "0"},
+    {"LGH_SLAB_EXACT": "0"},
+    {"LGH_SLAB_WIDE": "0"},
+    {"LGH_SLAB_WPS": "1", "LGH_SLAB_WIDE": "0", "LGH_SLAB_DYN": "0"},
+]
+
+
+@pytest.mark.parametrize("switches", SLAB_SWITCHES, ids=lambda d: ",".join(f"{k[9:]}={v}" for k, v in d.items()))
+def test_slab_k1_switches(switches, monkeypatch):
+    """Every A/B switch of the slab-form K1 (lgh_vcg_slab.hip) selects a different instantiation: one or two wavefronts
+    per SIMD, row loads or node gathers, exact integer accumulation of (d, A d) or the ticketed fold, sets drawn from
+    the workgroup's queue or assigned statically.  128 zones (26 sets: a ragged last set),
+    distorted state, CG to 1e-14: the velocity part of dS/dt agrees with the oracle to the operator tolerance, and -
+    the sum being exact - the two schedules with exact accumulation give the same bits."""
+    from oracle.fem import Problem
+    prob = Problem(mesh="box01_hex", rs=1, order_v=3, order_e=2, problem=1)
+    S = deformed_state(prob, seed=39)
+    o = make_oracle(prob)
+    try:
+        o.cg_tol = 1e-14
+        dS_o = np.empty_like(S)
+        o.qdata_is_current = False
+        o.mult(S, dS_o)
+    finally:
+        o.close()
+    H1V = prob.H1V
+    monkeypatch.setenv("LGH_VCG_VARIANT", "4")
+    for k, v in switches.items():
+        monkeypatch.setenv(k, v)
+    g = make_gpu(prob)
+    try:
+        assert g.ctx.k1_form() == "slab"
+        g.cg_tol = 1e-14
+        Sd = g.ctx.to_dev(S)
+        dS = g.ctx.zeros(S.size)
+        g.reset_quadrature_data()
+        g.mult(Sd, dS)
+        g.ctx.sync()
+        dS = dS.cpu().numpy()
+    finally:
+        g.close()
+    assert rel_err(dS[H1V:2 * H1V], dS_o[H1V:2 * H1V]) < 1e-10
+    if "LGH_SLAB_EXACT" not in switches:
+        key = "slab_exact_bits"
+        ref = test_slab_k1_switches.__dict__.setdefault(key, dS[H1V:2 * H1V].copy())
+        assert np.array_equal(ref, dS[H1V:2 * H1V]), "exact accumulation: the result must not depend on the schedule"
+
+
 @pytest.mark.parametrize("order", [(3, 2), (4, 3)], ids=["Q3Q2", "Q4Q3"])
 def test_mass_kernels_without_table_symmetry(order, monkeypatch):
     """LGH_B_SYM=0: lgh_create treats the 1-D tables as not mirror symmetric, as it would for a basis on asymmetric
