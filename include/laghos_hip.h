@@ -129,17 +129,35 @@ int lgh_qupdate(lgh_ctx *ctx, const double *S);
 int lgh_qupdate_set_tiny_grad(lgh_ctx *ctx, double tiny_grad);
 /* lgh_qupdate also forms the two force products of the state it is called for - F.1 as E-vector (3D) and
  * F^T v for the state's own velocity - from the stress values it has in registers; lgh_solve_velocity and
- * lgh_solve_energy use them instead of a pass over stressJinvT each when they are called for that state (and
- * lgh_solve_energy with that velocity; `one_l2` is checked to be all ones).  on = 0 switches that off: the
- * force products then always come from the ForcePAOperator kernels (per-kernel timing, A/B).  Default on. */
+ * lgh_solve_energy use them instead of a pass over stressJinvT each.  When they are used (no address is ever
+ * compared):
+ *   - both products belong to the quadrature data as lgh_qupdate left it: lgh_reset_quadrature_data, a set-up
+ *     call, lgh_set_fused_forces and handing out the mutable lgh_qdata_stressJinvT pointer all discard them;
+ *   - F.1 only for the all-ones L2 function (one_l2 == NULL, or a vector that is checked on that call);
+ *   - F^T v only for a v whose every element equals the velocity block lgh_qupdate saw (a copy is kept and
+ *     compared on the device inside lgh_solve_energy; any other v runs ForceMultTranspose, as
+ *     laghos_solver.cpp:473 does for whatever v it is given).
+ * on = 0 switches the fusion off: the products then always come from the ForcePAOperator kernels (per-kernel
+ * timing, A/B).  Default on. */
 int lgh_set_fused_forces(lgh_ctx *ctx, int on);
+/* ResetQuadratureData (laghos_solver.hpp: qdata_is_current = false): the state has changed, the quadrature data -
+ * and the force products formed with it - are stale.  The shells call it wherever the reference does. */
+int lgh_reset_quadrature_data(lgh_ctx *ctx);
+/* The two fused products as vectors, for callers (and tests) that want ForcePA->Mult(one) / MultTranspose(v_state)
+ * of the current quadrature data without another pass over it: F.1 summed to the H1 L-vector (dim*N), F^T v as
+ * L2 vector.  LGH_ERR_ARG when the product is not on hand. */
+int lgh_fused_force_mult(lgh_ctx *ctx, double *y_h1);
+int lgh_fused_force_mult_transpose(lgh_ctx *ctx, double *y_l2);
+/* *gen counts lgh_qupdate calls and invalidations; *f1_valid / *ftv_valid: a fused F.1 / F^T v is on hand (tests). */
+int lgh_quadrature_generation(lgh_ctx *ctx, unsigned long *gen, int *f1_valid, int *ftv_valid);
 /* *f1 / *ftv = 1 when lgh_qupdate forms F.1 / F^T v (what the region timers then see: the "Forces" region of
  * lgh_get_timers only holds the E->L sum and right-hand-side set-up, the products are inside "UpdateQuadData") */
 int lgh_get_fused_forces(lgh_ctx *ctx, int *f1, int *ftv);
 
 /* ---- LagrangianHydroOperator pieces kept together for launch efficiency
  * (laghos_solver.cpp:329-399, :442-490).  dS_dt = [dx|dv|de]; one_l2 is the
- * constant-one L2 vector (laghos_solver.cpp:170-171); rhs_h1 / e_rhs / work are
+ * constant-one L2 vector (laghos_solver.cpp:170-171) or NULL for the operator's own (the reference's
+ * SolveVelocity takes none: it is a member); rhs_h1 / e_rhs / work are
  * caller scratch (dim*N, L2 size, N).  e_source may be NULL.
  * *h1_iters / *l2_iters accumulate CG iteration counts (timer.H1iter, L2iter). */
 int lgh_solve_velocity(lgh_ctx *ctx, const double *S, double *dS_dt, const double *one_l2,

@@ -89,6 +89,10 @@ SYMBOLS = {
     "lgh_k1_form": (_I, [_P, c_int_p]),
     "lgh_qupdate_set_tiny_grad": (_I, [_P, _D]),
     "lgh_set_fused_forces": (_I, [_P, _I]),
+    "lgh_reset_quadrature_data": (_I, [_P]),
+    "lgh_fused_force_mult": (_I, [_P, _P]),
+    "lgh_fused_force_mult_transpose": (_I, [_P, _P]),
+    "lgh_quadrature_generation": (_I, [_P, ctypes.POINTER(ctypes.c_ulong), c_int_p, c_int_p]),
     "lgh_get_fused_forces": (_I, [_P, c_int_p, c_int_p]),
     "lgh_comm_unique_id": (_I, [ctypes.c_char_p]),
     "lgh_comm_init": (_I, [_P, _I, _I, ctypes.c_char_p]),

@@ -233,9 +233,29 @@ class Context:
         check(self.lib.lgh_k1_form(self.h, ctypes.byref(f)))
         return {0: "column", 2: "plane", 3: "mfma", 4: "slab"}.get(f.value)
 
+    def set_fused_forces(self, on):
+        check(self.lib.lgh_set_fused_forces(self.h, 1 if on else 0))
+
+    def reset_quadrature_data(self):
+        check(self.lib.lgh_reset_quadrature_data(self.h))
+
+    def fused_force_mult(self, y_h1):
+        """F.1 formed by the last qupdate, summed to the H1 L-vector; False when it is not on hand"""
+        return self.lib.lgh_fused_force_mult(self.h, _ptr(y_h1)) == 0
+
+    def fused_force_mult_transpose(self, y_l2):
+        return self.lib.lgh_fused_force_mult_transpose(self.h, _ptr(y_l2)) == 0
+
+    def quadrature_generation(self):
+        """(generation, fused F.1 on hand, fused F^T v on hand)"""
+        g, a, b = ctypes.c_ulong(0), ctypes.c_int(-1), ctypes.c_int(-1)
+        check(self.lib.lgh_quadrature_generation(self.h, ctypes.byref(g), ctypes.byref(a), ctypes.byref(b)))
+        return g.value, a.value, b.value
+
     def solve_velocity(self, S, dS, one, rhs, work, rel_tol, max_iter):
+        """one = None: the operator's own constant-one vector (laghos_solver.cpp:170-171)"""
         it = ctypes.c_int(0)
-        check(self.lib.lgh_solve_velocity(self.h, _ptr(S), _ptr(dS), _ptr(one), _ptr(rhs), _ptr(work),
+        check(self.lib.lgh_solve_velocity(self.h, _ptr(S), _ptr(dS), _ptr(one) if one is not None else None, _ptr(rhs), _ptr(work),
                                           rel_tol, max_iter, ctypes.byref(it)))
         return it.value
 

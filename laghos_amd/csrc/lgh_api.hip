@@ -346,7 +346,12 @@ static int create_impl(const lgh_config *cfg, lgh_ctx *c, const int kid)
    LGH_TRY(dev_alloc_zero(&c->dt_est_dev, 1));
    {
       const char *env = getenv("LGH_FUSED_FTV"); // A/B: 0 = F^T v always by its own kernel
-      if (!(env && env[0] == '0')) { LGH_TRY(dev_alloc_zero(&c->erhs_q, (size_t)c->L2V)); }
+      if (!(env && env[0] == '0'))
+      {
+         LGH_TRY(dev_alloc_zero(&c->erhs_q, (size_t)c->L2V));
+         LGH_TRY(dev_alloc_zero(&c->v_snap, (size_t)c->H1V));
+      }
+      LGH_TRY(dev_alloc_zero(&c->dev_flags, (size_t)4));
       env = getenv("LGH_FUSED_F1");              // A/B: 0 = F.1 always by its own kernel
       if (c->dim == 3 && !(env && env[0] == '0')) { LGH_TRY(dev_alloc_zero(&c->force_e_q, nmap * dim + (size_t)dim * c->ND)); } // (+ a zero element: vcg_init_force_z_k)
    }
@@ -381,7 +386,7 @@ int lgh_destroy(lgh_ctx *c)
    void *ptrs[] = {c->B, c->G, c->Bl, c->W, c->gamma, c->h1map, c->t_off, c->t_idx, c->t_ell, c->essmask[0],
                    c->essmask[1], c->essmask[2], c->ess[0], c->ess[1], c->ess[2], c->owner,
                    c->stressJinvT, c->Jac0inv, c->Jac0inv_soa, c->rho0DetJ0w, c->massD, c->diagV, c->dinvV,
-                   c->dt_est_dev, c->erhs_q, c->force_e_q, c->XE, c->YE, c->cg_r, c->cg_z, c->cg_d0, c->cg_d1, c->cg_y,
+                   c->dt_est_dev, c->erhs_q, c->v_snap, c->dev_flags, c->ones_l2, c->force_e_q, c->XE, c->YE, c->cg_r, c->cg_z, c->cg_d0, c->cg_d1, c->cg_y,
                    c->partials, c->tickets, c->cgs, c->scal, c->vcg_s, c->vcg_vec, c->vcg_partials,
                    c->vcg_tickets};
    for (void *p : ptrs) { if (p) { (void)hipFree(p); } }
@@ -418,12 +423,49 @@ int lgh_sync(lgh_ctx *c)
 }
 void *lgh_stream(lgh_ctx *c) { return c ? (void *)c->stream : nullptr; }
 
+static void invalidate_fused(lgh_ctx *c)
+{
+   c->fused_ftv_valid = 0;
+   c->fused_f1_valid = 0;
+   c->qgen++;
+}
 double *lgh_qdata_stressJinvT(lgh_ctx *c)
 {
    // the caller may write through this pointer: F^T v and F.1 of the fused update no longer belong to it
-   c->force_e_state = nullptr;
-   c->erhs_state = nullptr;
+   invalidate_fused(c);
    return c->stressJinvT;
+}
+int lgh_reset_quadrature_data(lgh_ctx *c)
+{
+   LGH_CHECK_ARG(c);
+   invalidate_fused(c);
+   return LGH_OK;
+}
+// The force products of the last lgh_qupdate as vectors: F.1 summed to the H1 L-vector (what SolveVelocity negates into
+// its right-hand side), F^T v_state as L2 vector.  LGH_ERR_ARG when the product is not on hand (fusion off, 2D for
+// F.1, quadrature data changed since).
+int lgh_fused_force_mult(lgh_ctx *c, double *y_h1)
+{
+   LGH_CHECK_ARG(c && y_h1);
+   if (!(c->force_e_q && c->fused_f1_valid)) { set_error("lgh_fused_force_mult: no fused F.1 on hand"); return LGH_ERR_ARG; }
+   int rc = h1_transpose_gather(c, c->dim, c->force_e_q, y_h1);
+   if (rc == LGH_OK && c->multi != 0) { rc = halo_sum(c, y_h1, c->dim); }
+   return rc;
+}
+int lgh_fused_force_mult_transpose(lgh_ctx *c, double *y_l2)
+{
+   LGH_CHECK_ARG(c && y_l2);
+   if (!(c->erhs_q && c->fused_ftv_valid)) { set_error("lgh_fused_force_mult_transpose: no fused F^T v on hand"); return LGH_ERR_ARG; }
+   LGH_HIP_CHECK(hipMemcpyAsync(y_l2, c->erhs_q, sizeof(double) * (size_t)c->L2V, hipMemcpyDeviceToDevice, c->stream));
+   return LGH_OK;
+}
+int lgh_quadrature_generation(lgh_ctx *c, unsigned long *gen, int *f1_valid, int *ftv_valid)
+{
+   LGH_CHECK_ARG(c && gen && f1_valid && ftv_valid);
+   *gen = c->qgen;
+   *f1_valid = c->fused_f1_valid;
+   *ftv_valid = c->fused_ftv_valid;
+   return LGH_OK;
 }
 double *lgh_qdata_Jac0inv(lgh_ctx *c) { return c->Jac0inv; }
 double *lgh_qdata_rho0DetJ0w(lgh_ctx *c) { return c->rho0DetJ0w; }
@@ -452,6 +494,7 @@ int lgh_setup_rho0detj0(lgh_ctx *c, const double *x0, const double *rho0_l2, con
                         double *volume)
 {
    LGH_CHECK_ARG(c && x0 && rho0_l2 && rho0_q && volume);
+   invalidate_fused(c);
    int rc = setup_rho0detj0(c, x0, rho0_l2, rho0_q, volume);
    if (rc) { return rc; }
    return mass_assemble_diag(c);
@@ -522,8 +565,9 @@ int lgh_qupdate(lgh_ctx *c, const double *S)
 }
 
 // The fused update forms F.1 for the constant-one L2 function, which is what SolveVelocity passes
-// (laghos_solver.cpp:170-171, :354).  The C ABI takes the vector as an argument, so it is checked once per
-// pointer that it really is all ones before the fused result is used in its place.
+// (laghos_solver.cpp:170-171, :354).  one_l2 == NULL means exactly that - the operator's own `one`, as in the
+// reference, whose SolveVelocity takes no such argument - and costs nothing.  A vector passed explicitly is checked
+// on every call (a pass over it and a host look): nothing is remembered about an address.
 __global__ void __launch_bounds__(256) not_all_ones_k(const double *x, const long n, int *flag)
 {
    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -531,15 +575,27 @@ __global__ void __launch_bounds__(256) not_all_ones_k(const double *x, const lon
 }
 static bool is_the_one_vector(lgh_ctx *c, const double *one_l2)
 {
-   if (c->one_checked == one_l2) { return true; }
-   int *flag = (int *)c->scal; // 16 doubles of device scratch
+   if (!one_l2) { return true; }
+   int *flag = c->dev_flags + 1;
    if (hipMemsetAsync(flag, 0, sizeof(int), c->stream) != hipSuccess) { return false; }
    hipLaunchKernelGGL(not_all_ones_k, dim3(ceil_div(c->L2V, 256)), dim3(256), 0, c->stream, one_l2, (long)c->L2V, flag);
    int h = 1;
    if (hipMemcpyAsync(&h, flag, sizeof(int), hipMemcpyDeviceToHost, c->stream) != hipSuccess) { return false; }
    if (hipStreamSynchronize(c->stream) != hipSuccess) { return false; }
-   if (h == 0) { c->one_checked = one_l2; }
    return h == 0;
+}
+// the vector ForcePA->Mult is applied to when the kernel has to run: the caller's, or the context's own ones
+static int one_vector(lgh_ctx *c, const double *one_l2, const double **out)
+{
+   if (one_l2) { *out = one_l2; return LGH_OK; }
+   if (!c->ones_l2)
+   {
+      LGH_HIP_CHECK(hipMalloc((void **)&c->ones_l2, sizeof(double) * (size_t)c->L2V));
+      const int rc = vec_set(c, c->ones_l2, 1.0, c->L2V);
+      if (rc) { return rc; }
+   }
+   *out = c->ones_l2;
+   return LGH_OK;
 }
 
 // SolveVelocity, PA branch without acceleration source (laghos_solver.cpp:329-399).
@@ -547,7 +603,7 @@ static bool is_the_one_vector(lgh_ctx *c, const double *one_l2)
 int lgh_solve_velocity(lgh_ctx *c, const double *S, double *dS_dt, const double *one_l2,
                        double *rhs_h1, double *work_B, double rel_tol, int max_iter, int *h1_iters)
 {
-   LGH_CHECK_ARG(c && S && dS_dt && one_l2 && rhs_h1 && work_B);
+   LGH_CHECK_ARG(c && S && dS_dt && rhs_h1 && work_B);
    const int dim = c->dim, N = c->N;
    double *dv = dS_dt + c->H1V;
    int rc;
@@ -558,11 +614,14 @@ int lgh_solve_velocity(lgh_ctx *c, const double *S, double *dS_dt, const double 
    {
       // F.1 up to the E-vector (:354): formed by the fused update for this very state, or by the force kernel
       const double *force_E = c->YE;
-      if (c->force_e_q && c->force_e_state == S && is_the_one_vector(c, one_l2)) { force_E = c->force_e_q; }
+      if (c->force_e_q && c->fused_f1_valid && is_the_one_vector(c, one_l2)) { force_E = c->force_e_q; }
       else
       {
+         const double *ones = nullptr;
+         rc = one_vector(c, one_l2, &ones);
+         if (rc) { return rc; }
          kt_begin(c, LGH_KERNEL_FORCE_MULT);
-         rc = force_mult_E(c, c->stressJinvT, one_l2, c->YE);
+         rc = force_mult_E(c, c->stressJinvT, ones, c->YE);
          kt_end(c, LGH_KERNEL_FORCE_MULT);
          if (rc) { return rc; }
       }
@@ -580,14 +639,19 @@ int lgh_solve_velocity(lgh_ctx *c, const double *S, double *dS_dt, const double 
    rc = vec_set(c, dv, 0.0, c->H1V); // dv = 0.0 (:338)
    if (rc) { return rc; }
    timer_start(c);
-   if (c->force_e_q && c->force_e_state == S && is_the_one_vector(c, one_l2))
+   if (c->force_e_q && c->fused_f1_valid && is_the_one_vector(c, one_l2))
    {
       // F.1 of this state from the fused update: only H1R^T (and the sum over the ranks) is left of :354, and
       // the right-hand side has the bits of the fused-init path above
       rc = h1_transpose_gather(c, c->dim, c->force_e_q, rhs_h1);
       if (rc == LGH_OK && c->multi != 0) { rc = halo_sum(c, rhs_h1, c->dim); }
    }
-   else { rc = lgh_force_mult(c, one_l2, rhs_h1); } // :354
+   else
+   {
+      const double *ones = nullptr;
+      rc = one_vector(c, one_l2, &ones);
+      if (rc == LGH_OK) { rc = lgh_force_mult(c, ones, rhs_h1); } // :354
+   }
    timer_stop(c, 2);
    if (rc) { return rc; }
    rc = vec_neg_inplace(c, rhs_h1, c->H1V); // :358
@@ -647,14 +711,35 @@ int lgh_solve_velocity(lgh_ctx *c, const double *S, double *dS_dt, const double 
    return LGH_OK;
 }
 
-// ForcePA->MultTranspose(v, e_rhs) of SolveEnergy (laghos_solver.cpp:473).  When v is the velocity block of
-// the state the quadrature data was last updated for, the fused QUpdate has already formed it (one pass over
-// the 9 stressJinvT planes less per stage); any other v - RK2Avg's averaged velocity - goes through the kernel.
+// ForcePA->MultTranspose(v, e_rhs) of SolveEnergy (laghos_solver.cpp:473).  The fused QUpdate has formed F^T v for the
+// velocity of the state it was called for; it stands in for the kernel exactly when the quadrature data is still that
+// of this update AND the v passed now equals that velocity element for element - compared on the device, whatever the
+// address (RK2Avg's averaged velocity, or a state changed in place since, go through the kernel, as in the reference).
+// No host look: the comparison leaves a flag, the force kernel returns at once when it is 0, the copy when it is not.
+__global__ void __launch_bounds__(256) vec_differs_k(const double *__restrict__ a, const double *__restrict__ b, const long n, int *flag)
+{
+   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+   // (compared as bit patterns: -0.0 vs 0.0 or a NaN payload count as different - the kernel then simply runs)
+   if (i < n && __double_as_longlong(a[i]) != __double_as_longlong(b[i])) { *flag = 1; }
+}
+__global__ void __launch_bounds__(256) copy_unless_k(double *__restrict__ y, const double *__restrict__ x, const long n, const int *__restrict__ flag)
+{
+   if (*flag != 0) { return; }
+   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+   if (i < n) { y[i] = x[i]; }
+}
 static int energy_rhs(lgh_ctx *c, const double *v_h1, double *e_rhs)
 {
-   if (c->erhs_q && c->erhs_state && v_h1 == c->erhs_state + c->H1V)
+   if (c->erhs_q && c->fused_ftv_valid)
    {
-      LGH_HIP_CHECK(hipMemcpyAsync(e_rhs, c->erhs_q, sizeof(double) * (size_t)c->L2V, hipMemcpyDeviceToDevice, c->stream));
+      int *flag = c->dev_flags + (c->on_stream2 ? 2 : 0);
+      LGH_HIP_CHECK(hipMemsetAsync(flag, 0, sizeof(int), c->stream));
+      hipLaunchKernelGGL(vec_differs_k, dim3(ceil_div(c->H1V, 256)), dim3(256), 0, c->stream, v_h1, c->v_snap, (long)c->H1V, flag);
+      LGH_HIP_CHECK(hipGetLastError());
+      const int rc = force_mult_t_L(c, c->stressJinvT, v_h1, e_rhs, flag); // (runs only for a different v)
+      if (rc) { return rc; }
+      hipLaunchKernelGGL(copy_unless_k, dim3(ceil_div(c->L2V, 256)), dim3(256), 0, c->stream, e_rhs, c->erhs_q, (long)c->L2V, flag);
+      LGH_HIP_CHECK(hipGetLastError());
       return LGH_OK;
    }
    return lgh_force_mult_transpose(c, v_h1, e_rhs);
@@ -863,8 +948,7 @@ int lgh_set_fused_forces(lgh_ctx *c, int on)
 {
    LGH_CHECK_ARG(c);
    c->fused_forces_off = on ? 0 : 1;
-   c->force_e_state = nullptr;
-   c->erhs_state = nullptr;
+   invalidate_fused(c);
    return LGH_OK;
 }
 

@@ -112,11 +112,17 @@ struct lgh_ctx
    double *stressJinvT, *Jac0inv, *rho0DetJ0w, *massD, *diagV, *dinvV;
    double *Jac0inv_soa;  // plane-major copy of Jac0inv for coalesced reads in QUpdate
    double *dt_est_dev;   // 1 double: running min of the point-wise estimate
-   double *erhs_q;       // L2V: F^T v formed inside the fused QUpdate for the velocity block of ...
-   const double *erhs_state; // ... this state vector (the S of the last lgh_qupdate), or nullptr
-   double *force_e_q;    // NE*ND*dim: F.1 as E-vector formed inside the fused QUpdate (3D) for ...
-   const double *force_e_state; // ... this state vector, or nullptr
-   const double *one_checked;   // the caller's `one` L2 vector that has been verified to be all ones
+   // Force products formed inside the fused QUpdate.  Validity is by construction, not by address: `fused_*_valid` says
+   // that the product belongs to the quadrature data as it stands (set by lgh_qupdate, cleared by everything that can
+   // change stressJinvT: lgh_reset_quadrature_data, lgh_qdata_stressJinvT, lgh_set_fused_forces, the set-up), and
+   // F^T v is only used for a velocity that compares equal, element for element, to the one it was formed from.
+   double *erhs_q;       // L2V: F^T v of ...
+   double *v_snap;       // ... H1V: the velocity block of the state of the last lgh_qupdate (copy)
+   double *force_e_q;    // NE*ND*dim: F.1 as E-vector (3D)
+   int fused_ftv_valid, fused_f1_valid;
+   unsigned long qgen;   // counts lgh_qupdate / invalidations (lgh_quadrature_generation)
+   int *dev_flags;       // 4 device ints: [0] "v differs from v_snap" of the current lgh_solve_energy
+   double *ones_l2;      // L2V ones: the operator's own `one` (laghos_solver.cpp:170-171), allocated on first use
    int fused_forces_off;        // lgh_set_fused_forces(ctx, 0): the update forms no force products (measurement / A-B)
    // scratch
    double *XE;           // max(L2V, NE*ND*dim)
@@ -396,7 +402,7 @@ inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 
 // ---- cross-TU launch helpers (implemented in the .hip files) ------------------
 int force_mult_E(lgh_ctx *c, const double *sJit, const double *xE, double *yE);
-int force_mult_t_L(lgh_ctx *c, const double *sJit, const double *v_h1, double *y_l2);
+int force_mult_t_L(lgh_ctx *c, const double *sJit, const double *v_h1, double *y_l2, const int *guard = nullptr);
 int force_mult_t_E(lgh_ctx *c, const double *sJit, const double *vE, double *y_l2);
 int h1_transpose_gather(lgh_ctx *c, int ncomp, const double *YE, double *yL);
 int mass_apply_h1(lgh_ctx *c, const double *x, double *y, bool eliminate);

@@ -199,8 +199,9 @@ force_mult_t_3d(const int NE, const int N, const double *__restrict__ Bl,
                 const double *__restrict__ B, const double *__restrict__ G,
                 const double *__restrict__ sJit, const double *__restrict__ v,
                 const int *__restrict__ map /* null: v is an E-vector */,
-                double *__restrict__ y)
+                double *__restrict__ y, const int *__restrict__ guard /* non-null: run only when *guard != 0 */)
 {
+   if (guard && *guard == 0) { return; }
    constexpr int NQ = Q * Q * Q, ND = D * D * D, NL = L * L * L;
    constexpr int SV = 3 * ND;        // V[c][dz][dy][dx]
    constexpr int SA = 2 * D * D * Q; // Bx/Gx [k][dz][dy][qx]
@@ -447,8 +448,9 @@ __global__ void __launch_bounds__(Q *Q *NEB)
 force_mult_t_2d(const int NE, const int N, const double *__restrict__ Bl,
                 const double *__restrict__ B, const double *__restrict__ G,
                 const double *__restrict__ sJit, const double *__restrict__ v,
-                const int *__restrict__ map, double *__restrict__ y)
+                const int *__restrict__ map, double *__restrict__ y, const int *__restrict__ guard)
 {
+   if (guard && *guard == 0) { return; }
    constexpr int NQ = Q * Q, ND = D * D, NL = L * L;
    constexpr int PER = 2 * ND + 2 * D * Q + Q * L + 1;
    __shared__ double smem[NEB * PER];
@@ -588,32 +590,33 @@ int force_mult_E(lgh_ctx *c, const double *sJit, const double *xE, double *yE)
    return LGH_OK;
 }
 
-static int force_mult_t_any(lgh_ctx *c, const double *sJit, const double *v, const int *map, double *y)
+static int force_mult_t_any(lgh_ctx *c, const double *sJit, const double *v, const int *map, double *y, const int *guard)
 {
    switch (c->kid)
    {
-      case 0x222: LGH_LAUNCH_3D(force_mult_t_2d, 2, 2, 1, c->NE, c->N, c->Bl, c->B, c->G, sJit, v, map, y); break;
-      case 0x234: LGH_LAUNCH_3D(force_mult_t_2d, 3, 4, 2, c->NE, c->N, c->Bl, c->B, c->G, sJit, v, map, y); break;
-      case 0x246: LGH_LAUNCH_3D(force_mult_t_2d, 4, 6, 3, c->NE, c->N, c->Bl, c->B, c->G, sJit, v, map, y); break;
-      case 0x258: LGH_LAUNCH_3D(force_mult_t_2d, 5, 8, 4, c->NE, c->N, c->Bl, c->B, c->G, sJit, v, map, y); break;
-      case 0x26A: LGH_LAUNCH_3D(force_mult_t_2d, 6, 10, 5, c->NE, c->N, c->Bl, c->B, c->G, sJit, v, map, y); break;
-      case 0x322: LGH_LAUNCH_3D(force_mult_t_3d, 2, 2, 1, c->NE, c->N, c->Bl, c->B, c->G, sJit, v, map, y); break;
-      case 0x334: LGH_LAUNCH_3D(force_mult_t_3d, 3, 4, 2, c->NE, c->N, c->Bl, c->B, c->G, sJit, v, map, y); break;
-      case 0x346: LGH_LAUNCH_3D(force_mult_t_3d, 4, 6, 3, c->NE, c->N, c->Bl, c->B, c->G, sJit, v, map, y); break;
-      case 0x358: LGH_LAUNCH_3D(force_mult_t_3d, 5, 8, 4, c->NE, c->N, c->Bl, c->B, c->G, sJit, v, map, y); break;
-      case 0x36A: LGH_LAUNCH_3D(force_mult_t_3d, 6, 10, 5, c->NE, c->N, c->Bl, c->B, c->G, sJit, v, map, y); break;
+      case 0x222: LGH_LAUNCH_3D(force_mult_t_2d, 2, 2, 1, c->NE, c->N, c->Bl, c->B, c->G, sJit, v, map, y, guard); break;
+      case 0x234: LGH_LAUNCH_3D(force_mult_t_2d, 3, 4, 2, c->NE, c->N, c->Bl, c->B, c->G, sJit, v, map, y, guard); break;
+      case 0x246: LGH_LAUNCH_3D(force_mult_t_2d, 4, 6, 3, c->NE, c->N, c->Bl, c->B, c->G, sJit, v, map, y, guard); break;
+      case 0x258: LGH_LAUNCH_3D(force_mult_t_2d, 5, 8, 4, c->NE, c->N, c->Bl, c->B, c->G, sJit, v, map, y, guard); break;
+      case 0x26A: LGH_LAUNCH_3D(force_mult_t_2d, 6, 10, 5, c->NE, c->N, c->Bl, c->B, c->G, sJit, v, map, y, guard); break;
+      case 0x322: LGH_LAUNCH_3D(force_mult_t_3d, 2, 2, 1, c->NE, c->N, c->Bl, c->B, c->G, sJit, v, map, y, guard); break;
+      case 0x334: LGH_LAUNCH_3D(force_mult_t_3d, 3, 4, 2, c->NE, c->N, c->Bl, c->B, c->G, sJit, v, map, y, guard); break;
+      case 0x346: LGH_LAUNCH_3D(force_mult_t_3d, 4, 6, 3, c->NE, c->N, c->Bl, c->B, c->G, sJit, v, map, y, guard); break;
+      case 0x358: LGH_LAUNCH_3D(force_mult_t_3d, 5, 8, 4, c->NE, c->N, c->Bl, c->B, c->G, sJit, v, map, y, guard); break;
+      case 0x36A: LGH_LAUNCH_3D(force_mult_t_3d, 6, 10, 5, c->NE, c->N, c->Bl, c->B, c->G, sJit, v, map, y, guard); break;
       default: return unknown_kernel(c->kid);
    }
    LGH_HIP_CHECK(hipGetLastError());
    return LGH_OK;
 }
-int force_mult_t_L(lgh_ctx *c, const double *sJit, const double *v_h1, double *y_l2)
+// guard: device flag; the kernel does nothing when it is 0 (lgh_solve_energy: the fused F^T v is current)
+int force_mult_t_L(lgh_ctx *c, const double *sJit, const double *v_h1, double *y_l2, const int *guard)
 {
-   return force_mult_t_any(c, sJit, v_h1, c->h1map, y_l2);
+   return force_mult_t_any(c, sJit, v_h1, c->h1map, y_l2, guard);
 }
 int force_mult_t_E(lgh_ctx *c, const double *sJit, const double *vE, double *y_l2)
 {
-   return force_mult_t_any(c, sJit, vE, nullptr, y_l2);
+   return force_mult_t_any(c, sJit, vE, nullptr, y_l2, nullptr);
 }
 
 } // namespace lgh

@@ -819,9 +819,15 @@ int qupdate(lgh_ctx *c, const double *S)
    a.e = S + 2 * (size_t)c->H1V;
    a.result = c->dt_est_dev;
    const int rc = launch_q<QMODE_UPDATE>(c, a);
-   // F^T v of this state's velocity block is now in c->erhs_q (lgh_solve_energy)
-   c->erhs_state = (rc == LGH_OK && a.erhs_q) ? S : nullptr;
-   c->force_e_state = (rc == LGH_OK && a.force_e) ? S : nullptr;
+   // F^T v of this state's velocity block is now in c->erhs_q, F.1 in c->force_e_q; lgh_solve_energy compares the
+   // velocity it is given with the one the product was formed from
+   c->qgen++;
+   c->fused_ftv_valid = (rc == LGH_OK && a.erhs_q && c->v_snap) ? 1 : 0;
+   c->fused_f1_valid = (rc == LGH_OK && a.force_e) ? 1 : 0;
+   if (c->fused_ftv_valid)
+   {
+      LGH_HIP_CHECK(hipMemcpyAsync(c->v_snap, S + c->H1V, sizeof(double) * (size_t)c->H1V, hipMemcpyDeviceToDevice, c->stream));
+   }
    return rc;
 }
 

@@ -150,7 +150,8 @@ void LagrangianHydroOperator::SolveVelocity(const Vector &S, Vector &dS_dt) cons
    UpdateQuadratureData(S); // :332
    int it = 0;
    // ForcePA->Mult(one, rhs); rhs.Neg(); per-component EliminateRHS + CG_VMass (:354-398)
-   LGH_VERIFY(lgh_solve_velocity(ctx, S.Read(), dS_dt.Write(), one.Read(), rhs.Write(), B.Write(),
+   // (one: NULL = the operator's own constant-one function, :170-171; the member `one` above stays for ForcePAOperator::Mult callers)
+   LGH_VERIFY(lgh_solve_velocity(ctx, S.Read(), dS_dt.Write(), nullptr, rhs.Write(), B.Write(),
                                  cg_rel_tol, cg_max_iter, &it));
 }
 

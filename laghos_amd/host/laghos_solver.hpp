@@ -73,7 +73,8 @@ public:
    // Calls UpdateQuadratureData (laghos_solver.cpp:527-535); all-reduce MIN
    double GetTimeStepEstimate(const Vector &S) const;
    void ResetTimeStepEstimate() const;
-   void ResetQuadratureData() const { qdata_is_current = false; }
+   // (laghos_solver.hpp:193) - the force products lgh_qupdate formed with the stale data are discarded with it
+   void ResetQuadratureData() const { qdata_is_current = false; LGH_VERIFY(lgh_reset_quadrature_data(ctx)); }
    double InternalEnergy(const Vector &S) const;
    double KineticEnergy(const Vector &S) const;
    double ENorm(const Vector &S) const; // ||e||_2, all-reduced (laghos.cpp:794-795)

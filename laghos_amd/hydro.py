@@ -81,6 +81,7 @@ class HydroOperator:
 
     def reset_quadrature_data(self):
         self.qdata_is_current = False
+        self.ctx.reset_quadrature_data()  # the force products formed with the stale data go with it
 
     def update_quadrature_data(self, S):
         if self.qdata_is_current:
@@ -104,7 +105,7 @@ class HydroOperator:
             ctx.tg_source_2d(S, self.e_source)
         ctx.solve_energy_begin(S, S[p.H1V:2 * p.H1V], dS, self.e_rhs, self.cg_tol, self.cg_max_iter,
                                e_source=self.e_source)
-        ctx.solve_velocity(S, dS, self.one, self.rhs, self.work, self.cg_tol, self.cg_max_iter)
+        ctx.solve_velocity(S, dS, None, self.rhs, self.work, self.cg_tol, self.cg_max_iter)  # (one: the operator's own)
         ctx.solve_energy_end()
         self.qdata_is_current = False
 
@@ -228,7 +229,7 @@ def rk2avg_step(hydro, S, t, dt, work):
             ctx.vec_axpby(S, 1.0, S0, 0.5 * dt, dS)                # S = S0 + dt/2 dS_dt
             hydro.reset_quadrature_data()
         hydro.update_quadrature_data(S)
-        ctx.solve_velocity(S, dS, hydro.one, hydro.rhs, hydro.work, hydro.cg_tol, hydro.cg_max_iter)
+        ctx.solve_velocity(S, dS, None, hydro.rhs, hydro.work, hydro.cg_tol, hydro.cg_max_iter)
         ctx.vec_axpby(V, 1.0, v0, 0.5 * dt, dv)                   # V = v0 + dt/2 dv_dt
         if hydro.e_source is not None:
             ctx.tg_source_2d(S, hydro.e_source)

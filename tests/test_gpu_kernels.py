@@ -15,7 +15,7 @@ TOL = 1e-13
 
 CONFIGS = [
     # (mesh, rs, order_v, order_e) -> kernel ids 0x234, 0x246, 0x334, 0x346, 0x358, 0x322,
-    # and 0x36A (Q5Q4: not instantiated in the reference, laghos_assembly.cpp:544-547;
+    # 0x222, 0x26A, and 0x36A (Q5Q4: not instantiated in the reference, laghos_assembly.cpp:544-547;
     # oracle-only parity, BASELINE config 5)
     ("square01_quad", 2, 2, 1),
     ("square01_quad", 1, 3, 2),
@@ -25,6 +25,9 @@ CONFIGS = [
     ("cube01_hex", 1, 1, 0),
     ("box01_hex", 0, 3, 2),
     ("cube01_hex", 0, 5, 4),
+    # 0x222 and 0x26A: both instantiated by the reference (laghos_assembly.cpp:538-542)
+    ("square01_quad", 2, 1, 0),
+    ("square01_quad", 0, 5, 4),
 ]
 
 
@@ -454,6 +457,139 @@ def test_lockstep_k1_forms_agree_at_q3q2(mesh, rs, monkeypatch):
         finally:
             g.close()
         assert rel_err(dS[H1V:2 * H1V], dS_o[H1V:2 * H1V]) < 1e-10, variant
+
+
+def _fused_state(kind, prob, g):
+    """deformed: a seeded distorted state; sedov: the live state after 12 real time steps"""
+    if kind == "deformed":
+        return g.ctx.to_dev(deformed_state(prob, seed=41))
+    from laghos_amd.hydro import TimeLoop
+    loop = TimeLoop(g, t_final=1e9, max_steps=12)
+    while loop.step():
+        pass
+    return loop.S
+
+
+@pytest.mark.parametrize("kind", ["deformed", "sedov"])
+@pytest.mark.parametrize("cfg", [("cube01_hex", 1, 3, 2), ("cube01_hex", 1, 2, 1), ("cube01_hex", 0, 4, 3), ("square01_quad", 1, 3, 2)],
+                         ids=lambda c: f"{c[0]}-rs{c[1]}-Q{c[2]}Q{c[3]}")
+def test_fused_force_products(cfg, kind):
+    """The force products the production step uses are formed inside the fused QUpdate kernel
+    (lgh_qupdate -> force_e_q / erhs_q), not by force_mult_3d / force_mult_t_3d.  Here they are taken out through
+    lgh_fused_force_mult / _transpose and compared, at the force kernels' own tolerance, with
+      * the oracle's ForceMult(one) and ForceMultTranspose(v) (laghos_assembly.cpp:296-514, :715-924) on the
+        oracle's quadrature data of the same state, and
+      * the stand-alone HIP kernels on the device's own quadrature data (lgh_set_fused_forces(ctx, 0) path),
+    on a distorted random state and on a live Sedov state.  2D forms only F^T v inside the update."""
+    from oracle.fem import Problem
+    mesh, rs, ok, ot = cfg
+    prob = Problem(mesh=mesh, rs=rs, order_v=ok, order_e=ot, problem=1)
+    g, o = make_gpu(prob), make_oracle(prob)
+    try:
+        S = _fused_state(kind, prob, g)
+        Sh = S.cpu().numpy()
+        H1V = prob.H1V
+        g.reset_quadrature_data()
+        g.update_quadrature_data(S)
+        gen, f1_ok, ftv_ok = g.ctx.quadrature_generation()
+        assert ftv_ok == 1 and f1_ok == (1 if prob.dim == 3 else 0)
+        o.qdata_is_current = False
+        o.update_quadrature_data(Sh)
+        one = np.ones(prob.L2V)
+        F1_o = o.force_mult(one)
+        Ftv_o = o.force_mult_transpose(Sh[H1V:2 * H1V].copy())
+        # fused products
+        ftv = g.ctx.empty(prob.L2V)
+        assert g.ctx.fused_force_mult_transpose(ftv)
+        g.ctx.sync()
+        ftv = ftv.cpu().numpy()
+        assert rel_err(ftv, Ftv_o) < 1e-12   # (the fused update's own bar against the oracle's quadrature data)
+        f1 = None
+        if prob.dim == 3:
+            f1 = g.ctx.empty(H1V)
+            assert g.ctx.fused_force_mult(f1)
+            g.ctx.sync()
+            f1 = f1.cpu().numpy()
+            assert rel_err(f1, F1_o) < 1e-12
+        # the stand-alone kernels on the device's own stressJinvT: same operator, same data -> the kernel tolerance
+        f1_k, ftv_k = g.ctx.empty(H1V), g.ctx.empty(prob.L2V)
+        g.ctx.force_mult(g.ctx.to_dev(one), f1_k)
+        g.ctx.force_mult_transpose(S[H1V:2 * H1V].contiguous(), ftv_k)
+        g.ctx.sync()
+        assert rel_err(ftv, ftv_k.cpu().numpy()) < TOL
+        if f1 is not None:
+            assert rel_err(f1, f1_k.cpu().numpy()) < TOL
+        # (force_mult hands out nothing mutable: the products are still on hand) ... until the data is reset
+        assert g.ctx.quadrature_generation()[1:] == (f1_ok, 1)
+        g.ctx.reset_quadrature_data()
+        assert g.ctx.quadrature_generation()[1:] == (0, 0)
+        assert not g.ctx.fused_force_mult_transpose(g.ctx.empty(prob.L2V))
+    finally:
+        g.close()
+        o.close()
+
+
+def test_fused_products_follow_content_not_addresses():
+    """lgh_solve_energy must use the velocity it is GIVEN (ForcePA->MultTranspose(v, e_rhs),
+    laghos_solver.cpp:473), whatever lgh_qupdate saw before:
+      * S.v changed in place after lgh_qupdate(S) (no ResetQuadratureData): the reference multiplies the stale
+        stress with the NEW v - so must the library (an address-keyed cache returned F^T v_old);
+      * the same velocity at another address may use the fused product - and gives the same numbers;
+      * a `one` that is not all ones is not treated as one; NULL stands for the operator's own."""
+    import torch
+    from oracle.fem import Problem
+    prob = Problem(mesh="cube01_hex", rs=1, order_v=3, order_e=2, problem=1)
+    g, o = make_gpu(prob), make_oracle(prob)
+    try:
+        H1V, L2V = prob.H1V, prob.L2V
+        Sh = deformed_state(prob, seed=43)
+        S = g.ctx.to_dev(Sh)
+        o.qdata_is_current = False
+        o.update_quadrature_data(Sh)            # the stress both sides keep from now on
+        g.reset_quadrature_data()
+        g.update_quadrature_data(S)
+        v_old = Sh[H1V:2 * H1V].copy()
+        rng = np.random.default_rng(5)
+        v_new = 1.5 * v_old + 0.1 * rng.uniform(-1, 1, H1V)
+        ref_old, ref_new = o.force_mult_transpose(v_old), o.force_mult_transpose(v_new)
+        assert rel_err(ref_old, ref_new) > 0.1  # the two right-hand sides are far apart
+        dS, e_rhs = g.ctx.zeros(Sh.size), g.ctx.zeros(L2V)
+        # same content at another address
+        v_copy = S[H1V:2 * H1V].clone()
+        g.ctx.solve_energy(S, v_copy, dS, e_rhs, 1e-14, 200)
+        g.ctx.sync()
+        rhs_copy = e_rhs.cpu().numpy().copy()
+        assert rel_err(rhs_copy, ref_old) < 1e-12
+        # in-place change of the state's velocity, no reset
+        S[H1V:2 * H1V] = g.ctx.to_dev(v_new)
+        torch.cuda.synchronize()
+        g.ctx.solve_energy(S, S[H1V:2 * H1V], dS, e_rhs, 1e-14, 200)
+        g.ctx.sync()
+        assert rel_err(e_rhs.cpu().numpy(), ref_new) < 1e-12
+        # back to the old velocity: the fused product is usable again, and equals what it was
+        S[H1V:2 * H1V] = g.ctx.to_dev(v_old)
+        torch.cuda.synchronize()
+        g.ctx.solve_energy(S, S[H1V:2 * H1V], dS, e_rhs, 1e-14, 200)
+        g.ctx.sync()
+        assert np.array_equal(e_rhs.cpu().numpy(), rhs_copy)
+        # `one`: NULL is the operator's own; a vector that is not all ones goes through ForceMult
+        F1_o = o.force_mult(np.ones(L2V))
+        x = np.ones(L2V)
+        x[::7] = 0.5
+        Fx_o = o.force_mult(x)
+        rhs, work = g.ctx.zeros(H1V), g.ctx.zeros(prob.N)
+        for one_arg, ref in ((None, F1_o), (g.ctx.to_dev(np.ones(L2V)), F1_o), (g.ctx.to_dev(x), Fx_o)):
+            dS.zero_()
+            torch.cuda.synchronize()
+            g.ctx.solve_velocity(S, dS, one_arg, rhs, work, 1e-14, 300)
+            g.ctx.sync()
+            # rhs_h1 holds -F x with the essential rows zeroed; compare away from them
+            r = rhs.cpu().numpy()
+            free = r != 0.0
+            assert rel_err(-r[free], ref[free]) < 1e-12
+    finally:
+        g.close()
+        o.close()
 
 
 SLAB_SWITCHES = [
