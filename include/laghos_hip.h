@@ -244,13 +244,8 @@ int lgh_enable_timers(lgh_ctx *ctx, int on);
 #define LGH_KERNEL_FORCE_MULT 3
 #define LGH_KERNEL_FORCE_MULT_T 4
 #define LGH_KERNEL_MASS_CG_L2 5
-#define LGH_KERNEL_PCG 6          /* one persistent launch = one whole lockstep mass solve (lgh_pcg.hip) */
 int lgh_ktime_begin(lgh_ctx *ctx, int which, int max_samples);
 int lgh_ktime_end(lgh_ctx *ctx, int *launches, double *mean_seconds);
-/* CG iterations (loop trips of the persistent solve kernel, all lockstep components advancing
- * together) executed since the last call; resets the counter.  With lgh_ktime_* on
- * LGH_KERNEL_PCG this gives the time of one fused CG iteration. */
-int lgh_pcg_iterations(lgh_ctx *ctx, long *iterations);
 /* Whether lgh_create found the 1-D H1 / L2 tables mirror symmetric, B[q,d] = B[Q-1-q, D-1-d] (any nodal or
  * Bernstein basis on symmetric points is): the plane-form mass kernels keep half a table in scalar registers
  * and are only dispatched then (the column forms run otherwise). */

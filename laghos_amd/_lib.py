@@ -84,7 +84,6 @@ SYMBOLS = {
     "lgh_enable_timers": (_I, [_P, _I]),
     "lgh_ktime_begin": (_I, [_P, _I, _I]),
     "lgh_ktime_end": (_I, [_P, c_int_p, c_dbl_p]),
-    "lgh_pcg_iterations": (_I, [_P, ctypes.POINTER(ctypes.c_long)]),
     "lgh_table_symmetry": (_I, [_P, c_int_p, c_int_p]),
     "lgh_k1_form": (_I, [_P, c_int_p]),
     "lgh_qupdate_set_tiny_grad": (_I, [_P, _D]),

@@ -306,9 +306,7 @@ static int create_impl(const lgh_config *cfg, lgh_ctx *c, const int kid)
          for (int k = off[n]; k < off[(size_t)n + 1]; k++) { ell[(size_t)(k - off[n]) * c->N + n] = idx[k]; }
       c->t_deg = deg;
       LGH_TRY(dev_alloc_copy(&c->t_ell, ell.data(), ell.size()));
-      const char *env = getenv("LGH_ATOMIC_SCATTER");
-      c->atomic_scatter = (env && env[0] == '1') ? 1 : 0;
-      env = getenv("LGH_VCG_VARIANT"); // A/B switch of the lockstep K1 (lgh_vcg.hip)
+      const char *env = getenv("LGH_VCG_VARIANT"); // A/B switch of the lockstep K1 (lgh_vcg.hip)
       c->vcg_variant = (env && env[0] >= '0' && env[0] <= '9') ? env[0] - '0' : -1; // -1: by kernel id and mesh size (vcg_k1_form)
       // slab-form K1 (lgh_vcg_slab.hip), A/B: wavefronts per SIMD (default 2), row loads, exact sum of (d, A d), sets drawn from a workgroup queue
       env = getenv("LGH_SLAB_WPS");
@@ -399,7 +397,6 @@ int lgh_destroy(lgh_ctx *c)
       delete c->ktime;
    }
    cg_l2_free(c);
-   pcg_free(c);
    vcg_free(c);
    if (c->stream2)
    {
@@ -784,9 +781,7 @@ int lgh_solve_energy(lgh_ctx *c, const double *S, const double *v_h1, double *dS
 static bool energy_overlap_ok(const lgh_ctx *c)
 {
    static const bool on = !(getenv("LGH_OVERLAP") && getenv("LGH_OVERLAP")[0] == '0');
-   // the persistent solve kernel (lgh_pcg.hip) needs all its workgroups resident: nothing runs beside it
-   return on && (c->multi == 0 || comm_second_channel(c)) && !c->timers.enabled && !(c->ktime && c->ktime->which >= 0) && vcg_available(c) &&
-          !pcg_available(c);
+   return on && (c->multi == 0 || comm_second_channel(c)) && !c->timers.enabled && !(c->ktime && c->ktime->which >= 0) && vcg_available(c);
 }
 int lgh_solve_energy_begin(lgh_ctx *c, const double *S, const double *v_h1, double *dS_dt, double *e_rhs,
                            const double *e_source, double rel_tol, int max_iter)
@@ -978,13 +973,6 @@ int lgh_k1_form(lgh_ctx *c, int *form)
 {
    LGH_CHECK_ARG(c && form);
    *form = vcg_k1_form(c);
-   return LGH_OK;
-}
-int lgh_pcg_iterations(lgh_ctx *c, long *iterations)
-{
-   LGH_CHECK_ARG(c && iterations);
-   *iterations = c->pcg_iterations;
-   c->pcg_iterations = 0;
    return LGH_OK;
 }
 

@@ -430,6 +430,7 @@ int lgh_comm_init(lgh_ctx *c, int nranks, int rank, const char unique_id[128])
       c->nranks = nranks;
       c->rank = rank;
       c->multi = 1;
+      vcg_free(c); // (tables of K2 built for another communicator)
       if (!g->barrier()) { set_error("local communicator: not all %d ranks arrived", nranks); return LGH_ERR_COMM; }
       return LGH_OK;
    }
@@ -446,25 +447,36 @@ int lgh_comm_init(lgh_ctx *c, int nranks, int rank, const char unique_id[128])
       const char *env = getenv("LGH_FORCE_MULTI");
       c->multi = (nranks > 1 || (env && env[0] == '1')) ? 1 : 0;
    }
-   // Second communicator (same ranks) for the second stream: its id is drawn by rank 0 and travels over the
-   // first one.  Collective; the outcome is agreed on by a MIN over the ranks, so either every rank has it
-   // (and overlaps the energy solve with the velocity solve) or none does.  LGH_COMM2=0 (set on every rank)
-   // skips it.
-   if (c->multi && g_nccl.Broadcast && !(getenv("LGH_COMM2") && getenv("LGH_COMM2")[0] == '0'))
+   // Second communicator (same ranks) for the second stream, so that the energy solve can run beside the velocity solve
+   // on several ranks too.  Its id is drawn by rank 0 and travels over the first one TOGETHER with rank 0's verdict (a
+   // rank that got no id must not leave the others blocked in CommInitRank); the outcome is then agreed on by a MIN over
+   // the ranks, so either every rank has the channel or none does.
+   // Two communicators driven from two streams of one device have only ever run on a communicator of size 1 and on the
+   // in-process loopback here (no multi-GPU box): collectives of different communicators that the ranks happen to
+   // schedule in different orders can block each other.  Until a real multi-GPU run has validated it, the channel is
+   // therefore opt-in on more than one rank: LGH_COMM2=1 on every rank (LGH_COMM2=0 switches it off everywhere).
+   const char *env2 = getenv("LGH_COMM2");
+   const bool want2 = env2 ? env2[0] == '1' : (nranks == 1);
+   if (c->multi && g_nccl.Broadcast && want2)
    {
       Comm *cm = c->comm;
       char *dbuf = nullptr;
-      LGH_HIP_CHECK(hipMalloc((void **)&dbuf, 128 + sizeof(double)));
+      LGH_HIP_CHECK(hipMalloc((void **)&dbuf, 128 + 2 * sizeof(double)));
+      char hbuf[128 + sizeof(double)];
       ncclUniqueId id2;
       memset(&id2, 0, sizeof(id2));
       double ok = 1.0;
       if (rank == 0 && g_nccl.GetUniqueId(&id2) != ncclSuccess) { ok = 0.0; }
-      LGH_HIP_CHECK(hipMemcpy(dbuf, id2.internal, 128, hipMemcpyHostToDevice));
-      LGH_NCCL_CHECK(g_nccl.Broadcast(dbuf, dbuf, 128, /* ncclChar */ 0, 0, cm->comm, c->stream));
+      memcpy(hbuf, id2.internal, 128);
+      memcpy(hbuf + 128, &ok, sizeof(double));
+      LGH_HIP_CHECK(hipMemcpy(dbuf, hbuf, sizeof(hbuf), hipMemcpyHostToDevice));
+      LGH_NCCL_CHECK(g_nccl.Broadcast(dbuf, dbuf, sizeof(hbuf), /* ncclChar */ 0, 0, cm->comm, c->stream));
       LGH_HIP_CHECK(hipStreamSynchronize(c->stream));
-      LGH_HIP_CHECK(hipMemcpy(id2.internal, dbuf, 128, hipMemcpyDeviceToHost));
+      LGH_HIP_CHECK(hipMemcpy(hbuf, dbuf, sizeof(hbuf), hipMemcpyDeviceToHost));
+      memcpy(id2.internal, hbuf, 128);
+      memcpy(&ok, hbuf + 128, sizeof(double)); // rank 0's verdict: nobody calls CommInitRank when it is 0
       if (ok != 0.0 && g_nccl.CommInitRank(&cm->comm2, nranks, id2, rank) != ncclSuccess) { ok = 0.0; cm->comm2 = nullptr; }
-      double *dok = (double *)(dbuf + 128);
+      double *dok = (double *)(dbuf + 128 + sizeof(double));
       LGH_HIP_CHECK(hipMemcpy(dok, &ok, sizeof(double), hipMemcpyHostToDevice));
       LGH_NCCL_CHECK(g_nccl.AllReduce(dok, dok, 1, ncclFloat64, ncclMin, cm->comm, c->stream));
       LGH_HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -473,6 +485,7 @@ int lgh_comm_init(lgh_ctx *c, int nranks, int rank, const char unique_id[128])
       cm->channel2 = (ok != 0.0);
       if (!cm->channel2 && cm->comm2) { g_nccl.CommDestroy(cm->comm2); cm->comm2 = nullptr; }
    }
+   vcg_free(c); // the tables of the node kernel K2 carry the shared-node / owner flags of the previous communicator
    return LGH_OK;
 }
 
@@ -554,6 +567,7 @@ int lgh_comm_set_neighbors(lgh_ctx *c, int n_nbr, const int *nbr_rank, const int
       std::vector<uint8_t> hm((size_t)c->N, 0);
       for (int n : uniq) { hm[n] = 1; }
       if (cm->hmask) { (void)hipFree(cm->hmask); }
+      vcg_free(c); // (the flag bytes of the node kernel K2 were built from the previous neighbour lists)
       LGH_HIP_CHECK(hipMalloc((void **)&cm->hmask, std::max<size_t>(hm.size(), 1)));
       LGH_HIP_CHECK(hipMemcpy(cm->hmask, hm.data(), hm.size(), hipMemcpyHostToDevice));
    }

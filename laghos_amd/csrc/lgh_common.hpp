@@ -101,7 +101,6 @@ struct lgh_ctx
    int *t_idx;   // NE*ND: E-vector positions (e*ND + d) contributing to node
    int *t_ell;   // t_deg*N: the same in ELL format, [k*N + n], -1 = none
    int t_deg;    // max contributions per node (8 for hexes, 4 for quads)
-   int atomic_scatter; // LGH_ATOMIC_SCATTER=1: f64 atomics instead of E-vector + gather
    uint8_t *essmask[3]; // N each (0/1)
    int *ess[3];
    int ess_count[3];
@@ -146,8 +145,6 @@ struct lgh_ctx
    int vcg_variant;      // LGH_VCG_VARIANT: which K1 form vcg_solve launches (lgh_vcg.hip); -1: by kernel id and mesh size
    int slab_wps, slab_wide, slab_exact, slab_dyn; // A/B switches of the slab-form K1 (LGH_SLAB_WPS / _WIDE / _EXACT / _DYN, read by lgh_create)
    void *vcg_aux;        // tables of the node kernel K2 (lgh_vcg.hip VcgAux), allocated on first use
-   void *pcg;            // state of the persistent solve kernel (lgh_pcg.hip), allocated on first use
-   long pcg_iterations;  // loop trips of the persistent solve kernel since lgh_pcg_iterations()
 
    lgh::Timers timers;
    lgh::KTime *ktime;
@@ -412,11 +409,7 @@ int mass_assemble_diag(lgh_ctx *c);
 int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, int iters[3],
               const double *force_E = nullptr);
 bool vcg_fused_init_ok(const lgh_ctx *c);
-bool pcg_available(const lgh_ctx *c);
-int pcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, int iters[3],
-              const double *force_E);
-void pcg_free(lgh_ctx *c);
-// tables shared by the node kernels of lgh_vcg.hip and lgh_pcg.hip (built in lgh_pcg.hip)
+// tables of the node kernel K2 (lgh_vcg.hip)
 int partition_nodes_by_cost(lgh_ctx *c, int W, int **out);
 int make_ellz(lgh_ctx *c, unsigned **out);
 int make_essbits(lgh_ctx *c, uint8_t **out);

@@ -44,7 +44,6 @@ struct MassArgs
    double *y;         // E-vector (H1) or L2 vector output
    // CG
    double *d;         // direction vector (read; MODE 3 also writes it in place)
-   double *yL;        // atomic-scatter variant: L-vector accumulated with f64 atomics
    CgScalars *cgs;
    double *partials;
    unsigned int *ticket;
@@ -254,8 +253,7 @@ mass_apply_3d(const MassArgs a)
 #pragma unroll
          for (int qy = 0; qy < Q; qy++) { u += brow[qy] * sA[tx + D * (qy + Q * dz)]; }
          const size_t po = tx + D * (ty + D * dz) + (size_t)ND * e;
-         if (MODE == 2 && a.yL) { unsafeAtomicAdd(&a.yL[a.map[po]], u); }
-         else { a.y[po] = u; }
+         a.y[po] = u;
          if (MODE >= 2) { dot += xcol[dz] * u; }
       }
    }
@@ -543,8 +541,7 @@ mass_apply_2d(const MassArgs a)
       double u = 0.0;
       for (int qy = 0; qy < Q; qy++) { u += a.B[qy + Q * ty] * sA[tx + D * qy]; }
       const size_t po = tx + D * ty + (size_t)ND * e;
-      if (MODE == 2 && a.yL) { unsafeAtomicAdd(&a.yL[a.map[po]], u); }
-      else { a.y[po] = u; }
+      a.y[po] = u;
       if (MODE >= 2) { dot = sX[tx + D * ty] * u; }
    }
    if (MODE >= 2)
@@ -784,7 +781,6 @@ struct CgVecArgs
    int deg;
    const double *YE;   // E-vector from K1 (H1) ...
    double *yL;         // ... or the operator result as an L-vector (L2, multi-GPU H1, atomics)
-   int zero_yL;        // atomic-scatter variant: reset yL[n] after consuming it
    int d_in_place;     // 1: d already holds the new direction (L2); 0: form z + beta d here
    const uint8_t *ess; // essential mask or null
    const double *dinv; // Jacobi (null: no preconditioner)
@@ -924,7 +920,6 @@ cg_update_k(const CgVecArgs a)
    for (int k = 0; k < kUpdU; k++)
    {
       if (!ok[k]) { continue; }
-      if (!FUSED_GATHER && a.zero_yL) { a.yL[n[k]] = 0.0; }
       const double z_ = es[k] ? 0.0 : zv[k];
       double dv;
       if (a.d_in_place) { dv = dold[k]; }
@@ -1034,16 +1029,9 @@ int cg_solve(lgh_ctx *c, int space, const double *b, double *x, double rel_tol, 
    m.ticket = c->tickets + 1 * kTicketSlot;
    m.multi = multi ? 1 : 0;
 
-   const bool atomic = h1 && !multi && c->atomic_scatter;
    m.d = c->cg_d0;
    v.d = c->cg_d0;
    v.d_in_place = h1 ? 0 : 1;
-   if (atomic)
-   {
-      m.yL = c->cg_y;
-      rc = vec_set(c, c->cg_y, 0.0, n);
-      if (rc) { return rc; }
-   }
    int it = 0;
    CgScalars *hs = (CgScalars *)c->host_pinned;
    // chunk = iterations enqueued between two looks at the convergence flag.  The
@@ -1075,13 +1063,7 @@ int cg_solve(lgh_ctx *c, int space, const double *b, double *x, double rel_tol, 
          if (rc) { return rc; }
          v.iter = it;
          v.ess = ess;
-         if (atomic)
-         {
-            v.yL = c->cg_y;
-            v.zero_yL = 1;
-            hipLaunchKernelGGL((cg_update_k<false, 0>), dim3(nbu), dim3(256), 0, c->stream, v);
-         }
-         else if (h1 && !multi)
+         if (h1 && !multi)
          {
             v.ell = c->t_ell;
             v.deg = c->t_deg;

@@ -24,10 +24,14 @@ LGH_HD void swap2(double &a, double &b) { const double t = a; a = b; b = t; }
 // sqrt on the device: v_rsq_f64, one Goldschmidt step and one residual correction - 8 instructions and <= 1 ulp on
 // normal operands, against 22 for the compiler's correctly rounded expansion (which rescales tiny and huge
 // operands and handles the special values; the update kernel is bound by vector issue and takes ~10 roots per
-// point).  0 -> 0; no denormal rescue, NaN for +inf.  tests/test_gpu_kernels.py::test_device_sqrt.
+// point).  +-0 and +inf are returned as they are (one class test); no denormal rescue.
+// tests/test_gpu_kernels.py::test_device_sqrt.  Building with -DLGH_IEEE_SQRT (make IEEE_SQRT=1) takes the correctly
+// rounded library root instead - the reference's arithmetic, for parity runs that want it.
 LGH_HD double fsqrt(const double x)
 {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && defined(LGH_IEEE_SQRT)
+   return __builtin_sqrt(x);
+#elif defined(__HIP_DEVICE_COMPILE__)
    const double y = __builtin_amdgcn_rsq(x);
    double g = x * y, h = 0.5 * y;
    const double r = fma(-h, g, 0.5);
@@ -35,7 +39,7 @@ LGH_HD double fsqrt(const double x)
    h = fma(h, r, h);
    const double d = fma(-g, g, x);
    g = fma(d, h, g);
-   return (x == 0.0) ? 0.0 : g;
+   return __builtin_amdgcn_class(x, 0x260) ? x : g; // -0, +0, +inf
 #else
    return std::sqrt(x);
 #endif

@@ -1103,7 +1103,7 @@ vcg_update_k(const VcgArgs a)
 
 // ---- K2, bounded-grid form (one rank) ---------------------------------------------------------------
 // The same node update as vcg_update_k, organised the way the node phase of the persistent kernel
-// (lgh_pcg.hip) turned out to run fastest - its measurements carry over to a kernel of its own:
+// (round 2's persistent-solve experiment, profiles/r2_pcg_trace_*.txt) turned out to run fastest - its measurements carry over to a kernel of its own:
 //  * four workgroups of 512 threads per CU (more on large meshes: ranges of at most ~1000 nodes), each with a contiguous node range of equal COST (a node costs a
 //    fixed part plus a part per element contribution; with equal counts the ranges that cover
 //    element-boundary planes take 40 % longer), all ~35 loads of a node issued before the first use,
@@ -1347,6 +1347,82 @@ vcg_gather_list_k(const VcgArgs a)
    }
 }
 
+// ---- tables of the node kernel K2 ---------------------------------------------------------
+__global__ void __launch_bounds__(256)
+vcg_essbits_k(const uint8_t *e0, const uint8_t *e1, const uint8_t *e2, const uint8_t *hmask, const double *owner, uint8_t *bits,
+              const int N)
+{
+   const int n = blockIdx.x * blockDim.x + threadIdx.x;
+   if (n >= N) { return; }
+   // bits 0-2: essential for component k; several ranks: bit 3 = shared with another rank (its A d comes halo-summed
+   // from the L-vector), bit 4 = owned by another rank (weight 0 in the dot products)
+   bits[n] = (uint8_t)(((e0 && e0[n]) ? 1 : 0) | ((e1 && e1[n]) ? 2 : 0) | ((e2 && e2[n]) ? 4 : 0) | ((hmask && hmask[n]) ? 8 : 0) |
+                       ((owner && owner[n] == 0.0) ? 16 : 0));
+}
+__global__ void __launch_bounds__(256)
+vcg_ellz_k(const int *__restrict__ ell, unsigned *__restrict__ ellz, const size_t n_have, const size_t n_all, const int zslot)
+{
+   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+   if (i >= n_all) { return; }
+   const int p = (i < n_have) ? ell[i] : -1; // rows beyond the mesh's valence: absent
+   ellz[i] = 8u * (unsigned)(p < 0 ? zslot : p);
+}
+
+// Node phase: a node costs a fixed part (its vectors, the ELL row) plus a part per element contribution
+// (measured: t = 4.2..5.3 ns + 1.7..1.8 ns * valence per node and workgroup, the traces of the persistent-solve experiment, profiles/r2_pcg_trace_*.txt); with equal
+// node counts the workgroups whose range covers element-boundary planes take 40 % longer and every barrier
+// waits for them.  Ranges of equal cost instead, boundaries rounded to 16 nodes (128 B).
+int partition_nodes_by_cost(lgh_ctx *c, const int W, int **out)
+{
+   const int N = c->N;
+   std::vector<int> off((size_t)N + 1);
+   LGH_HIP_CHECK(hipMemcpy(off.data(), c->t_off, off.size() * sizeof(int), hipMemcpyDeviceToHost));
+   static const char *wenv = getenv("LGH_K2_NODE_WEIGHT"); // fixed part in units of half a contribution; <0: equal counts
+   const long fixed = wenv ? atol(wenv) : 5;
+   std::vector<long> cum((size_t)N + 1, 0);
+   for (int n = 0; n < N; n++) { cum[(size_t)n + 1] = cum[n] + (fixed < 0 ? 1 : fixed + 2 * (long)(off[(size_t)n + 1] - off[n])); }
+   std::vector<int> ns((size_t)std::max(W, 1) + 1, N);
+   ns[0] = 0;
+   int n = 0;
+   for (int w = 1; w < W; w++)
+   {
+      const long target = cum[N] * w / W;
+      while (n < N && cum[n] < target) { n++; }
+      int nb = (n + 8) & ~15; // nearest multiple of 16
+      nb = std::max(nb, ns[(size_t)w - 1]);
+      ns[w] = std::min(nb, N);
+   }
+   ns[std::max(W, 1)] = N;
+   LGH_HIP_CHECK(hipMalloc((void **)out, ns.size() * sizeof(int)));
+   LGH_HIP_CHECK(hipMemcpy(*out, ns.data(), ns.size() * sizeof(int), hipMemcpyHostToDevice));
+   return LGH_OK;
+}
+// ELL transpose of the restriction as byte offsets into a Y_E plane of NE*ND + pad doubles whose slot NE*ND is
+// zero: absent contributions point there, so the gather needs no predicate
+int make_ellz(lgh_ctx *c, unsigned **out)
+{
+   const size_t ell_n = (size_t)8 * c->N;
+   LGH_HIP_CHECK(hipMalloc((void **)out, ell_n * sizeof(unsigned)));
+   hipLaunchKernelGGL(vcg_ellz_k, dim3((unsigned)((ell_n + 255) / 256)), dim3(256), 0, nullptr, c->t_ell, *out,
+                      (size_t)c->t_deg * c->N, ell_n, c->NE * c->ND);
+   LGH_HIP_CHECK(hipGetLastError());
+   return LGH_OK;
+}
+// bit k of entry n: node n is essential for component k
+int make_essbits(lgh_ctx *c, uint8_t **out)
+{
+   LGH_HIP_CHECK(hipMalloc((void **)out, (size_t)c->N));
+   const uint8_t *hmask = nullptr;
+   const int *sh_node = nullptr;
+   int n_shared = 0;
+   if (c->multi) { comm_shared_nodes(c, &hmask, &sh_node, &n_shared); }
+   hipLaunchKernelGGL(vcg_essbits_k, dim3((unsigned)((c->N + 255) / 256)), dim3(256), 0, nullptr, c->essmask[0], c->essmask[1],
+                      c->essmask[2], hmask, c->multi ? c->owner : nullptr, *out, c->N);
+   LGH_HIP_CHECK(hipGetLastError());
+   return LGH_OK;
+}
+
+
 // ---- host side -----------------------------------------------------------------------
 struct VcgAux
 {
@@ -1469,8 +1545,6 @@ bool vcg_fused_init_ok(const lgh_ctx *c)
 int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, int iters[3], const double *force_E)
 {
    if (!vcg_supported(c)) { return LGH_ERR_UNSUPPORTED; }
-   // one rank: the whole solve is one persistent kernel (lgh_pcg.hip)
-   if (pcg_available(c)) { return pcg_solve(c, B, X, rel_tol, max_iter, iters, force_E); }
    const bool multi = c->multi != 0;
    const size_t N = (size_t)c->N;
    int rc;
@@ -1489,6 +1563,9 @@ int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
       LGH_HIP_CHECK(hipMemset(c->vcg_partials, 0, 2 * kVC * (size_t)c->vcg_stride * sizeof(double)));
       LGH_HIP_CHECK(hipMalloc((void **)&c->vcg_tickets, 2 * kTicketSlot * sizeof(unsigned int)));
       LGH_HIP_CHECK(hipMemset(c->vcg_tickets, 0, 2 * kTicketSlot * sizeof(unsigned int)));
+   }
+   if (!c->vcg_aux) // (first solve, or the communicator has changed since: lgh_comm_init / lgh_comm_set_neighbors drop the tables)
+   {
       // the CG's own E-vector (the force E-vector of the fused init stays in c->YE) and the tables of K2
       VcgAux *x = new VcgAux();
       c->vcg_aux = x;
@@ -1506,6 +1583,7 @@ int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
          static const char *genv = getenv("LGH_K2_GRID");
          if (genv && atoi(genv) > 0) { x->grid2 = atoi(genv) * ncu; }
          else { x->grid2 = (int)std::max<long>(4L * ncu, (((long)c->N + 1023) / 1024 + 7) & ~7L); }
+         x->grid2 = std::min<long>(x->grid2, (long)c->vcg_stride - (long)kShards); // (one partial per workgroup in a reduction slot)
          rc = make_ellz(c, &x->ellz);
          if (rc) { return rc; }
          rc = make_essbits(c, &x->essbits);

@@ -268,7 +268,7 @@ def test_smallmat_device():
 def test_device_sqrt():
     """The square root of the small-matrix routines (v_rsq_f64 + one Goldschmidt step + one residual correction, 8
     instructions instead of the 22 of the correctly rounded expansion): within 1 ulp of numpy's over 600 decades,
-    exact at 0 and at exact squares."""
+    exact at 0 and at exact squares; +inf and the signed zeros as the library root returns them."""
     from oracle.fem import Problem
     prob = Problem(mesh="cube01_hex", rs=0, order_v=1, order_e=0, problem=1)
     g = make_gpu(prob)
@@ -284,6 +284,14 @@ def test_device_sqrt():
         ref = np.sqrt(x)
         assert np.all(np.abs(y - ref) <= np.spacing(ref))
         assert np.array_equal(y[-9:-4], ref[-9:-4])  # 0 and exact squares
+        # special values come back as the library root returns them
+        sp = np.array([np.inf, -0.0, 0.0])
+        sd = g.ctx.to_dev(sp)
+        od = g.ctx.zeros(3)
+        g.ctx.test_sqrt(sd, od)
+        g.ctx.sync()
+        out = od.cpu().numpy()
+        assert out[0] == np.inf and out[1] == 0.0 and np.signbit(out[1]) and out[2] == 0.0 and not np.signbit(out[2])
     finally:
         g.close()
 
