@@ -780,7 +780,7 @@ int lgh_solve_energy(lgh_ctx *c, const double *S, const double *v_h1, double *dS
 // scratch).  LGH_OVERLAP=0 switches it off.
 static bool energy_overlap_ok(const lgh_ctx *c)
 {
-   static const bool on = !(getenv("LGH_OVERLAP") && getenv("LGH_OVERLAP")[0] == '0');
+   const bool on = !(getenv("LGH_OVERLAP") && getenv("LGH_OVERLAP")[0] == '0');
    return on && (c->multi == 0 || comm_second_channel(c)) && !c->timers.enabled && !(c->ktime && c->ktime->which >= 0) && vcg_available(c);
 }
 int lgh_solve_energy_begin(lgh_ctx *c, const double *S, const double *v_h1, double *dS_dt, double *e_rhs,

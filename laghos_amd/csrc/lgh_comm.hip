@@ -232,7 +232,7 @@ halo_combine_k(const int n_shared, const int ncomp, const int N, const int *__re
 
 bool halo_can_piggyback(const lgh_ctx *c)
 {
-   static const bool on = !(getenv("LGH_HALO_PIGGYBACK") && getenv("LGH_HALO_PIGGYBACK")[0] == '0');
+   const bool on = !(getenv("LGH_HALO_PIGGYBACK") && getenv("LGH_HALO_PIGGYBACK")[0] == '0');
    return on && c->comm && c->comm->allpairs;
 }
 

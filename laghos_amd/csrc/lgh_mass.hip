@@ -581,7 +581,7 @@ template <int MODE> static int launch_mass(lgh_ctx *c, int space, const MassArgs
    break
    if ((MODE == 0 || MODE == 3) && space == LGH_SPACE_L2 && c->b_l2_sym && (id == 0x336 || id == 0x348 || id == 0x35A))
    {
-      static const char *penv = getenv("LGH_L2_PLANE"); // A/B: 0 = column form
+      const char *penv = getenv("LGH_L2_PLANE"); // A/B: 0 = column form
       constexpr int M = (MODE == 3 ? 3 : 0);
       if (!(penv && penv[0] == '0'))
       {

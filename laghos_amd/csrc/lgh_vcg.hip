@@ -1377,7 +1377,7 @@ int partition_nodes_by_cost(lgh_ctx *c, const int W, int **out)
    const int N = c->N;
    std::vector<int> off((size_t)N + 1);
    LGH_HIP_CHECK(hipMemcpy(off.data(), c->t_off, off.size() * sizeof(int), hipMemcpyDeviceToHost));
-   static const char *wenv = getenv("LGH_K2_NODE_WEIGHT"); // fixed part in units of half a contribution; <0: equal counts
+   const char *wenv = getenv("LGH_K2_NODE_WEIGHT"); // fixed part in units of half a contribution; <0: equal counts
    const long fixed = wenv ? atol(wenv) : 5;
    std::vector<long> cum((size_t)N + 1, 0);
    for (int n = 0; n < N; n++) { cum[(size_t)n + 1] = cum[n] + (fixed < 0 ? 1 : fixed + 2 * (long)(off[(size_t)n + 1] - off[n])); }
@@ -1533,7 +1533,7 @@ int vcg_k1_form(lgh_ctx *c)
 }
 bool vcg_fused_init_ok(const lgh_ctx *c)
 {
-   static const char *env = getenv("LGH_FUSED_INIT"); // A/B switch
+   const char *env = getenv("LGH_FUSED_INIT"); // A/B switch
    if (env && env[0] == '0') { return false; }
    return vcg_supported(c) && c->multi == 0 && c->t_deg <= 8;
 }
@@ -1580,7 +1580,7 @@ int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
          // node ranges (= workgroups) of vcg_update_p_k: four per CU, and not more than ~1000 nodes (two passes) each -
          // on large meshes long static ranges lose to the hardware's dynamic distribution of many short ones
          // (64^3 zones: 367 vs 424 us; 128^3: H1 CG 2.72 vs 3.04 s).  LGH_K2_GRID=<ranges per CU> for A/B.
-         static const char *genv = getenv("LGH_K2_GRID");
+         const char *genv = getenv("LGH_K2_GRID");
          if (genv && atoi(genv) > 0) { x->grid2 = atoi(genv) * ncu; }
          else { x->grid2 = (int)std::max<long>(4L * ncu, (((long)c->N + 1023) / 1024 + 7) & ~7L); }
          x->grid2 = std::min<long>(x->grid2, (long)c->vcg_stride - (long)kShards); // (one partial per workgroup in a reduction slot)
@@ -1617,7 +1617,7 @@ int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
    }
    VcgAux *aux = (VcgAux *)c->vcg_aux;
    const int k1form = vcg_k1_form(c);
-   static const char *k2env = getenv("LGH_K2P"); // A/B: 0 = vcg_update_k (one node per thread, x every iteration)
+   const char *k2env = getenv("LGH_K2P"); // A/B: 0 = vcg_update_k (one node per thread, x every iteration)
    const bool k2p = aux->ellz != nullptr && !(k2env && k2env[0] == '0');
    VcgScalars *ds = (VcgScalars *)c->vcg_s;
    // exact accumulators of (d, A d): slab-form K1 on one rank with the bounded-grid K2 (LGH_SLAB_EXACT=0: ticketed fold)
@@ -1651,7 +1651,7 @@ int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
    a.limbs = limbs;
    a.queue = limbs ? (unsigned *)(limbs + 2 * kLimbWords) : nullptr;
    {
-      static const char *e0 = getenv("LGH_K2_SKIP");
+      const char *e0 = getenv("LGH_K2_SKIP");
       a.k2_skip = (e0 && e0[0] == '0') ? 0 : 1;
    }
    a.s = ds;
@@ -1742,7 +1742,7 @@ int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
          a.ticket = c->vcg_tickets;
          auto launch_k2p = [&]() {
             kt_begin(c, LGH_KERNEL_CG_UPDATE_H1);
-            static const char *uenv = getenv("LGH_K2_U"); // A/B: nodes per thread and pass (2: 182 VGPRs, one workgroup per CU resident)
+            const char *uenv = getenv("LGH_K2_U"); // A/B: nodes per thread and pass (2: 182 VGPRs, one workgroup per CU resident)
             const int u2 = (uenv && uenv[0] == '2') ? 1 : 0;
 #define LGH_K2P_LAUNCH(XU_, U_) hipLaunchKernelGGL((vcg_update_p_k<XU_, U_>), dim3(aux->grid2), dim3(512), 0, c->stream, a)
             if (it & 1) { if (u2) { LGH_K2P_LAUNCH(false, 2); } else { LGH_K2P_LAUNCH(false, 1); } }

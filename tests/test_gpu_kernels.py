@@ -684,3 +684,69 @@ def test_mass_kernels_without_table_symmetry(order, monkeypatch):
     H1V = prob.H1V
     assert rel_err(dS[H1V:2 * H1V], dS_o[H1V:2 * H1V]) < 1e-10
     assert rel_err(dS[2 * H1V:], dS_o[2 * H1V:]) < 1e-10
+
+
+# Every environment switch that selects a different kernel or launch sequence (DESIGN.md "Environment switches"), each
+# with the claim that goes with it: "bits" = the state must equal the default dispatch bit for bit (same operations in
+# the same order, only organised differently), "tol" = a different kernel / summation order, oracle tolerance only.
+KERNEL_SWITCHES = [
+    ((3, 2), {"LGH_FUSED_INIT": "0"}, "bits"),
+    ((3, 2), {"LGH_OVERLAP": "0"}, "bits"),
+    ((3, 2), {"LGH_K2_SKIP": "0"}, "bits"),
+    ((3, 2), {"LGH_FUSED_FTV": "0"}, "tol"),
+    ((3, 2), {"LGH_FUSED_F1": "0"}, "tol"),
+    ((3, 2), {"LGH_FUSED_FTV": "0", "LGH_FUSED_F1": "0"}, "tol"),
+    ((3, 2), {"LGH_K2P": "0"}, "tol"),
+    ((3, 2), {"LGH_K2_U": "2"}, "tol"),
+    ((3, 2), {"LGH_K2_GRID": "2"}, "tol"),
+    ((3, 2), {"LGH_K2_NODE_WEIGHT": "-1"}, "tol"),
+    ((4, 3), {"LGH_L2_PLANE": "0"}, "tol"),
+    ((4, 3), {"LGH_K2P": "0"}, "tol"),
+]
+_switch_default = {}
+
+
+@pytest.mark.parametrize("order,switches,claim", KERNEL_SWITCHES,
+                         ids=lambda v: ",".join(f"{k[4:]}={x}" for k, x in v.items()) if isinstance(v, dict) else (f"Q{v[0]}Q{v[1]}" if isinstance(v, tuple) else v))
+def test_kernel_switches(order, switches, claim, monkeypatch):
+    """No untested kernel behind an environment variable: one right-hand-side evaluation (QUpdate, both force
+    products, the lockstep velocity solve, the energy solve; both CGs to 1e-14) on a distorted state with the switch
+    set, against the oracle - and against the default dispatch bit for bit where the switch only reorganises the
+    launches."""
+    from oracle.fem import Problem
+    prob = Problem(mesh="box01_hex", rs=1 if order == (3, 2) else 0, order_v=order[0], order_e=order[1], problem=1)
+    S = deformed_state(prob, seed=45)
+    H1V = prob.H1V
+
+    def run():
+        g = make_gpu(prob)
+        try:
+            g.cg_tol = 1e-14
+            Sd = g.ctx.to_dev(S)
+            dS = g.ctx.zeros(S.size)
+            g.reset_quadrature_data()
+            g.mult(Sd, dS)
+            g.ctx.sync()
+            return dS.cpu().numpy()
+        finally:
+            g.close()
+
+    if order not in _switch_default:
+        o = make_oracle(prob)
+        try:
+            o.cg_tol = 1e-14
+            dS_o = np.empty_like(S)
+            o.qdata_is_current = False
+            o.mult(S, dS_o)
+        finally:
+            o.close()
+        _switch_default[order] = (dS_o, run())
+    dS_o, dS_def = _switch_default[order]
+    assert rel_err(dS_def[H1V:2 * H1V], dS_o[H1V:2 * H1V]) < 1e-10
+    for k, v in switches.items():
+        monkeypatch.setenv(k, v)
+    dS = run()
+    assert rel_err(dS[H1V:2 * H1V], dS_o[H1V:2 * H1V]) < 1e-10
+    assert rel_err(dS[2 * H1V:], dS_o[2 * H1V:]) < 1e-10
+    if claim == "bits":
+        assert np.array_equal(dS, dS_def)

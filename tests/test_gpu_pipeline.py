@@ -413,10 +413,24 @@ def test_halo_logic_emulated_ranks(pgrid):
         c.close()
 
 
-@pytest.mark.parametrize("nranks,nel,problem,timers", [(2, (8, 8, 8), 1, 1), (8, (8, 8, 8), 1, 1), (3, (9, 6, 6), 1, 1),
-                                                       (4, (8, 8, 4), 7, 1), (2, (8, 8, 8), 1, 0), (8, (8, 8, 8), 1, 0),
-                                                       (3, (9, 6, 6), 1, 0)])
-def test_multi_rank_run_on_one_gpu(nranks, nel, problem, timers):
+MULTI_RANK_CASES = [
+    # (ranks, zones, problem, region timers, (ok, ot), environment)
+    (2, (8, 8, 8), 1, 1, (3, 2), {}), (8, (8, 8, 8), 1, 1, (3, 2), {}), (3, (9, 6, 6), 1, 1, (3, 2), {}),
+    (4, (8, 8, 4), 7, 1, (3, 2), {}), (2, (8, 8, 8), 1, 0, (3, 2), {}), (8, (8, 8, 8), 1, 0, (3, 2), {}),
+    (3, (9, 6, 6), 1, 0, (3, 2), {}),
+    # the fallbacks a first run over real RCCL may need: no second channel (the default there), no piggy-backed sums
+    (8, (8, 8, 8), 1, 0, (3, 2), {"LGH_COMM2": "0"}),
+    (8, (8, 8, 8), 1, 0, (3, 2), {"LGH_HALO_PIGGYBACK": "0"}),
+    (2, (8, 8, 8), 1, 0, (3, 2), {"LGH_COMM2": "0", "LGH_HALO_PIGGYBACK": "0"}),
+    # the high-order forms of K1 / K2 on several ranks (BASELINE config 5 is an 8-GPU Q5Q4 run)
+    (8, (4, 4, 4), 1, 0, (4, 3), {}), (8, (4, 4, 4), 3, 0, (5, 4), {}), (2, (4, 4, 2), 3, 1, (5, 4), {"LGH_COMM2": "0"}),
+]
+
+
+@pytest.mark.parametrize("nranks,nel,problem,timers,order,env", MULTI_RANK_CASES,
+                         ids=[f"{c[0]}ranks-{'x'.join(map(str, c[1]))}-p{c[2]}-t{c[3]}-Q{c[4][0]}Q{c[4][1]}" + "".join(f"-{k[4:]}={v}" for k, v in c[5].items())
+                              for c in MULTI_RANK_CASES])
+def test_multi_rank_run_on_one_gpu(nranks, nel, problem, timers, order, env, monkeypatch):
     """The complete multi-rank algorithm (block partition, owner-weighted dot products,
     halo pack / canonical combine, separate-gather CG sequencing with its finish
     kernels, dt / |e| reductions) on ONE GPU: the ranks are contexts driven by one host
@@ -433,8 +447,10 @@ def test_multi_rank_run_on_one_gpu(nranks, nel, problem, timers):
     import os
     import threading
     from laghos_amd import host_lib
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
     args = ["-p", problem, "-dim", 3, "-nx", nel[0], "-ny", nel[1], "-nz", nel[2], "-Sx", 1, "-Sy", 1, "-Sz", 1, "-rs", 0,
-            "-ok", 3, "-ot", 2, "-pa", "-tf", 0.6, "-ms", 6, "-q"]
+            "-ok", order[0], "-ot", order[1], "-pa", "-tf", 0.6, "-ms", 6 if order == (3, 2) else 3, "-q"]
     ref = host_lib.Sim(args)
     ref.enable_timers(timers)
     while ref.step() == 1:
