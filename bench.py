@@ -27,7 +27,8 @@ sys.path.insert(0, ROOT)
 # GPU boxes; kept for environments built by hand)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_ACHIEVABLE_GBS = 6290.0  # same guide: what a float4 copy kernel reaches (79 % of the spec)
 
 
 def flush_c_stdio():
@@ -92,6 +93,16 @@ def usable_cpus():
     return max(1, n)
 
 
+def cpu_model():
+    try:
+        for l in open("/proc/cpuinfo"):
+            if l.startswith("model name"):
+                return l.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(threads):
     """The oracle (CPU restatement of the reference -pa path) timed on the host
     cores on a bounded sample of the same 32^3 Q3/Q2 Sedov workload: whole RK4
@@ -121,7 +132,7 @@ def cpu_baseline(threads):
     dofs = prob.dim * prob.N + prob.L2V
     tm = h.timers()
     h.close()
-    return dict(value=1e-6 * dofs * 4 * steps / wall, unit="Mdofs*steps/s", cores=threads, kind="port",
+    return dict(value=1e-6 * dofs * 4 * steps / wall, unit="Mdofs*steps/s", cores=threads, cpu_model=cpu_model(), kind="port",
                 sample="%d RK4 steps from t=0 of the same 3D Sedov Q3Q2 32^3 problem (oracle/ C++ kernels, "
                        "OpenMP %d threads), %.1f s" % (steps, threads, wall),
                 seconds=wall, rk4_steps=steps, h1_cg_iters=tm["H1iter"])
@@ -130,7 +141,18 @@ def cpu_baseline(threads):
 KERNEL_NAMES = {0: "vcg_apply_plane (H1 CG K1, 3 velocity components per launch)",
                 1: "vcg_update_k (H1 CG K2, 3 velocity components per launch)",
                 2: "qpoint_kernel (fused QUpdate)", 3: "force_mult_3d", 4: "force_mult_t_3d",
-                5: "mass_apply_3d (L2 CG K1)"}
+                5: "mass_apply_3d (L2 CG K1)",
+                6: "halo_sum (pack + grouped ncclSend/Recv + combine)", 7: "ncclAllReduce of device scalars"}
+K1_FORMS = {0: "vcg_apply_3d", 2: "vcg_apply_plane", 3: "vcg_apply_mfma346", 4: "vcg_apply_slab346"}
+
+
+def kernel_names(L, ctx):
+    """KERNEL_NAMES with the K1 form this context really launches (lgh_k1_form)"""
+    f = ctypes.c_int(-2)
+    L.lgh_k1_form(ctx, ctypes.byref(f))
+    names = dict(KERNEL_NAMES)
+    names[0] = K1_FORMS.get(f.value, "vcg_apply") + " (H1 CG K1, 3 velocity components per launch)"
+    return names
 
 
 def algorithmic_bytes(sz):
@@ -155,6 +177,7 @@ def measure_kernels(sim, sz):
     L = _lib.load()
     ctx = sim.L.laghos_sim_context(sim.h)
     bts = algorithmic_bytes(sz)
+    KERNEL_NAMES = kernel_names(L, ctx)
     kern, raw = {}, {}
     for kid in (0, 1, 2, 3, 4, 5):
         # In production the two force products come out of the fused QUpdate; the ForcePAOperator kernels are
@@ -178,7 +201,7 @@ def measure_kernels(sim, sz):
         t = sum(raw[k][0] * raw[k][1] for k in ids)
         return {"kernels": [KERNEL_NAMES[k].split(" ")[0] for k in ids], "launches_per_rk_step": {KERNEL_NAMES[k].split(" ")[0]: raw[k][0] for k in ids},
                 "algorithmic_bytes_per_rk_step": b, "seconds_per_rk_step": t, "achieved": 1e-9 * b / t,
-                "frac": 1e-9 * b / t / HBM_PEAK_GBS}
+                "frac": 1e-9 * b / t / HBM_PEAK_GBS, "frac_of_achievable": 1e-9 * b / t / HBM_ACHIEVABLE_GBS}
     # north_star: "Force+Mass operator apply" = ForceMult + ForceMultTranspose + the mass applies of the H1 CG (K1);
     # the node kernel of the CG (K2) listed with it in a second figure
     agg = {"force_mass_aggregate": aggregate((3, 4, 0)), "force_mass_cg_aggregate": aggregate((3, 4, 0, 1)),
@@ -186,26 +209,60 @@ def measure_kernels(sim, sz):
     return kern, agg
 
 
-def pmc_traffic():
-    """HBM-side bytes per K1 launch from the committed rocprofv3 PMC passes - only if they were taken with the
-    K1 source this build has (profiles/pmc_traffic.json records the sha256 of lgh_vcg.hip); otherwise null."""
+def measure_comm(sim, world):
+    """What the exchanges cost: HIP-event time of every halo exchange / all-reduce of one RK step (library stream),
+    messages per step, size of the largest message.  Several ranks, or the N-rank code path on one (LGH_FORCE_MULTI)."""
+    from laghos_amd import _lib
+    L = _lib.load()
+    ctx = sim.L.laghos_sim_context(sim.h)
+    out = {}
+    for kid, key in ((6, "halo_exchange"), (7, "allreduce")):
+        _lib.check(L.lgh_ktime_begin(ctx, kid, 8192))
+        sim.step()
+        n, mean = ctypes.c_int(), ctypes.c_double()
+        _lib.check(L.lgh_ktime_end(ctx, ctypes.byref(n), ctypes.byref(mean)))
+        out[key] = {"per_rk_step": n.value, "mean_us": 1e6 * mean.value if n.value else None}
+    nn, ap, c2 = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    mx, sh = ctypes.c_long(), ctypes.c_long()
+    _lib.check(L.lgh_comm_stats(ctx, ctypes.byref(nn), ctypes.byref(mx), ctypes.byref(sh), ctypes.byref(ap), ctypes.byref(c2)))
+    out.update({"neighbours": nn.value, "largest_message_bytes_3_components": 3 * 8 * mx.value, "shared_nodes": sh.value,
+                "all_pairs_partition": bool(ap.value), "second_channel": bool(c2.value), "ranks": world})
+    return out
+
+
+def k1_sources_sha():
     import hashlib
-    pj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    src = os.path.join(ROOT, "laghos_amd", "csrc", "lgh_vcg.hip")
+    h = hashlib.sha256()
+    for f in ("lgh_vcg.hpp", "lgh_vcg.hip", "lgh_vcg_slab.hip"):
+        h.update(open(os.path.join(ROOT, "laghos_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(workload="c2"):
+    """Memory-side bytes per K1 launch from the committed rocprofv3 PMC passes (profiles/r3_pmc_traffic.json, written by
+    tools/update_pmc_traffic.py) - only if they were taken with the K1 sources this build has; otherwise null."""
+    pj = os.path.join(ROOT, "profiles", "r3_pmc_traffic.json")
     try:
         d = json.load(open(pj))
-        sha = hashlib.sha256(open(src, "rb").read()).hexdigest()[:16]
-        if d.get("kernel_source_sha16") == sha:
-            return d.get("mass_apply_cg_h1_bytes_per_launch"), "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of lgh_vcg.hip@%s)" % sha
-        return None, "profiles/pmc_traffic.json is from another build of lgh_vcg.hip (%s != %s): not reported" % (d.get("kernel_source_sha16"), sha)
+        sha = k1_sources_sha()
+        if d.get("k1_sources_sha16") != sha:
+            return None, "profiles/r3_pmc_traffic.json is from another build of the K1 sources (%s != %s): not reported" % (d.get("k1_sources_sha16"), sha)
+        w = d["workloads"][workload]
+        return w["k1_bytes_per_launch"], ("profiles/r3_pmc_traffic.json[%s] (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, 2*FETCH + WRITE per "
+                                          "launch of %s, K1 sources @%s)" % (workload, w["k1_kernel"], sha))
     except Exception as e:
         return None, "unavailable: %r" % (e,)
 
 
-def run_leg(host_lib, args, steps, warmup, dev):
+def run_leg(host_lib, args, steps, warmup, dev, force_multi=False):
     """One extra single-GPU workload (a BASELINE.json config other than the one `value` is quoted on)."""
     import torch
-    sim = host_lib.Sim(args + ["-dev", dev, "-q"])
+    if force_multi:
+        os.environ["LGH_FORCE_MULTI"] = "1"  # read by the host layer when it builds the operator
+    try:
+        sim = host_lib.Sim(args + ["-dev", dev, "-q"])
+    finally:
+        os.environ.pop("LGH_FORCE_MULTI", None)
     sim.enable_timers(False)
     sz = sim.sizes()
     for _ in range(warmup):
@@ -225,7 +282,10 @@ def run_leg(host_lib, args, steps, warmup, dev):
     out = {"value": 1e-6 * dofs * 4 * rk / wall, "unit": "Mdofs*steps/s", "ms_per_step": 1e3 * wall / steps, "steps": steps,
            "elements": sz["global_NE"], "h1_dofs": sz["H1GTV"], "l2_dofs": sz["L2GTV"], "e_norm": sim.e_norm(), "t": sim.t,
            "kernels": {k: {"mean_us": v["mean_us"], "GBs": v["GBs"], "launches": v["launches"]} for k, v in kern.items()}}
-    out.update({k: ({"achieved": v["achieved"], "frac": v["frac"]} if isinstance(v, dict) else v) for k, v in agg.items()})
+    out.update({k: ({"achieved": v["achieved"], "frac": v["frac"], "frac_of_achievable": v["frac_of_achievable"]} if isinstance(v, dict) else v)
+                for k, v in agg.items()})
+    if force_multi:
+        out["comm"] = measure_comm(sim, 1)
     sim.close()
     return out
 
@@ -241,6 +301,22 @@ WORKLOADS = {
     "tg": (["-m", "data/cube01_hex.mesh", "-rs", 5, "-p", 0],
            "3D Taylor-Green -p 0 -m cube01_hex -rs 5 -ok 3 -ot 2 -pa (64^3 elements, visc off)"),
 }
+# further legs of the default run (never the headline):
+#  c5     BASELINE.json configs[4] on one GPU: 3D triple point Q5/Q4, 65 536 zones (the high-order kernels)
+#  c2dev  configs[1] after 300 time steps: the QUpdate on a developed flow (the timed window of `value` starts at t = 0,
+#         where its eigen-decomposition shortcut is at its most favourable)
+#  c2multi configs[1] through the N-rank code path on one rank (LGH_FORCE_MULTI=1: real RCCL calls on a communicator of
+#         size 1): what the multi-rank sequencing itself costs
+LEGS = {
+    "c3": dict(args=WORKLOADS["c3"][0], order=(3, 2), steps=5, warmup=2, workload=WORKLOADS["c3"][1]),
+    "tg": dict(args=WORKLOADS["tg"][0], order=(3, 2), steps=5, warmup=2, workload=WORKLOADS["tg"][1]),
+    "c5": dict(args=["-m", "data/box01_hex.mesh", "-rs", 4, "-p", 3], order=(5, 4), steps=2, warmup=1,
+               workload="3D triple point -p 3 -m box01_hex -rs 4 -ok 5 -ot 4 -pa (65 536 zones, Q5/Q4; BASELINE config 5 on one GPU)"),
+    "c2dev": dict(args=WORKLOADS["c2"][0], order=(3, 2), steps=10, warmup=300,
+                  workload=WORKLOADS["c2"][1] + ", after 300 time steps (developed flow)"),
+    "c2multi": dict(args=WORKLOADS["c2"][0], order=(3, 2), steps=10, warmup=3, force_multi=True,
+                    workload=WORKLOADS["c2"][1] + ", N-rank code path on one rank (LGH_FORCE_MULTI=1, RCCL communicator of size 1)"),
+}
 
 
 def main():
@@ -252,7 +328,10 @@ def main():
                     help="single-GPU workload `value` is measured on (default: BASELINE.json configs[1])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--no-legs", action="store_true", help="skip the extra 64^3 Sedov / Taylor-Green legs")
+    ap.add_argument("--no-legs", action="store_true", help="skip the extra legs (64^3 Sedov / Taylor-Green, Q5Q4, developed flow, N-rank path)")
+    ap.add_argument("--legs", default="c3,tg,c5,c2dev,c2multi", help="comma-separated extra legs of a single-GPU run")
+    ap.add_argument("--watchdog", type=float, default=900.0,
+                    help="several ranks: seconds a rank may spend without finishing a step before it reports and exits (a mismatched collective would otherwise hang silently)")
     a = ap.parse_args()
 
     import torch
@@ -308,13 +387,36 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
+    # several ranks: a collective that does not match on all ranks blocks inside a stream synchronisation that nothing
+    # can interrupt; the watchdog turns that into a rank-tagged message and a non-zero exit instead of a silent hang
+    progress = {"where": "start", "t": time.time()}
+
+    def mark(where):
+        progress["where"], progress["t"] = where, time.time()
+
+    def watchdog():
+        while not progress.get("done"):
+            time.sleep(2.0)
+            if time.time() - progress["t"] > a.watchdog:
+                sys.stderr.write("[bench.py rank %d/%d] no progress for %.0f s in '%s' - a collective probably does not match "
+                                 "across the ranks (try LGH_COMM2=0 LGH_HALO_PIGGYBACK=0); giving up\n" % (rank, world, a.watchdog, progress["where"]))
+                sys.stderr.flush()
+                os._exit(3)
+    if world > 1:
+        import threading
+        threading.Thread(target=watchdog, daemon=True).start()
+
+    for i in range(a.warmup):
+        mark("warm-up step %d" % i)
         sim.step()
+    mark("barrier after warm-up")
     barrier()
     rk0 = sim.rk_steps
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    for i in range(a.steps):
+        mark("timed step %d" % i)
         sim.step()
+    mark("barrier after the timed steps")
     barrier()
     wall = time.perf_counter() - t0
     if dist is not None:
@@ -363,32 +465,44 @@ def main():
                 "seconds": {k: tm[k] for k in ("cgH1", "cgL2", "force", "qdata")},
             }
         sim.enable_timers(False)
+        mark("per-kernel timing")
         kern, agg = measure_kernels(sim, sz)
-        dom = kern.get(KERNEL_NAMES[0])
+        k1_name = [k for k in kern if k.startswith("vcg_apply")]
+        dom = kern.get(k1_name[0]) if k1_name else None
         if dom:
-            traffic, traffic_source = pmc_traffic() if (world == 1 and a.workload == "c2") else (None, "not collected for this workload")
-            out["roofline"] = {"bound": "hbm", "kernel": KERNEL_NAMES[0], "achieved": dom["GBs"], "peak": HBM_PEAK_GBS,
-                               "unit": "GB/s", "frac": dom["GBs"] / HBM_PEAK_GBS, "traffic": traffic,
-                               "traffic_source": traffic_source,
+            traffic, traffic_source = pmc_traffic(a.workload) if (world == 1 and a.workload in ("c2", "c3")) else (None, "not collected for this workload")
+            out["roofline"] = {"bound": "hbm", "kernel": k1_name[0], "achieved": dom["GBs"], "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": dom["GBs"] / HBM_PEAK_GBS,
+                               "achievable": HBM_ACHIEVABLE_GBS, "frac_of_achievable": dom["GBs"] / HBM_ACHIEVABLE_GBS,
+                               "traffic": traffic, "traffic_source": traffic_source,
                                "mean_launch_us": dom["mean_us"], "launches_sampled": dom["launches"],
                                "algorithmic_bytes_per_launch": dom["algorithmic_bytes"]}
             out["roofline"].update(agg)
         out["kernels"] = kern
+        if world > 1 or os.environ.get("LGH_FORCE_MULTI") == "1":
+            mark("exchange timing")
+            out["comm"] = measure_comm(sim, world)
+    progress["done"] = True
     sim.close()
 
-    # ---- the other single-GPU configs of BASELINE.json as short extra legs (not part of `value`)
+    # ---- the other single-GPU configs of BASELINE.json (and two views of configs[1]) as short extra legs, not part of `value`
     if world == 1 and not a.no_legs and not a.no_roofline:
         legs = {}
-        for name in ("c3", "tg"):
+        for name in [n for n in a.legs.split(",") if n in LEGS]:
             if name == a.workload:
                 continue
+            leg = LEGS[name]
             try:
-                largs, lwork = WORKLOADS[name]
-                legs[name] = run_leg(host_lib, list(largs) + ["-ok", 3, "-ot", 2, "-pa", "-tf", 1e9, "-ms", 10 ** 6, "-vs", 10 ** 9],
-                                     steps=5, warmup=2, dev=local_rank)
-                legs[name]["workload"] = lwork
+                largs = list(leg["args"]) + ["-ok", leg["order"][0], "-ot", leg["order"][1], "-pa", "-tf", 1e9, "-ms", 10 ** 6, "-vs", 10 ** 9]
+                legs[name] = run_leg(host_lib, largs, steps=leg["steps"], warmup=leg["warmup"], dev=local_rank, force_multi=leg.get("force_multi", False))
+                legs[name]["workload"] = leg["workload"]
+                if name == "c3":
+                    t, src = pmc_traffic("c3")
+                    legs[name]["roofline_traffic"] = {"k1_bytes_per_launch": t, "source": src}
             except Exception as e:  # an extra leg must not cost the headline number
                 legs[name] = {"error": repr(e)}
+        if "c2multi" in legs and "value" in legs["c2multi"]:
+            legs["c2multi"]["ms_per_step_minus_single_rank_path"] = legs["c2multi"]["ms_per_step"] - out["ms_per_step"]
         out["legs"] = legs
 
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

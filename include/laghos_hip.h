@@ -244,6 +244,8 @@ int lgh_enable_timers(lgh_ctx *ctx, int on);
 #define LGH_KERNEL_FORCE_MULT 3
 #define LGH_KERNEL_FORCE_MULT_T 4
 #define LGH_KERNEL_MASS_CG_L2 5
+#define LGH_KERNEL_HALO 6         /* one shared-node / scalar exchange over RCCL: pack, grouped send/recv, combine */
+#define LGH_KERNEL_ALLREDUCE 7    /* one ncclAllReduce of device scalars */
 int lgh_ktime_begin(lgh_ctx *ctx, int which, int max_samples);
 int lgh_ktime_end(lgh_ctx *ctx, int *launches, double *mean_seconds);
 /* Whether lgh_create found the 1-D H1 / L2 tables mirror symmetric, B[q,d] = B[Q-1-q, D-1-d] (any nodal or
@@ -267,6 +269,11 @@ int lgh_comm_unique_id(char id_out[128]);
 int lgh_comm_init(lgh_ctx *ctx, int nranks, int rank, const char unique_id[128]);
 int lgh_comm_set_neighbors(lgh_ctx *ctx, int n_nbr, const int *nbr_rank, const int *nbr_count,
                            const int *const *nbr_nodes);
+/* What the exchanges of this rank look like (bench.py's `comm` block): neighbours, nodes of the largest message,
+ * distinct shared nodes, whether every rank neighbours every other (sums then ride on the halo messages) and
+ * whether the second channel (energy solve beside the velocity solve) is up. */
+int lgh_comm_stats(lgh_ctx *ctx, int *n_neighbours, long *max_nodes_per_neighbour, long *shared_nodes, int *all_pairs,
+                   int *second_channel);
 /* Host helper (no GPU, no context): the `owner` mask of lgh_config and the neighbour lists of
  * lgh_comm_set_neighbors from a description of the shared dofs by GROUPS - the form in which MFEM holds them
  * (ParFiniteElementSpace::GroupComm(): GroupTopology = the rank set and master of every group,

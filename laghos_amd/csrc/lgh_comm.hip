@@ -251,6 +251,7 @@ int halo_sum(lgh_ctx *c, double *v, int ncomp, double *extra, int nextra)
    double *const sbuf = ch2 ? cm->sendbuf2 : cm->sendbuf;
    double *const rbuf = ch2 ? cm->recvbuf2 : cm->recvbuf;
    const ncclComm_t ncomm = ch2 ? cm->comm2 : cm->comm;
+   kt_begin(c, LGH_KERNEL_HALO); // (sampling on: one event pair around pack + exchange + combine)
    // ncomp == 0 (v unused): the messages carry the scalars only - a sum over the ranks as one
    // exchange with every peer (allreduce_dev uses it in all-pairs partitions)
    const long npack = std::max((long)tot * ncomp, (long)cm->n_nbr * nx);
@@ -286,6 +287,7 @@ int halo_sum(lgh_ctx *c, double *v, int ncomp, double *extra, int nextra)
       if (!g->barrier()) { set_error("local communicator: barrier timed out (halo)"); return LGH_ERR_COMM; } // peers may repack
       combine();
       LGH_HIP_CHECK(hipGetLastError());
+      kt_end(c, LGH_KERNEL_HALO);
       return LGH_OK;
    }
    LGH_NCCL_CHECK(g_nccl.GroupStart());
@@ -299,6 +301,7 @@ int halo_sum(lgh_ctx *c, double *v, int ncomp, double *extra, int nextra)
    LGH_NCCL_CHECK(g_nccl.GroupEnd());
    combine();
    LGH_HIP_CHECK(hipGetLastError());
+   kt_end(c, LGH_KERNEL_HALO);
    return LGH_OK;
 }
 
@@ -352,8 +355,10 @@ int allreduce_dev(lgh_ctx *c, double *dev, int count, int op)
    }
    if (!cm || !cm->comm) { return LGH_OK; }
    if (c->on_stream2 && !cm->comm2) { set_error("all-reduce on the second stream without a second communicator"); return LGH_ERR_COMM; }
+   kt_begin(c, LGH_KERNEL_ALLREDUCE);
    LGH_NCCL_CHECK(g_nccl.AllReduce(dev, dev, (size_t)count, ncclFloat64, op == 0 ? ncclSum : ncclMin,
                                    c->on_stream2 ? cm->comm2 : cm->comm, c->stream));
+   kt_end(c, LGH_KERNEL_ALLREDUCE);
    return LGH_OK;
 }
 
@@ -486,6 +491,20 @@ int lgh_comm_init(lgh_ctx *c, int nranks, int rank, const char unique_id[128])
       if (!cm->channel2 && cm->comm2) { g_nccl.CommDestroy(cm->comm2); cm->comm2 = nullptr; }
    }
    vcg_free(c); // the tables of the node kernel K2 carry the shared-node / owner flags of the previous communicator
+   return LGH_OK;
+}
+
+int lgh_comm_stats(lgh_ctx *c, int *n_neighbours, long *max_nodes_per_neighbour, long *shared_nodes, int *all_pairs, int *second_channel)
+{
+   LGH_CHECK_ARG(c && n_neighbours && max_nodes_per_neighbour && shared_nodes && all_pairs && second_channel);
+   const Comm *cm = c->comm;
+   *n_neighbours = cm ? cm->n_nbr : 0;
+   long mx = 0;
+   if (cm) { for (int k = 0; k < cm->n_nbr; k++) { mx = std::max(mx, (long)cm->nbr_count[k]); } }
+   *max_nodes_per_neighbour = mx;
+   *shared_nodes = cm ? cm->n_shared : 0;
+   *all_pairs = (cm && cm->allpairs) ? 1 : 0;
+   *second_channel = (cm && cm->channel2) ? 1 : 0;
    return LGH_OK;
 }
 
