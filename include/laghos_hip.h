@@ -79,6 +79,12 @@ double *lgh_qdata_stressJinvT(lgh_ctx *ctx);
 double *lgh_qdata_Jac0inv(lgh_ctx *ctx);
 double *lgh_qdata_rho0DetJ0w(lgh_ctx *ctx);
 double *lgh_mass_D(lgh_ctx *ctx);
+/* Form of the mass quadrature data the plane / slab mass kernels read: 1 = compact, D[q, e] = W[q] s_e (the data of
+ * laghos_assembly.cpp:92-95 whenever rho0 detJ0 is constant within each element - every benchmark mesh of
+ * BASELINE.json; the kernels then read one double per element instead of NQ), 0 = the stored table.  The test is made
+ * on the device (every entry to 1e-12 relative, the size of the rounding of the stored entries; LGH_MASS_RANK1_TOL) at the first mass apply after lgh_setup_rho0detj0() or after lgh_mass_D() was
+ * called: a caller that writes through the lgh_mass_D() pointer calls lgh_mass_D() again after its last write. */
+int lgh_mass_data_form(lgh_ctx *ctx, int *form);
 double *lgh_mass_diag(lgh_ctx *ctx); /* Jacobi diagonal of the scalar H1 mass (N) */
 int lgh_set_h0(lgh_ctx *ctx, double h0);
 int lgh_get_h0(lgh_ctx *ctx, double *h0);

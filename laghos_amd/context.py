@@ -172,6 +172,12 @@ class Context:
     def massD(self):
         return self._view(self.lib.lgh_mass_D(self.h), self.NE * self.NQ)
 
+    @massD.setter
+    def massD(self, arr):
+        """overwrite the mass quadrature data (lgh_mass_D is called again after the write: its contract)"""
+        self._write(self.lib.lgh_mass_D(self.h), np.ascontiguousarray(arr, dtype=np.float64))
+        self.lib.lgh_mass_D(self.h)
+
     @property
     def mass_diag(self):
         return self._view(self.lib.lgh_mass_diag(self.h), self.N)
@@ -232,6 +238,12 @@ class Context:
         f = ctypes.c_int(-2)
         check(self.lib.lgh_k1_form(self.h, ctypes.byref(f)))
         return {0: "column", 2: "plane", 3: "mfma", 4: "slab"}.get(f.value)
+
+    def mass_data_form(self):
+        """'rank1' when the mass kernels read D[q, e] = W[q] s_e (one double per element), 'stored' otherwise."""
+        f = ctypes.c_int(-1)
+        check(self.lib.lgh_mass_data_form(self.h, ctypes.byref(f)))
+        return "rank1" if f.value == 1 else "stored"
 
     def set_fused_forces(self, on):
         check(self.lib.lgh_set_fused_forces(self.h, 1 if on else 0))

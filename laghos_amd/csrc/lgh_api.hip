@@ -350,6 +350,7 @@ static int create_impl(const lgh_config *cfg, lgh_ctx *c, const int kid)
          LGH_TRY(dev_alloc_zero(&c->v_snap, (size_t)c->H1V));
       }
       LGH_TRY(dev_alloc_zero(&c->dev_flags, (size_t)4));
+      c->mass_rank1 = -1;
       env = getenv("LGH_FUSED_F1");              // A/B: 0 = F.1 always by its own kernel
       if (c->dim == 3 && !(env && env[0] == '0')) { LGH_TRY(dev_alloc_zero(&c->force_e_q, nmap * dim + (size_t)dim * c->ND)); } // (+ a zero element: vcg_init_force_z_k)
    }
@@ -384,7 +385,7 @@ int lgh_destroy(lgh_ctx *c)
    void *ptrs[] = {c->B, c->G, c->Bl, c->W, c->gamma, c->h1map, c->t_off, c->t_idx, c->t_ell, c->essmask[0],
                    c->essmask[1], c->essmask[2], c->ess[0], c->ess[1], c->ess[2], c->owner,
                    c->stressJinvT, c->Jac0inv, c->Jac0inv_soa, c->rho0DetJ0w, c->massD, c->diagV, c->dinvV,
-                   c->dt_est_dev, c->erhs_q, c->v_snap, c->dev_flags, c->ones_l2, c->force_e_q, c->XE, c->YE, c->cg_r, c->cg_z, c->cg_d0, c->cg_d1, c->cg_y,
+                   c->dt_est_dev, c->erhs_q, c->v_snap, c->dev_flags, c->ones_l2, c->massS, c->ones_ne, c->force_e_q, c->XE, c->YE, c->cg_r, c->cg_z, c->cg_d0, c->cg_d1, c->cg_y,
                    c->partials, c->tickets, c->cgs, c->scal, c->vcg_s, c->vcg_vec, c->vcg_partials,
                    c->vcg_tickets};
    for (void *p : ptrs) { if (p) { (void)hipFree(p); } }
@@ -466,7 +467,21 @@ int lgh_quadrature_generation(lgh_ctx *c, unsigned long *gen, int *f1_valid, int
 }
 double *lgh_qdata_Jac0inv(lgh_ctx *c) { return c->Jac0inv; }
 double *lgh_qdata_rho0DetJ0w(lgh_ctx *c) { return c->rho0DetJ0w; }
-double *lgh_mass_D(lgh_ctx *c) { return c->massD; }
+double *lgh_mass_D(lgh_ctx *c)
+{
+   c->mass_rank1 = -1; // (the caller may write through this pointer: the compact form of the mass data is looked for again)
+   return c->massD;
+}
+int lgh_mass_data_form(lgh_ctx *c, int *form)
+{
+   LGH_CHECK_ARG(c && form);
+   const double *Dq, *Se;
+   int dqs;
+   int rc = mass_data(c, &Dq, &dqs, &Se);
+   if (rc) { return rc; }
+   *form = (c->mass_rank1 == 1) ? 1 : 0;
+   return LGH_OK;
+}
 double *lgh_mass_diag(lgh_ctx *c) { return c->diagV; }
 int lgh_set_h0(lgh_ctx *c, double h0) { LGH_CHECK_ARG(c); c->h0 = h0; return LGH_OK; }
 int lgh_get_h0(lgh_ctx *c, double *h0) { LGH_CHECK_ARG(c && h0); *h0 = c->h0; return LGH_OK; }
@@ -492,6 +507,7 @@ int lgh_setup_rho0detj0(lgh_ctx *c, const double *x0, const double *rho0_l2, con
 {
    LGH_CHECK_ARG(c && x0 && rho0_l2 && rho0_q && volume);
    invalidate_fused(c);
+   c->mass_rank1 = -1; // (new mass data)
    int rc = setup_rho0detj0(c, x0, rho0_l2, rho0_q, volume);
    if (rc) { return rc; }
    return mass_assemble_diag(c);

@@ -110,6 +110,12 @@ struct lgh_ctx
    // QuadratureData + mass PA data
    double *stressJinvT, *Jac0inv, *rho0DetJ0w, *massD, *diagV, *dinvV;
    double *Jac0inv_soa;  // plane-major copy of Jac0inv for coalesced reads in QUpdate
+   // Rank-1 form of the mass data: where detJ0 and rho0 are constant inside every element (affine elements, piecewise
+   // constant density - every mesh and problem of data/), massD[q + NQ e] = W[q] * massS[e] to the last bit or two;
+   // the mass kernels then read 8 bytes per element instead of 8 NQ.  -1: not looked at yet (set-up, lgh_mass_D handed
+   // out), 0: no (massD as stored), 1: yes (lgh_mass.hip mass_data).  LGH_MASS_RANK1=0 keeps massD.
+   double *massS, *ones_ne;
+   int mass_rank1;
    double *dt_est_dev;   // 1 double: running min of the point-wise estimate
    // Force products formed inside the fused QUpdate.  Validity is by construction, not by address: `fused_*_valid` says
    // that the product belongs to the quadrature data as it stands (set by lgh_qupdate, cleared by everything that can
@@ -406,6 +412,8 @@ int mass_apply_h1(lgh_ctx *c, const double *x, double *y, bool eliminate);
 int mass_apply_l2(lgh_ctx *c, const double *x, double *y);
 int mass_apply_E(lgh_ctx *c, int space, const double *xE, double *yE);
 int mass_assemble_diag(lgh_ctx *c);
+// the quadrature data of the mass operators as (table, element stride in doubles, per-element factor): value(q, e) = Dq[q + dqs e] * Se[e]
+int mass_data(lgh_ctx *c, const double **Dq, int *dqs, const double **Se);
 int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, int iters[3],
               const double *force_E = nullptr);
 bool vcg_fused_init_ok(const lgh_ctx *c);

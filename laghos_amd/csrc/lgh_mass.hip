@@ -38,7 +38,9 @@ struct MassArgs
 {
    int NE;
    const double *B;   // [q + Q*d]
-   const double *Dq;  // [q + NQ*e]
+   const double *Dq;  // [q + NQ*e] - mass_apply_l2_plane: value(q, e) = Dq[q + dqs e] * Se[e] (mass_data)
+   const double *Se;
+   int dqs;
    const double *x;   // MODE 0/1 input; MODE 2/3: z (H1) or r (L2)
    const int *map;    // NE*ND or null
    double *y;         // E-vector (H1) or L2 vector output
@@ -332,10 +334,11 @@ mass_apply_l2_plane(const MassArgs a)
       }
    }
    // first row of this thread's quadrature data, in flight across the barrier
-   const double *Dp = a.Dq + (size_t)(active ? e : 0) * NQ + qx + Q * (h * QH);
+   const double *Dp = a.Dq + (size_t)(active ? e : 0) * a.dqs + qx + Q * (h * QH);
+   const double se = a.Se[active ? e : 0];
    double dq[Q];
 #pragma unroll
-   for (int qz = 0; qz < Q; qz++) { dq[qz] = Dp[Q * Q * qz]; }
+   for (int qz = 0; qz < Q; qz++) { dq[qz] = Dp[Q * Q * qz] * se; }
    __syncthreads();
    const double *sI = sIn + eb * CS;
    // the 1-D table in scalar registers, in half: the Bernstein basis at Gauss-Legendre points is mirror symmetric,
@@ -371,7 +374,7 @@ mass_apply_l2_plane(const MassArgs a)
       if (r + 1 < QH)
       {
 #pragma unroll
-         for (int qz = 0; qz < Q; qz++) { dn[qz] = Dp[Q * (r + 1) + Q * Q * qz]; }
+         for (int qz = 0; qz < Q; qz++) { dn[qz] = Dp[Q * (r + 1) + Q * Q * qz] * se; }
       }
       // the table row of qy = h*QH + r (h differs between lanes: select, not index)
       double by[L];
@@ -568,8 +571,9 @@ static int unknown_kernel(int id)
 
 template <int Q> constexpr int neb_for() { return (256 / (Q * Q)) > 0 ? (256 / (Q * Q)) : 1; }
 
-template <int MODE> static int launch_mass(lgh_ctx *c, int space, const MassArgs &a)
+template <int MODE> static int launch_mass(lgh_ctx *c, int space, const MassArgs &a0)
 {
+   const MassArgs &a = a0;
    const int n1d = (space == LGH_SPACE_H1) ? c->D1D : c->L1D;
    const int id = (c->dim << 8) | (n1d << 4) | c->Q1D;
 #define LGH_MASS_CASE(DIMK, D_, Q_)                                                           \
@@ -585,6 +589,9 @@ template <int MODE> static int launch_mass(lgh_ctx *c, int space, const MassArgs
       constexpr int M = (MODE == 3 ? 3 : 0);
       if (!(penv && penv[0] == '0'))
       {
+         MassArgs a = a0; // (the plane form takes the mass data in its compact form where it has one)
+         const int rc_md = mass_data(c, &a.Dq, &a.dqs, &a.Se);
+         if (rc_md) { return rc_md; }
          if (id == 0x336) { hipLaunchKernelGGL((mass_apply_l2_plane<3, 6, 1, 42, M>), dim3(ceil_div(c->NE, 42)), dim3(252), 0, c->stream, a); }
          else if (id == 0x348) { hipLaunchKernelGGL((mass_apply_l2_plane<4, 8, 1, 32, M>), dim3(ceil_div(c->NE, 32)), dim3(256), 0, c->stream, a); }
          else { hipLaunchKernelGGL((mass_apply_l2_plane<5, 10, 2, 12, M>), dim3(ceil_div(c->NE, 12)), dim3(240), 0, c->stream, a); }
@@ -621,13 +628,59 @@ template <int MODE> static int launch_mass(lgh_ctx *c, int space, const MassArgs
    return LGH_OK;
 }
 
+// D[q, e] = W[q] s_e ?  In exact arithmetic the data of laghos_assembly.cpp:92-95, w_q detJ0(x_q) rho0(x_q), has this
+// form whenever the initial element is affine and rho0 constant in it; the stored entries carry the rounding of the
+// Jacobian and density evaluation at each point (measured: 220 ulp at Q3Q2 on the 8^3 box mesh, it grows like 1 / h).
+// One thread per element: s_e = mean of D / W over the points (the centre of that rounding cloud), every point within
+// tol (relative; kMassRank1Tol unless LGH_MASS_RANK1_TOL) or the stored table stays in use.
+constexpr double kMassRank1Tol = 1e-12;
+__global__ void __launch_bounds__(256)
+mass_rank1_k(const int NE, const int NQ, const double tol, const double *__restrict__ D, const double *__restrict__ W, double *__restrict__ S,
+             double *__restrict__ ones, int *flag)
+{
+   const int e = blockIdx.x * blockDim.x + threadIdx.x;
+   if (e >= NE) { return; }
+   const double *De = D + (size_t)e * NQ;
+   double s = 0.0;
+   for (int q = 0; q < NQ; q++) { s += De[q] / W[q]; }
+   s /= NQ;
+   bool ok = isfinite(s);
+   for (int q = 0; q < NQ; q++) { ok = ok && fabs(De[q] - W[q] * s) <= tol * fabs(De[q]); }
+   S[e] = s;
+   ones[e] = 1.0;
+   if (!ok) { *flag = 1; }
+}
+int mass_data(lgh_ctx *c, const double **Dq, int *dqs, const double **Se)
+{
+   if (c->mass_rank1 < 0)
+   {
+      if (!c->massS)
+      {
+         LGH_HIP_CHECK(hipMalloc((void **)&c->massS, sizeof(double) * (size_t)c->NE));
+         LGH_HIP_CHECK(hipMalloc((void **)&c->ones_ne, sizeof(double) * (size_t)c->NE));
+      }
+      int *flag = c->dev_flags + 3, h = 1;
+      LGH_HIP_CHECK(hipMemsetAsync(flag, 0, sizeof(int), c->stream));
+      const char *tenv = getenv("LGH_MASS_RANK1_TOL");
+      const double tol = tenv ? atof(tenv) : kMassRank1Tol;
+      hipLaunchKernelGGL(mass_rank1_k, dim3(ceil_div(c->NE, 256)), dim3(256), 0, c->stream, c->NE, c->NQ, tol, c->massD, c->W, c->massS, c->ones_ne, flag);
+      LGH_HIP_CHECK(hipMemcpyAsync(&h, flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+      LGH_HIP_CHECK(hipStreamSynchronize(c->stream));
+      const char *env = getenv("LGH_MASS_RANK1");
+      c->mass_rank1 = (h == 0 && !(env && env[0] == '0')) ? 1 : 0;
+   }
+   if (c->mass_rank1 == 1) { *Dq = c->W; *dqs = 0; *Se = c->massS; }
+   else { *Dq = c->massD; *dqs = c->NQ; *Se = c->ones_ne; }
+   return LGH_OK;
+}
+
 static MassArgs base_args(lgh_ctx *c, int space)
 {
    MassArgs a;
    memset(&a, 0, sizeof(a));
    a.NE = c->NE;
    a.B = (space == LGH_SPACE_H1) ? c->B : c->Bl;
-   a.Dq = c->massD;
+   a.Dq = c->massD; // (every kernel but mass_apply_l2_plane reads the stored table; launch_mass fills Se / dqs)
    return a;
 }
 

@@ -94,7 +94,7 @@ vcg_apply_3d(const VcgArgs a, const int nbatch)
       }
       if (e < a.NE)
       {
-         const double *p = a.Dq + (size_t)e * NQ + tx + Q * ty;
+         const double *p = a.DqFull + (size_t)e * NQ + tx + Q * ty;
 #pragma unroll
          for (int qz = 0; qz < Q; qz++) { dqn[qz] = p[Q * Q * qz]; }
       }
@@ -376,11 +376,12 @@ vcg_apply_plane(const VcgArgs a, const int nbatch)
    };
    auto load_dq = [&](const int bb) {
       const int e = min(bb * NEB + eb, a.NE - 1);
+      const double se = a.Se[e];
 #pragma unroll
       for (int k = 0; k < DPT; k++)
       {
          const int j = lt + k * TE;
-         dq[k] = a.Dq[(size_t)e * NQ + ((DPT * TE == NQ) ? j : min(j, NQ - 1))];
+         dq[k] = a.Dq[(size_t)e * a.dqs + ((DPT * TE == NQ) ? j : min(j, NQ - 1))] * se;
       }
    };
 
@@ -593,8 +594,8 @@ vcg_apply_plane_ho(const VcgArgs a)
 #pragma unroll
    for (int k = 0; k < DPT; k++)
    {
-      const int i = tid + k * NT;
-      dst[k] = (i < nel * NQ) ? a.Dq[(size_t)e0 * NQ + i] : 0.0;
+      const int i = tid + k * NT, ei = i / NQ;
+      dst[k] = (i < nel * NQ) ? a.Dq[(size_t)(e0 + ei) * a.dqs + (i - ei * NQ)] * a.Se[e0 + ei] : 0.0;
    }
    const bool first = a.s->first != 0;
    bool todo[kVC];
@@ -1629,7 +1630,9 @@ int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
    a.NE = c->NE;
    a.N = c->N;
    a.B = c->B;
-   a.Dq = c->massD;
+   a.DqFull = c->massD;
+   rc = mass_data(c, &a.Dq, &a.dqs, &a.Se);
+   if (rc) { return rc; }
    a.map = c->h1map;
    a.ell = c->t_ell;
    a.deg = c->t_deg;

@@ -183,7 +183,10 @@ __device__ __forceinline__ bool grid_sum3_last_block_flat(const double bp[kVC], 
 struct VcgArgs
 {
    int NE, N;
-   const double *B, *Dq;
+   const double *B, *Dq;  // Dq: quadrature data of the mass operator, value(q, e) = Dq[q + dqs e] * Se[e] (mass_data, lgh_mass.hip) in the
+   const double *Se;      // plane and slab forms of K1; the column and matrix-core forms read DqFull[q + NQ e]
+   const double *DqFull;
+   int dqs;
    const int *map;
    const unsigned *mapb;  // map as byte offsets into a node vector (8 * node): the matrix-core K1 (lgh_vcg_mfma.hip)
    int map_xrows;         // 1: the D1D nodes of every x-row of every element are consecutive node numbers (checked at set-up)

@@ -238,7 +238,7 @@ vcg_apply_mfma346(const VcgArgs a, const int nset)
       }
    };
    auto load_dq = [&](const int ss) {
-      const double *p = a.Dq + (size_t)min(ss, nset - 1) * (ES * NQ); // (scalar)
+      const double *p = a.DqFull + (size_t)min(ss, nset - 1) * (ES * NQ); // (scalar)
 #pragma unroll
       for (int k = 0; k < DPT; k++) { dq[k] = mfma_ld(p, 8u * (unsigned)(lane + 64 * k)); }
    };

@@ -145,7 +145,7 @@ static bool slab_swaps_ok(lgh_ctx *c)
    return good;
 }
 
-template <bool SYM, int WPS, int TRACE, bool WIDE, bool EXACT, bool DYN>
+template <bool SYM, int WPS, int TRACE, bool WIDE, bool EXACT, bool DYN, bool RANK1>
 __global__ void __launch_bounds__(256 * WPS, WPS)
 vcg_apply_slab346(const VcgArgs a, const int nset)
 {
@@ -278,7 +278,11 @@ vcg_apply_slab346(const VcgArgs a, const int nset)
       }
    };
    // quadrature data of a set: LDS-DMA, 16 bytes per lane and piece, straight into the wave's buffer `buf` (no registers)
+   // Quadrature data of a set -> the wave's LDS buffer by LDS-DMA (16 bytes per lane and piece, no registers).
+   // RANK1 (mass_data, lgh_mass.hip: D[q, e] = W[q] s_e): both buffers take the point weights of five elements once,
+   // before the loop, and a set only brings its five factors s_e - 8 instead of 1728 bytes per element.
    auto load_dq = [&](const int ss, double *__restrict__ l) {
+      if (RANK1) { return; }
       const double *p = a.Dq + (size_t)min(ss, nset - 1) * (ES * NQ) + 2 * lane;
 #pragma unroll
       for (int k = 0; k < NDMA; k++)
@@ -286,6 +290,18 @@ vcg_apply_slab346(const VcgArgs a, const int nset)
          __builtin_amdgcn_global_load_lds(p + 128 * k, (__attribute__((address_space(3))) void *)(l + 128 * k), 16, 0, 0);
       }
    };
+   if (RANK1)
+   {
+#pragma unroll
+      for (int k = 0; k < NDMA; k++)
+      {
+         const int t = (128 * k + 2 * lane) % NQ; // (NQ is even: a 16-byte piece never straddles two elements)
+         __builtin_amdgcn_global_load_lds(a.Dq + t, (__attribute__((address_space(3))) void *)(sDa + wid * SBUF + 128 * k), 16, 0, 0);
+         __builtin_amdgcn_global_load_lds(a.Dq + t, (__attribute__((address_space(3))) void *)(sDb + wid * SBUF + 128 * k), 16, 0, 0);
+      }
+   }
+   double se_nxt = 1.0, se_cur = 1.0; // per-element factor of the set in flight / being contracted
+   auto load_se = [&](const int ss) { if (RANK1) { se_nxt = a.Se[min(ES * min(ss, nset - 1) + el, a.NE - 1)]; } };
    // direction d = z + beta d (K2 stores the same values)
    double dd[16];
    auto convert = [&]() {
@@ -300,9 +316,11 @@ vcg_apply_slab346(const VcgArgs a, const int nset)
    const int accE = exact_scale((c == 0) ? a.s->rz[0] : (c == 1) ? a.s->rz[1] : a.s->rz[2]);
    load_gather();
    load_dq(s, sDa + wid * SBUF);
+   load_se(s);
    load_map(DYN ? max(s1, 0) : s1);
    __builtin_amdgcn_s_waitcnt(0x0F70);
    convert();
+   se_cur = se_nxt;
    // debug (LGH_VCG_TRACE): wall-clock stamps of wave 0 and the shader cycles it spends waiting for the loads of a set
    unsigned long long t_start = 0, t_loop = 0, c_wait = 0, c_loop = 0;
    unsigned long long c_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, c_prev = 0; // shader cycles per phase of the loop body (wave 0)
@@ -319,6 +337,7 @@ vcg_apply_slab346(const VcgArgs a, const int nset)
       // LDS-DMA, or the compiler loses track of what it writes and drains every load before the first LDS read)
       load_gather();
       load_dq(DYN ? max(s1, 0) : s1, sDnxt);
+      load_se(DYN ? max(s1, 0) : s1);
       load_map(DYN ? max(s2, 0) : s2);
       LGH_SLAB_STAMP(0); // issue of the loads
       double o[16], dset = 0.0;
@@ -378,7 +397,7 @@ vcg_apply_slab346(const VcgArgs a, const int nset)
             double u = 0.0;
 #pragma unroll
             for (int dz = 0; dz < D; dz++) { u = fma(Bs(qz + Q * dz), w[9 * dz + i], u); }
-            cz[qz] = u * dcur[qz];
+            cz[qz] = RANK1 ? u * (dcur[qz] * se_cur) : u * dcur[qz];
             dset = fma(u, cz[qz], dset);
          }
 #pragma unroll
@@ -440,6 +459,7 @@ vcg_apply_slab346(const VcgArgs a, const int nset)
       }
       __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): gathers, LDS-DMA and map of the next set (and the ticket)
       if (!DYN || s1 >= 0) { convert(); }
+      se_cur = se_nxt;
       __builtin_amdgcn_sched_barrier(0);
       LGH_SLAB_STAMP(6); // wait + direction of the next set
       // the slab of the E-vector: 16 contiguous doubles
@@ -611,7 +631,8 @@ void launch_vcg_slab(lgh_ctx *c, const VcgArgs &a)
    const bool wide = c->slab_wide && a.map_xrows != 0;
    const bool exact = a.limbs != nullptr;
    const bool dyn = exact && c->slab_dyn;
-#define LGH_SLAB_LAUNCH(SYM_, WPS_, TR_, WIDE_, EX_, DYN_) hipLaunchKernelGGL((vcg_apply_slab346<SYM_, WPS_, TR_, WIDE_, EX_, DYN_>), dim3(grid), dim3(256 * WPS_), 0, c->stream, a, nset)
+#define LGH_SLAB_LAUNCH(SYM_, WPS_, TR_, WIDE_, EX_, DYN_) do { if (a.dqs == 0) { hipLaunchKernelGGL((vcg_apply_slab346<SYM_, WPS_, TR_, WIDE_, EX_, DYN_, true>), dim3(grid), dim3(256 * WPS_), 0, c->stream, a, nset); } \
+                                                                  else { hipLaunchKernelGGL((vcg_apply_slab346<SYM_, WPS_, TR_, WIDE_, EX_, DYN_, false>), dim3(grid), dim3(256 * WPS_), 0, c->stream, a, nset); } } while (0)
 #define LGH_SLAB_LAUNCH2(SYM_, WPS_, TR_) do { if (wide && dyn) { LGH_SLAB_LAUNCH(SYM_, WPS_, TR_, true, true, true); } else if (wide && exact) { LGH_SLAB_LAUNCH(SYM_, WPS_, TR_, true, true, false); } \
                                                else if (wide) { LGH_SLAB_LAUNCH(SYM_, WPS_, TR_, true, false, false); } \
                                                else if (exact) { LGH_SLAB_LAUNCH(SYM_, WPS_, TR_, false, true, false); } else { LGH_SLAB_LAUNCH(SYM_, WPS_, TR_, false, false, false); } } while (0)

@@ -168,13 +168,13 @@ def test_config4_3d_sedov_q3q2_rs5_full_size_one_gpu():
     _full_size_properties(Problem(mesh="cube01_hex", rs=5, order_v=3, order_e=2, problem=1), total_mass=1.0, e_total=0.125)
 
 
-def test_config4_eight_emulated_ranks_q3q2_16cubed():
+def test_config4_eight_emulated_ranks_q3q2_16cubed(monkeypatch):
     """config4's partition (2x2x2 blocks) at Q3/Q2 with a 16^3 global mesh: eight contexts on one GPU over
     the loopback communicator must reproduce the single-rank run (steps, dt, |e|) - with the region timers on
     (sequential solves, the reference's order) and off (energy solve beside the velocity solve, as in bench.py)."""
     from test_gpu_pipeline import test_multi_rank_run_on_one_gpu as run_ranks
-    run_ranks(8, (16, 16, 16), 1, 1)
-    run_ranks(8, (16, 16, 16), 1, 0)
+    run_ranks(8, (16, 16, 16), 1, 1, (3, 2), {}, monkeypatch)
+    run_ranks(8, (16, 16, 16), 1, 0, (3, 2), {}, monkeypatch)
 
 
 # ---- config5 ---------------------------------------------------------------------------------

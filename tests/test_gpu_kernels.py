@@ -189,8 +189,9 @@ def test_cg_l2(pair):
     it = g.ctx.cg_solve(1, g.ctx.to_dev(b), x, 1e-10, 300)
     g.ctx.sync()
     # unpreconditioned CG on the Bernstein mass matrix: at order 4 it needs > 60
-    # iterations and the count moves by a few with the summation order
-    assert abs(it - it_o) <= max(1, it_o // 20), (it, it_o)
+    # iterations and the count moves by a few with the summation order and with the rounding of the mass data
+    # (compact form, lgh_mass_data_form: 111 against 118 at Q5Q4); the solution is held to 1e-8 either way
+    assert abs(it - it_o) <= max(1, it_o // 10), (it, it_o)
     assert rel_err(x.cpu().numpy(), x_o) < 1e-8
 
 
@@ -651,6 +652,58 @@ def test_slab_k1_switches(switches, monkeypatch):
         assert np.array_equal(ref, dS[H1V:2 * H1V]), "exact accumulation: the result must not depend on the schedule"
 
 
+@pytest.mark.parametrize("variant", ["2", "4"], ids=["plane", "slab"])
+def test_mass_data_forms(variant, monkeypatch):
+    """Compact mass data (lgh_mass_data_form: D[q, e] = W[q] s_e, found by a device check at first use) against the
+    stored table.  Sedov on a Cartesian mesh has it; after the table is rewritten through lgh_mass_D() with a factor
+    that varies inside the elements the check must fail and the kernels must read the new table: H1 and L2 mass
+    products and the lockstep velocity solve then agree with a run that has the compact form switched off
+    (LGH_MASS_RANK1=0: same kernels, same data, hence the same bits), and differ from the products of the old data."""
+    from oracle.fem import Problem
+    prob = Problem(mesh="box01_hex", rs=1, order_v=3, order_e=2, problem=1)
+    S = deformed_state(prob, seed=51)
+    xv, xe = seeded(prob.N, 52), seeded(prob.L2V, 53)
+    factor = 1.0 + 0.25 * np.abs(seeded(prob.NE * prob.NQ, 54))
+    monkeypatch.setenv("LGH_VCG_VARIANT", variant)
+    import torch
+
+    def run(rewrite):
+        g = make_gpu(prob)
+        try:
+            form0 = g.ctx.mass_data_form()
+            if rewrite:
+                g.ctx.massD = g.ctx.massD * factor  # (the setter calls lgh_mass_D again after the write: its contract)
+            form1 = g.ctx.mass_data_form()
+            yv, ye = g.ctx.empty(prob.N), g.ctx.empty(prob.L2V)
+            xvd, xed, Sd = g.ctx.to_dev(xv), g.ctx.to_dev(xe), g.ctx.to_dev(S)
+            torch.cuda.synchronize()
+            g.ctx.mass_set_ess(-1)
+            g.ctx.mass_mult(0, xvd, yv)
+            g.ctx.mass_mult(1, xed, ye)
+            g.cg_tol = 1e-14
+            dS = g.ctx.zeros(S.size)
+            g.reset_quadrature_data()
+            g.mult(Sd, dS)
+            g.ctx.sync()
+            return form0, form1, yv.cpu().numpy(), ye.cpu().numpy(), dS.cpu().numpy()
+        finally:
+            g.close()
+
+    f0, f1, yv_c, ye_c, dS_c = run(False)
+    assert (f0, f1) == ("rank1", "rank1")
+    f0, f1, yv_w, ye_w, dS_w = run(True)
+    assert (f0, f1) == ("rank1", "stored"), "a rewritten table must be looked at again"
+    monkeypatch.setenv("LGH_MASS_RANK1", "0")
+    f0, f1, yv_s, ye_s, dS_s = run(True)
+    assert (f0, f1) == ("stored", "stored")
+    assert np.array_equal(yv_w, yv_s) and np.array_equal(ye_w, ye_s) and np.array_equal(dS_w, dS_s)
+    assert rel_err(yv_w, yv_c) > 1e-3 and rel_err(ye_w, ye_c) > 1e-3
+    f0, f1, yv_t, ye_t, dS_t = run(False)      # the stored table of the unmodified data against its compact form
+    assert rel_err(yv_t, yv_c) < 1e-12 and rel_err(ye_t, ye_c) < 1e-12  # (the check admits 1e-12 per entry)
+    H1V = prob.H1V
+    assert rel_err(dS_t[H1V:], dS_c[H1V:]) < 1e-10
+
+
 @pytest.mark.parametrize("order", [(3, 2), (4, 3)], ids=["Q3Q2", "Q4Q3"])
 def test_mass_kernels_without_table_symmetry(order, monkeypatch):
     """LGH_B_SYM=0: lgh_create treats the 1-D tables as not mirror symmetric, as it would for a basis on asymmetric
@@ -700,6 +753,8 @@ KERNEL_SWITCHES = [
     ((3, 2), {"LGH_K2_U": "2"}, "tol"),
     ((3, 2), {"LGH_K2_GRID": "2"}, "tol"),
     ((3, 2), {"LGH_K2_NODE_WEIGHT": "-1"}, "tol"),
+    ((3, 2), {"LGH_MASS_RANK1": "0"}, "tol"),
+    ((4, 3), {"LGH_MASS_RANK1": "0"}, "tol"),
     ((4, 3), {"LGH_L2_PLANE": "0"}, "tol"),
     ((4, 3), {"LGH_K2P": "0"}, "tol"),
 ]
