@@ -308,9 +308,9 @@ static int create_impl(const lgh_config *cfg, lgh_ctx *c, const int kid)
       LGH_TRY(dev_alloc_copy(&c->t_ell, ell.data(), ell.size()));
       const char *env = getenv("LGH_VCG_VARIANT"); // A/B switch of the lockstep K1 (lgh_vcg.hip)
       c->vcg_variant = (env && env[0] >= '0' && env[0] <= '9') ? env[0] - '0' : -1; // -1: by kernel id and mesh size (vcg_k1_form)
-      // slab-form K1 (lgh_vcg_slab.hip), A/B: wavefronts per SIMD (default 2), row loads, exact sum of (d, A d), sets drawn from a workgroup queue
+      // slab-form K1 (lgh_vcg_slab.hip), A/B: wavefronts per SIMD (default 1), row loads, exact sum of (d, A d), sets drawn from a workgroup queue
       env = getenv("LGH_SLAB_WPS");
-      c->slab_wps = (env && env[0] == '1') ? 1 : 2;
+      c->slab_wps = (env && env[0] == '2') ? 2 : 1;
       env = getenv("LGH_SLAB_WIDE");
       c->slab_wide = (env && env[0] == '0') ? 0 : 1;
       env = getenv("LGH_SLAB_EXACT");

@@ -1135,11 +1135,13 @@ vcg_update_p_k(const VcgArgs a)
    bool todo[kVC];
    double alpha[kVC], alpha_prev[kVC], beta[kVC], den[kVC];
 #pragma unroll
-   for (int k = 0; k < kVC; k++) { den[k] = a.s->den[k]; }
+   for (int k = 0; k < kVC; k++) { den[k] = a.den_limbs ? exact_den(a.limbs + (it & 1) * kLimbWords, k, a.s->rz[k]) : a.s->den[k]; }
+   if (a.den_limbs && blockIdx.x == 0 && tid < kLimbWords) { a.limbs[((it + 1) & 1) * kLimbWords + tid] = 0; } // the set of the next K1
 #pragma unroll
    for (int k = 0; k < kVC; k++)
    {
       todo[k] = a.s->done[k] == 0;
+      if (a.den_limbs && den[k] == 0.0) { todo[k] = false; } // breakdown, as upstream (marked below)
       // (several ranks: breakdown is looked at here, after the sum of (d, A d) over the ranks - vcg_pending_den)
       if (a.multi && todo[k] && vcg_pending_den(a.s, k, blockIdx.x == 0 && tid == 0)) { todo[k] = false; }
       alpha[k] = todo[k] ? a.s->rz[k] / den[k] : 0.0;
@@ -1273,8 +1275,14 @@ vcg_update_p_k(const VcgArgs a)
       {
          VcgScalars *s = a.s;
          int all = 1;
+         if (a.den_limbs) { s->first = 0; }
          for (int k = 0; k < kVC; k++)
          {
+            if (a.den_limbs && !s->done[k])
+            {
+               s->den[k] = den[k];
+               if (den[k] == 0.0) { s->done[k] = 1; }
+            }
             if (!s->done[k] && !(a.multi && s->den[k] == 0.0)) // (several ranks: breakdown found by this launch)
             {
                s->alpha_last[k] = s->rz[k] / den[k]; // the alpha this launch used
@@ -1653,6 +1661,12 @@ int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
    a.map_xrows = aux->map_xrows;
    a.limbs = limbs;
    a.queue = limbs ? (unsigned *)(limbs + 2 * kLimbWords) : nullptr;
+   {
+      const char *e0 = getenv("LGH_SLAB_DEFER"); // A/B: 0 = the last workgroup of K1 folds the accumulators (ticket), K2 reads the result
+      a.den_limbs = (limbs && !(e0 && e0[0] == '0')) ? 1 : 0;
+      e0 = getenv("LGH_SLAB_STORE_WAIT"); // A/B: 0 / 1; default by mesh size
+      a.store_wait = e0 ? (e0[0] == '1' ? 1 : 0) : (c->NE >= kSlabStoreWaitElements ? 1 : 0);
+   }
    {
       const char *e0 = getenv("LGH_K2_SKIP");
       a.k2_skip = (e0 && e0[0] == '0') ? 0 : 1;

@@ -7,7 +7,8 @@ namespace lgh
 {
 
 constexpr int kVC = 3; // velocity components handled in lockstep
-constexpr int kSlabMinElements = 100000; // default dispatch of the slab-form K1 (vcg_k1_form)
+constexpr int kSlabMinElements = 20000;  // default dispatch of the slab-form K1 (vcg_k1_form): 40.6 against 48.5 us at 32^3, 316 against 383 at 64^3
+constexpr int kSlabStoreWaitElements = 100000; // meshes that live in HBM: a wavefront waits for the stores of a pass before the next one (316 against 333 us at 64^3; 32^3: 44.5 against 40.6)
 constexpr int kTraceRec = 16; // debug (LGH_VCG_TRACE): 64-bit words per workgroup record of K1
 
 struct VcgScalars
@@ -191,7 +192,8 @@ struct VcgArgs
    const unsigned *mapb;  // map as byte offsets into a node vector (8 * node): the matrix-core K1 (lgh_vcg_mfma.hip)
    int map_xrows;         // 1: the D1D nodes of every x-row of every element are consecutive node numbers (checked at set-up)
    unsigned *queue;       // slab-form K1, dynamic schedule: one set counter per XCD range, 128 bytes apart (zero between launches)
-   long long *limbs;      // exact accumulators of (d, A d): kLimbWords words (slab-form K1), or nullptr (ticketed fold of workgroup partials)
+   long long *limbs;      // exact accumulators of (d, A d): two sets of kLimbWords words (slab-form K1), or nullptr (ticketed fold of workgroup partials)
+   int den_limbs;         // 1: K1 only adds into set (iter & 1) of limbs - no ticket, no last workgroup; K2 folds the set itself (exact_den) and clears the other one
    const int *ell;
    int deg;
    const uint8_t *ess[kVC];
@@ -218,6 +220,7 @@ struct VcgArgs
    const uint8_t *essbits;    // bit k: node essential for component k
    const int *nstart;         // node range of block w: [nstart[w], nstart[w+1]), balanced by cost
    int k2_skip;               // vcg_update_p_k: skip ELL slots no node of the wavefront uses (LGH_K2_SKIP=0: fetch all 8)
+   int store_wait;        // slab-form K1 (A/B, LGH_SLAB_STORE_WAIT): every wavefront waits for the stores of a pass before it starts the next one
 };
 
 // ---- exact, order-independent sums of doubles (the (d, A d) of the slab-form K1) -------------------------------
@@ -278,6 +281,23 @@ __device__ __forceinline__ double exact_value(const long long (&L)[kLimbs], cons
    s += ldexp((double)m, E - 32);
    s += ldexp((double)h, E - 32 + 26);
    return s;
+}
+
+// (d, A d) of component k out of one set of accumulators (den_limbs: every workgroup of K2 folds the dozen words itself
+// - integers, so all of them get the same bits - instead of one last workgroup of K1 doing it while the chip waits).
+__device__ __forceinline__ double exact_den(const long long *__restrict__ set, const int k, const double rz)
+{
+   long long l4[kLimbs];
+#pragma unroll
+   for (int j = 0; j < kLimbs; j++) { l4[j] = 0; }
+#pragma unroll
+   for (int sh = 0; sh < kLimbShards; sh++)
+   {
+#pragma unroll
+      for (int j = 0; j < kLimbs; j++) { l4[j] += set[sh * (kVC * kLimbs) + kLimbs * k + j]; }
+   }
+   const long long bad = set[kLimbShards * kVC * kLimbs];
+   return bad ? __builtin_nan("") : exact_value(l4, exact_scale(rz));
 }
 // 64-bit integer sum over the 64 lanes of a full wavefront (DPP, as wave_sum); the total is returned in every lane
 __device__ __forceinline__ long long wave_sum_i64(long long v)

@@ -202,13 +202,14 @@ vcg_apply_slab346(const VcgArgs a, const int nset)
    // past the end the last element, and the quadrature data is padded by one set behind its last element (lgh_create);
    // nothing of that is stored or summed.  The loop body is straight-line code.
    unsigned mo[16]; // byte offsets of this lane's 16 nodes (dx + 4 dy; dz = g) into a node vector (WIDE: of the first node of each x-row, mo[4 dy])
-   auto load_map = [&](const int ss) {
+   unsigned mn[16]; // ... of the set after: the gathers of a set go out in four parts during the pass before it (see the loop body)
+   auto load_map = [&](const int ss, unsigned (&m_)[16]) {
       const int e = min(ES * min(ss, nset - 1) + el, a.NE - 1);
       if (WIDE)
       {
          const unsigned *p = a.mapb + (size_t)e * ND + 16 * g;
 #pragma unroll
-         for (int dy = 0; dy < 4; dy++) { mo[4 * dy] = p[4 * dy]; }
+         for (int dy = 0; dy < 4; dy++) { m_[4 * dy] = p[4 * dy]; }
          return;
       }
       const v4u *p = (const v4u *)(a.mapb + (size_t)e * ND + 16 * g);
@@ -216,10 +217,10 @@ vcg_apply_slab346(const VcgArgs a, const int nset)
       for (int dy = 0; dy < 4; dy++)
       {
          const v4u m = p[dy];
-         mo[4 * dy + 0] = m[0]; mo[4 * dy + 1] = m[1]; mo[4 * dy + 2] = m[2]; mo[4 * dy + 3] = m[3];
+         m_[4 * dy + 0] = m[0]; m_[4 * dy + 1] = m[1]; m_[4 * dy + 2] = m[2]; m_[4 * dy + 3] = m[3];
       }
    };
-   load_map(s); // in flight while the scalars are read
+   load_map(s, mo); // in flight while the scalars are read
 
    if (a.s->all_done) { return; }
    const bool first = a.s->first != 0;
@@ -247,35 +248,35 @@ vcg_apply_slab346(const VcgArgs a, const int nset)
    // true for any tensor-product numbering with x fastest) - a row is two 16-byte loads per vector instead of four
    // 8-byte gathers, and every cache line is asked for by one or two instructions instead of four
    double gz[16], gd[16], gv[16];
-   auto load_gather = [&]() {
+   auto load_gather_part = [&](const int dy, const bool pin = false) __attribute__((always_inline)) {
       if (WIDE)
       {
-#pragma unroll
-         for (int dy = 0; dy < 4; dy++)
-         {
-            const v2d_a8 *pv = (const v2d_a8 *)((const char *)a.dinv + mo[4 * dy]);
-            const v2d va = pv[0], vb = pv[1];
-            gv[4 * dy] = va[0]; gv[4 * dy + 1] = va[1]; gv[4 * dy + 2] = vb[0]; gv[4 * dy + 3] = vb[1];
-         }
-#pragma unroll
-         for (int dy = 0; dy < 4; dy++)
-         {
-            const v2d_a8 *pz = (const v2d_a8 *)((const char *)a.r + (mo[4 * dy] + coff));
-            const v2d_a8 *pd = (const v2d_a8 *)((const char *)dsrc + (mo[4 * dy] + coff));
-            const v2d za = pz[0], zb = pz[1], da = pd[0], db = pd[1];
-            gz[4 * dy] = za[0]; gz[4 * dy + 1] = za[1]; gz[4 * dy + 2] = zb[0]; gz[4 * dy + 3] = zb[1];
-            gd[4 * dy] = da[0]; gd[4 * dy + 1] = da[1]; gd[4 * dy + 2] = db[0]; gd[4 * dy + 3] = db[1];
-         }
+         // (pin: the offset passes through an empty volatile asm - the loads are read-only and the optimiser would
+         //  otherwise collect all parts in one place, whatever fences stand between them)
+         unsigned off = mo[4 * dy];
+         if (pin) { asm volatile("" : "+v"(off)); }
+         const v2d_a8 *pv = (const v2d_a8 *)((const char *)a.dinv + off);
+         const v2d_a8 *pz = (const v2d_a8 *)((const char *)a.r + (off + coff));
+         const v2d_a8 *pd = (const v2d_a8 *)((const char *)dsrc + (off + coff));
+         const v2d va = pv[0], vb = pv[1], za = pz[0], zb = pz[1], da = pd[0], db = pd[1];
+         gv[4 * dy] = va[0]; gv[4 * dy + 1] = va[1]; gv[4 * dy + 2] = vb[0]; gv[4 * dy + 3] = vb[1];
+         gz[4 * dy] = za[0]; gz[4 * dy + 1] = za[1]; gz[4 * dy + 2] = zb[0]; gz[4 * dy + 3] = zb[1];
+         gd[4 * dy] = da[0]; gd[4 * dy + 1] = da[1]; gd[4 * dy + 2] = db[0]; gd[4 * dy + 3] = db[1];
          return;
       }
 #pragma unroll
-      for (int j = 0; j < 16; j++) { gv[j] = slab_ld(a.dinv, mo[j]); }
-#pragma unroll
-      for (int j = 0; j < 16; j++)
+      for (int j = 4 * dy; j < 4 * dy + 4; j++)
       {
-         gz[j] = slab_ld(a.r, mo[j] + coff);
-         gd[j] = slab_ld(dsrc, mo[j] + coff);
+         unsigned off = mo[j];
+         if (pin) { asm volatile("" : "+v"(off)); }
+         gv[j] = slab_ld(a.dinv, off);
+         gz[j] = slab_ld(a.r, off + coff);
+         gd[j] = slab_ld(dsrc, off + coff);
       }
+   };
+   auto load_gather = [&]() {
+#pragma unroll
+      for (int dy = 0; dy < 4; dy++) { load_gather_part(dy); }
    };
    // quadrature data of a set: LDS-DMA, 16 bytes per lane and piece, straight into the wave's buffer `buf` (no registers)
    // Quadrature data of a set -> the wave's LDS buffer by LDS-DMA (16 bytes per lane and piece, no registers).
@@ -300,8 +301,8 @@ vcg_apply_slab346(const VcgArgs a, const int nset)
          __builtin_amdgcn_global_load_lds(a.Dq + t, (__attribute__((address_space(3))) void *)(sDb + wid * SBUF + 128 * k), 16, 0, 0);
       }
    }
-   double se_nxt = 1.0, se_cur = 1.0; // per-element factor of the set in flight / being contracted
-   auto load_se = [&](const int ss) { if (RANK1) { se_nxt = a.Se[min(ES * min(ss, nset - 1) + el, a.NE - 1)]; } };
+   // (RANK1: A d = s_e (B^T W B d) - the element factor multiplies the 16 outputs and the partial of (d, A d) at the
+   //  end of the pass, not the 54 point values; loaded with the gathers of the pass, two registers)
    // direction d = z + beta d (K2 stores the same values)
    double dd[16];
    auto convert = [&]() {
@@ -316,11 +317,9 @@ vcg_apply_slab346(const VcgArgs a, const int nset)
    const int accE = exact_scale((c == 0) ? a.s->rz[0] : (c == 1) ? a.s->rz[1] : a.s->rz[2]);
    load_gather();
    load_dq(s, sDa + wid * SBUF);
-   load_se(s);
-   load_map(DYN ? max(s1, 0) : s1);
+   load_map(DYN ? max(s1, 0) : s1, mo);
    __builtin_amdgcn_s_waitcnt(0x0F70);
    convert();
-   se_cur = se_nxt;
    // debug (LGH_VCG_TRACE): wall-clock stamps of wave 0 and the shader cycles it spends waiting for the loads of a set
    unsigned long long t_start = 0, t_loop = 0, c_wait = 0, c_loop = 0;
    unsigned long long c_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, c_prev = 0; // shader cycles per phase of the loop body (wave 0)
@@ -335,10 +334,15 @@ vcg_apply_slab346(const VcgArgs a, const int nset)
       // next set: gathers and quadrature data now, the map of the one after
       // (DYN: an empty pipeline slot - at most three per wavefront, at the end - re-reads set 0: no branch around the
       // LDS-DMA, or the compiler loses track of what it writes and drains every load before the first LDS read)
-      load_gather();
+      double se = 1.0;
+      if (RANK1) { se = a.Se[min(e, a.NE - 1)]; }
+      const unsigned ye_lane = 8u * ((unsigned)c * (unsigned)a.ye_stride + 16u * (unsigned)g);
+      // The gathers go out in four parts (one per y-row: 6 wide loads, or 12 single ones), a part at the top and the
+      // others between the phases below: issued all at once they queue up behind the address unit of the CU and the
+      // wavefront - the only one on its SIMD, or one of two - stands still for a quarter of the pass.
+      load_gather_part(0);
       load_dq(DYN ? max(s1, 0) : s1, sDnxt);
-      load_se(DYN ? max(s1, 0) : s1);
-      load_map(DYN ? max(s2, 0) : s2);
+      load_map(DYN ? max(s2, 0) : s2, mn);
       LGH_SLAB_STAMP(0); // issue of the loads
       double o[16], dset = 0.0;
       if (!DYN || s0 >= 0)
@@ -370,6 +374,8 @@ vcg_apply_slab346(const VcgArgs a, const int nset)
          }
       }
       __builtin_amdgcn_sched_barrier(0);
+      load_gather_part(1, true);
+      __builtin_amdgcn_sched_barrier(0);
       LGH_SLAB_STAMP(1); // forward x, y
       // slabs -> pairs: w[9 dz + i] = slab dz, pair 9 g + i
       slab_to_pairs(w);
@@ -397,7 +403,7 @@ vcg_apply_slab346(const VcgArgs a, const int nset)
             double u = 0.0;
 #pragma unroll
             for (int dz = 0; dz < D; dz++) { u = fma(Bs(qz + Q * dz), w[9 * dz + i], u); }
-            cz[qz] = RANK1 ? u * (dcur[qz] * se_cur) : u * dcur[qz];
+            cz[qz] = u * dcur[qz];
             dset = fma(u, cz[qz], dset);
          }
 #pragma unroll
@@ -418,6 +424,8 @@ vcg_apply_slab346(const VcgArgs a, const int nset)
 #pragma unroll
             for (int qz = 0; qz < Q; qz++) { dcur[qz] = sDp[i + 1 + 36 * qz]; }
          }
+         if (i == 2) { load_gather_part(2, true); }
+         if (i == 5) { load_gather_part(3, true); }
          asm volatile("" : "+v"(dset)); // the partial sum exists HERE: left alone, the compiler keeps all 54 factor pairs alive (216 registers) and forms the sum after the loop body
          __builtin_amdgcn_sched_barrier(0);
       }
@@ -451,6 +459,12 @@ vcg_apply_slab346(const VcgArgs a, const int nset)
       // the stores of this set go out behind them, so that no wait ever covers a store that has just been issued
       LGH_SLAB_STAMP(5); // backward y, x
       } // (s0)
+      else
+      {
+         load_gather_part(1);
+         load_gather_part(2);
+         load_gather_part(3);
+      }
       if (TRACE == 2)
       {
          const unsigned long long c0 = clock64();
@@ -459,20 +473,23 @@ vcg_apply_slab346(const VcgArgs a, const int nset)
       }
       __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): gathers, LDS-DMA and map of the next set (and the ticket)
       if (!DYN || s1 >= 0) { convert(); }
-      se_cur = se_nxt;
+#pragma unroll
+      for (int j = 0; j < 16; j += (WIDE ? 4 : 1)) { mo[j] = mn[j]; }
       __builtin_amdgcn_sched_barrier(0);
       LGH_SLAB_STAMP(6); // wait + direction of the next set
       // the slab of the E-vector: 16 contiguous doubles
       if (act)
       {
-         double *yc = a.YE + (size_t)c * a.ye_stride + (size_t)ND * e + 16 * g;
+         // (one scalar base + a 32-bit byte offset: a per-lane 64-bit pointer that lives across the pass is two registers too many)
+         char *yc = (char *)a.YE + (ye_lane + 8u * (unsigned)ND * (unsigned)e);
 #pragma unroll
-         for (int dy = 0; dy < D; dy++) { *(v4d *)(yc + 4 * dy) = v4d{o[4 * dy], o[4 * dy + 1], o[4 * dy + 2], o[4 * dy + 3]}; }
+         for (int dy = 0; dy < D; dy++) { *(v4d *)(yc + 32 * dy) = v4d{o[4 * dy] * se, o[4 * dy + 1] * se, o[4 * dy + 2] * se, o[4 * dy + 3] * se}; }
       }
+      if (a.store_wait) { __builtin_amdgcn_s_waitcnt(0x0F70); }
       LGH_SLAB_STAMP(7); // stores
       // (a select would let the compiler sink all 54 products of dset behind the branch: 216 live registers)
-      if (EXACT) { acc_bad = acc_bad || !exact_add(acc, dset * actf, accE); }
-      else { dot = fma(dset, actf, dot); }
+      if (EXACT) { acc_bad = acc_bad || !exact_add(acc, dset * (actf * se), accE); }
+      else { dot = fma(dset, actf * se, dot); }
       // the pipeline moves on
       if (DYN)
       {
@@ -489,8 +506,10 @@ vcg_apply_slab346(const VcgArgs a, const int nset)
    };
    auto more = [&]() -> bool { return DYN ? (s0 >= 0 || s1 >= 0 || s2 >= 0) : (s0 >= 0); };
    double *bcur = sDa + wid * SBUF, *bnxt = sDb + wid * SBUF;
+   int n_pass = 0;
    while (more())
    {
+      if (TRACE == 1) { n_pass += (s0 >= 0) ? 1 : 0; }
       body(bcur, bnxt);
       double *const tmp = bcur;
       bcur = bnxt;
@@ -498,6 +517,8 @@ vcg_apply_slab346(const VcgArgs a, const int nset)
    }
    if (TRACE) { t_loop = wall_clock64(); }
    if (TRACE == 2) { c_loop = clock64() - c_loop; }
+   __shared__ unsigned long long s_twave[NW]; // debug (TRACE 1): when every wavefront left the loop, and after how many passes
+   if (TRACE == 1 && lane == 0) { s_twave[wid] = (t_loop << 8) | (unsigned long long)(n_pass & 0xff); }
    if (EXACT)
    {
       // integer sums over the workgroup, then kVC * kLimbs fire-and-forget atomics into this workgroup's shard
@@ -516,7 +537,7 @@ vcg_apply_slab346(const VcgArgs a, const int nset)
       const bool anybad = __any(acc_bad && n < 15 && mine);
       if (lane == 0) { redbad[wid] = anybad ? 1 : 0; }
       __syncthreads();
-      long long *L = a.limbs;
+      long long *L = a.limbs + (a.den_limbs ? (a.iter & 1) * kLimbWords : 0);
       __shared__ unsigned int s_last;
       if (tid < kVC * kLimbs)
       {
@@ -531,6 +552,19 @@ vcg_apply_slab346(const VcgArgs a, const int nset)
 #pragma unroll
          for (int w = 0; w < NW; w++) { bad |= redbad[w]; }
          if (bad) { (void)__hip_atomic_fetch_or(&L[kLimbShards * kVC * kLimbs], 1LL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+      }
+      if (a.den_limbs)
+      {
+         // K2 folds the set: nothing returns to this kernel, the workgroup is gone as soon as its atomics are on their way
+         if (TRACE && tid == 0)
+         {
+            a.trace[kTraceRec * blockIdx.x + 0] = t_start;
+            a.trace[kTraceRec * blockIdx.x + 1] = t_loop;
+            a.trace[kTraceRec * blockIdx.x + 2] = wall_clock64();
+            a.trace[kTraceRec * blockIdx.x + 3] = (c_wait << 32) | (c_loop & 0xffffffffull);
+            for (int k = 0; k < 8; k++) { a.trace[kTraceRec * blockIdx.x + 4 + k] = (TRACE == 1) ? (k < NW ? s_twave[k] : 0ull) : c_ph[k]; }
+         }
+         return;
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the atomics have been performed (gfx9: vmcnt counts them) ...
       __syncthreads();
@@ -614,7 +648,7 @@ vcg_apply_slab346(const VcgArgs a, const int nset)
 bool vcg_slab_available(lgh_ctx *c)
 {
    // (node vectors are addressed by one scalar base + a 32-bit byte offset)
-   return c->dim == 3 && c->kid == 0x346 && (size_t)c->N * 8 * kVC < 0xffffffffull && slab_swaps_ok(c);
+   return c->dim == 3 && c->kid == 0x346 && (size_t)c->N * 8 * kVC < 0xffffffffull && ((size_t)c->NE * c->ND + kYePad) * 8 * kVC < 0xffffffffull && slab_swaps_ok(c);
 }
 
 void launch_vcg_slab(lgh_ctx *c, const VcgArgs &a)

@@ -608,6 +608,9 @@ SLAB_SWITCHES = [
     {"LGH_SLAB_EXACT": "0"},
     {"LGH_SLAB_WIDE": "0"},
     {"LGH_SLAB_WPS": "1", "LGH_SLAB_WIDE": "0", "LGH_SLAB_DYN": "0"},
+    {"LGH_SLAB_DEFER": "0"},
+    {"LGH_SLAB_STORE_WAIT": "1"},
+    {"LGH_SLAB_WPS": "2", "LGH_SLAB_WIDE": "0"},
 ]
 
 
