@@ -1135,13 +1135,13 @@ vcg_update_p_k(const VcgArgs a)
    bool todo[kVC];
    double alpha[kVC], alpha_prev[kVC], beta[kVC], den[kVC];
 #pragma unroll
-   for (int k = 0; k < kVC; k++) { den[k] = a.den_limbs ? exact_den(a.limbs + (it & 1) * kLimbWords, k, a.s->rz[k]) : a.s->den[k]; }
-   if (a.den_limbs && blockIdx.x == 0 && tid < kLimbWords) { a.limbs[((it + 1) & 1) * kLimbWords + tid] = 0; } // the set of the next K1
+   for (int k = 0; k < kVC; k++) { den[k] = (a.den_limbs == 1) ? exact_den(a.limbs + (it & 1) * kLimbWords, k, a.s->rz[k]) : a.s->den[k]; }
+   if (a.den_limbs == 1 && blockIdx.x == 0 && tid < kLimbWords) { a.limbs[((it + 1) & 1) * kLimbWords + tid] = 0; } // the set of the next K1
 #pragma unroll
    for (int k = 0; k < kVC; k++)
    {
       todo[k] = a.s->done[k] == 0;
-      if (a.den_limbs && den[k] == 0.0) { todo[k] = false; } // breakdown, as upstream (marked below)
+      if (a.den_limbs == 1 && den[k] == 0.0) { todo[k] = false; } // breakdown, as upstream (marked below)
       // (several ranks: breakdown is looked at here, after the sum of (d, A d) over the ranks - vcg_pending_den)
       if (a.multi && todo[k] && vcg_pending_den(a.s, k, blockIdx.x == 0 && tid == 0)) { todo[k] = false; }
       alpha[k] = todo[k] ? a.s->rz[k] / den[k] : 0.0;
@@ -1275,10 +1275,10 @@ vcg_update_p_k(const VcgArgs a)
       {
          VcgScalars *s = a.s;
          int all = 1;
-         if (a.den_limbs) { s->first = 0; }
+         if (a.den_limbs == 1) { s->first = 0; }
          for (int k = 0; k < kVC; k++)
          {
-            if (a.den_limbs && !s->done[k])
+            if (a.den_limbs == 1 && !s->done[k])
             {
                s->den[k] = den[k];
                if (den[k] == 0.0) { s->done[k] = 1; }
@@ -1335,10 +1335,24 @@ vcg_gather_k(const VcgArgs a)
    }
 }
 
+// Several ranks, slab-form K1 with exact accumulators (den_limbs == 2): the local part of (d, A d) has to exist as a
+// double before the exchange that sums it over the ranks - one workgroup (of the kernel that runs between K1 and the
+// exchange anyway) folds the set K1 added into and clears the other one for the next K1.  256 threads.
+__device__ __forceinline__ void vcg_fold_den(const VcgArgs &a)
+{
+   const int tid = threadIdx.x, it = a.iter;
+   if (tid < kVC && !a.s->done[tid]) { a.s->den[tid] = exact_den(a.limbs + (it & 1) * kLimbWords, tid, a.s->rz[tid]); }
+   if (tid < kLimbWords) { a.limbs[((it + 1) & 1) * kLimbWords + tid] = 0; }
+   if (tid == 0) { a.s->first = 0; }
+}
+__global__ void __launch_bounds__(256)
+vcg_fold_den_k(const VcgArgs a) { vcg_fold_den(a); }
+
 // E -> L sum at the listed (rank-shared) nodes only: what the halo exchange needs
 __global__ void __launch_bounds__(256)
 vcg_gather_list_k(const VcgArgs a)
 {
+   if (a.den_limbs == 2 && blockIdx.x == 0) { vcg_fold_den(a); }
    const int u = blockIdx.x * blockDim.x + threadIdx.x;
    if (u >= a.n_shared) { return; }
    const int n = a.sh_node[u];
@@ -1532,10 +1546,9 @@ int vcg_k1_form(lgh_ctx *c)
    if (!vcg_supported(c)) { return -1; }
    if (c->kid == 0x346 && c->vcg_variant == 3 && vcg_mfma_available(c)) { return 3; }
    if (c->kid == 0x346 && c->vcg_variant == 4 && vcg_slab_available(c)) { return 4; }
-   // Default at Q3Q2: the slab form where the mesh does not fit the Infinity Cache - measured (profiles/README.md): 64^3
-   // zones 309 vs 375 us per launch, 32^3 zones 56 vs 50 us (there its longer tail outweighs its shorter loop).  One rank
-   // only: its exact sum of (d, A d) and its schedule have no multi-rank path.
-   if (c->kid == 0x346 && c->vcg_variant < 0 && c->multi == 0 && c->NE >= kSlabMinElements && vcg_slab_available(c)) { return 4; }
+   // Default at Q3Q2 from kSlabMinElements zones per rank: 40.6 vs 48.5 us per launch at 32^3 zones, 316 vs 383 at 64^3
+   // (profiles/README.md); smaller meshes do not fill its one workgroup per CU.
+   if (c->kid == 0x346 && c->vcg_variant < 0 && c->NE >= kSlabMinElements && vcg_slab_available(c)) { return 4; }
    if (c->vcg_variant == 0) { return 0; }
    if ((c->kid == 0x358 || c->kid == 0x36A) && !c->b_h1_sym) { return 0; }
    return 2;
@@ -1629,8 +1642,8 @@ int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
    const char *k2env = getenv("LGH_K2P"); // A/B: 0 = vcg_update_k (one node per thread, x every iteration)
    const bool k2p = aux->ellz != nullptr && !(k2env && k2env[0] == '0');
    VcgScalars *ds = (VcgScalars *)c->vcg_s;
-   // exact accumulators of (d, A d): slab-form K1 on one rank with the bounded-grid K2 (LGH_SLAB_EXACT=0: ticketed fold)
-   long long *limbs = (c->slab_exact && k2p && !multi && k1form == 4) ? aux->limbs : nullptr;
+   // exact accumulators of (d, A d): slab-form K1 with the bounded-grid K2 (LGH_SLAB_EXACT=0: ticketed fold)
+   long long *limbs = (c->slab_exact && k2p && k1form == 4) ? aux->limbs : nullptr;
    hipLaunchKernelGGL(vcg_set_tol_k, dim3(1), dim3(1), 0, c->stream, ds, rel_tol * rel_tol, limbs);
 
    VcgArgs a;
@@ -1663,7 +1676,7 @@ int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
    a.queue = limbs ? (unsigned *)(limbs + 2 * kLimbWords) : nullptr;
    {
       const char *e0 = getenv("LGH_SLAB_DEFER"); // A/B: 0 = the last workgroup of K1 folds the accumulators (ticket), K2 reads the result
-      a.den_limbs = (limbs && !(e0 && e0[0] == '0')) ? 1 : 0;
+      a.den_limbs = (limbs && !(e0 && e0[0] == '0')) ? (multi ? 2 : 1) : 0; // (several ranks: folded before the exchange, vcg_fold_den)
       e0 = getenv("LGH_SLAB_STORE_WAIT"); // A/B: 0 / 1; default by mesh size
       a.store_wait = e0 ? (e0[0] == '1' ? 1 : 0) : (c->NE >= kSlabStoreWaitElements ? 1 : 0);
    }
@@ -1785,8 +1798,13 @@ int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
                {
                   hipLaunchKernelGGL(vcg_gather_list_k, dim3(ceil_div(a.n_shared, 256)), dim3(256), 0, c->stream, a);
                }
+               else if (a.den_limbs == 2) { hipLaunchKernelGGL(vcg_fold_den_k, dim3(1), dim3(256), 0, c->stream, a); }
             }
-            else { hipLaunchKernelGGL(vcg_gather_k, dim3(nb), dim3(256), 0, c->stream, a); }
+            else
+            {
+               if (a.den_limbs == 2) { hipLaunchKernelGGL(vcg_fold_den_k, dim3(1), dim3(256), 0, c->stream, a); }
+               hipLaunchKernelGGL(vcg_gather_k, dim3(nb), dim3(256), 0, c->stream, a);
+            }
             LGH_HIP_CHECK(hipGetLastError());
             if (multi)
             {
