@@ -298,7 +298,6 @@ vcg_apply_slab346(const VcgArgs a, const int nset)
       {
          const int t = (128 * k + 2 * lane) % NQ; // (NQ is even: a 16-byte piece never straddles two elements)
          __builtin_amdgcn_global_load_lds(a.Dq + t, (__attribute__((address_space(3))) void *)(sDa + wid * SBUF + 128 * k), 16, 0, 0);
-         __builtin_amdgcn_global_load_lds(a.Dq + t, (__attribute__((address_space(3))) void *)(sDb + wid * SBUF + 128 * k), 16, 0, 0);
       }
    }
    // (RANK1: A d = s_e (B^T W B d) - the element factor multiplies the 16 outputs and the partial of (d, A d) at the
@@ -310,6 +309,25 @@ vcg_apply_slab346(const VcgArgs a, const int nset)
       for (int j = 0; j < 16; j++) { dd[j] = fma(betac, gd[j], __dmul_rn(gz[j], gv[j])); }
    };
 
+   // The E-vector stores.  The 16 outputs of a lane are one 128-byte line of Y_E, and a store instruction that writes
+   // 16 bytes of 64 different lines costs the memory pipeline as much as 64 full lines would (measured: a quarter of the
+   // pass spent behind them, profiles/README.md).  The lines of a group of eight lanes are therefore exchanged through
+   // the wavefront's LDS buffer (144-byte pitch: every access at the bank limit) so that instruction k stores the
+   // complete line of lane (lane & ~7) + k, 16 bytes per lane.  Per lane and k: the byte offset of that piece inside the
+   // set's slice of Y_E, and whether the owner is an item at all (n < 15) whose component still iterates.
+   constexpr int TP = 18; // doubles per lane in the exchange buffer (16 + 2: pitch 144 bytes)
+   static_assert(64 * TP <= SBUF, "the exchange buffer is a quadrature-data buffer of the wavefront");
+   unsigned st_off[8];
+   unsigned st_ok = 0, st_el = 0; // bit k / bits 3k..3k+2: owner k is live / its element within the set
+#pragma unroll
+   for (int k = 0; k < 8; k++)
+   {
+      const int no = (n & 8) + k, nio = min(no, 14), elo = nio / 3, co = nio - 3 * elo;
+      st_off[k] = 8u * ((unsigned)co * (unsigned)a.ye_stride + (unsigned)(ND * elo + 16 * g)) + 16u * (unsigned)(lane & 7);
+      const bool live = (no < 15) && ((co == 0) ? todo[0] : (co == 1) ? todo[1] : todo[2]);
+      st_ok |= live ? (1u << k) : 0u;
+      st_el |= (unsigned)elo << (3 * k);
+   }
    double dot = 0.0;
    // EXACT: (d, A d) in integer accumulators (lgh_vcg.hpp): no ticket, no last workgroup; vcg_update_p_k forms the value
    long long acc[kLimbs] = {0, 0, 0, 0};
@@ -336,7 +354,6 @@ vcg_apply_slab346(const VcgArgs a, const int nset)
       // LDS-DMA, or the compiler loses track of what it writes and drains every load before the first LDS read)
       double se = 1.0;
       if (RANK1) { se = a.Se[min(e, a.NE - 1)]; }
-      const unsigned ye_lane = 8u * ((unsigned)c * (unsigned)a.ye_stride + 16u * (unsigned)g);
       // The gathers go out in four parts (one per y-row: 6 wide loads, or 12 single ones), a part at the top and the
       // others between the phases below: issued all at once they queue up behind the address unit of the CU and the
       // wavefront - the only one on its SIMD, or one of two - stands still for a quarter of the pass.
@@ -477,13 +494,24 @@ vcg_apply_slab346(const VcgArgs a, const int nset)
       for (int j = 0; j < 16; j += (WIDE ? 4 : 1)) { mo[j] = mn[j]; }
       __builtin_amdgcn_sched_barrier(0);
       LGH_SLAB_STAMP(6); // wait + direction of the next set
-      // the slab of the E-vector: 16 contiguous doubles
-      if (act)
+      // the slab of the E-vector: 16 contiguous doubles per lane, stored as whole lines by groups of eight lanes (above)
+      if (!DYN || s0 >= 0)
       {
-         // (one scalar base + a 32-bit byte offset: a per-lane 64-bit pointer that lives across the pass is two registers too many)
-         char *yc = (char *)a.YE + (ye_lane + 8u * (unsigned)ND * (unsigned)e);
+         double *tl = RANK1 ? (sDb + wid * SBUF) : const_cast<double *>(sDcur); // (not RANK1: the data of this set has been used)
+         v2d *wp = (v2d *)(tl + lane * TP);
 #pragma unroll
-         for (int dy = 0; dy < D; dy++) { *(v4d *)(yc + 32 * dy) = v4d{o[4 * dy] * se, o[4 * dy + 1] * se, o[4 * dy + 2] * se, o[4 * dy + 3] * se}; }
+         for (int j = 0; j < 8; j++) { wp[j] = v2d{o[2 * j] * se, o[2 * j + 1] * se}; }
+         __builtin_amdgcn_wave_barrier(); // (one wavefront: its LDS instructions execute in order; this only pins the compiler)
+         const int s0c = max(s0, 0);
+         const int nel = min(ES, a.NE - ES * s0c); // elements of this set (the last one may be short)
+         const unsigned set_off = 8u * (unsigned)ND * (unsigned)(ES * s0c);
+         const v2d *rp = (const v2d *)(tl + (lane & ~7) * TP) + (lane & 7);
+#pragma unroll
+         for (int k = 0; k < 8; k++)
+         {
+            const v2d val = rp[k * (TP / 2)];
+            if (((st_ok >> k) & 1u) && (int)((st_el >> (3 * k)) & 7u) < nel) { *(v2d *)((char *)a.YE + (st_off[k] + set_off)) = val; }
+         }
       }
       if (a.store_wait) { __builtin_amdgcn_s_waitcnt(0x0F70); }
       LGH_SLAB_STAMP(7); // stores
@@ -505,7 +533,7 @@ vcg_apply_slab346(const VcgArgs a, const int nset)
       }
    };
    auto more = [&]() -> bool { return DYN ? (s0 >= 0 || s1 >= 0 || s2 >= 0) : (s0 >= 0); };
-   double *bcur = sDa + wid * SBUF, *bnxt = sDb + wid * SBUF;
+   double *bcur = sDa + wid * SBUF, *bnxt = RANK1 ? bcur : sDb + wid * SBUF; // (RANK1: the weights stay in sDa, sDb is the exchange buffer of the stores)
    int n_pass = 0;
    while (more())
    {
