@@ -1677,8 +1677,8 @@ int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
    {
       const char *e0 = getenv("LGH_SLAB_DEFER"); // A/B: 0 = the last workgroup of K1 folds the accumulators (ticket), K2 reads the result
       a.den_limbs = (limbs && !(e0 && e0[0] == '0')) ? (multi ? 2 : 1) : 0; // (several ranks: folded before the exchange, vcg_fold_den)
-      e0 = getenv("LGH_SLAB_STORE_WAIT"); // A/B: 0 / 1; default by mesh size
-      a.store_wait = e0 ? (e0[0] == '1' ? 1 : 0) : (c->NE >= kSlabStoreWaitElements ? 1 : 0);
+      e0 = getenv("LGH_SLAB_STORE_WAIT"); // A/B: 1 = a wavefront waits for the stores of a pass before the next one (it paid at 64^3 while the stores were partial lines: 306 vs 370 us; with whole lines 275 vs 248)
+      a.store_wait = (e0 && e0[0] == '1') ? 1 : 0;
    }
    {
       const char *e0 = getenv("LGH_K2_SKIP");

@@ -7,8 +7,7 @@ namespace lgh
 {
 
 constexpr int kVC = 3; // velocity components handled in lockstep
-constexpr int kSlabMinElements = 20000;  // default dispatch of the slab-form K1 (vcg_k1_form): 40.6 against 48.5 us at 32^3, 316 against 383 at 64^3
-constexpr int kSlabStoreWaitElements = 100000; // meshes that live in HBM: a wavefront waits for the stores of a pass before the next one (316 against 333 us at 64^3; 32^3: 44.5 against 40.6)
+constexpr int kSlabMinElements = 20000;  // default dispatch of the slab-form K1 (vcg_k1_form): 39.3 against 48.5 us at 32^3, 248 against 383 at 64^3
 constexpr int kTraceRec = 16; // debug (LGH_VCG_TRACE): 64-bit words per workgroup record of K1
 
 struct VcgScalars
