@@ -206,6 +206,26 @@ def measure_kernels(sim, sz):
     # the node kernel of the CG (K2) listed with it in a second figure
     agg = {"force_mass_aggregate": aggregate((3, 4, 0)), "force_mass_cg_aggregate": aggregate((3, 4, 0, 1)),
            "force_products_in_production": "formed inside qpoint_kernel (fused QUpdate): no force kernel runs in the timed steps"}
+    if 0 in raw:
+        # What `achieved` counts and what the kernel that ran really has to move (DESIGN.md "Roofline accounting").
+        # `achieved` is SURVEY 8(d)'s figure for the mass apply, 8 (NQ + 2 dim D1D^3) bytes per element: the quadrature
+        # data once, one E-vector in, one out.  The lockstep K1 departs from it on both sides: with compact mass data
+        # (lgh_mass_data_form: D[q, e] = W[q] s_e) it reads 8 bytes of quadrature data per element instead of 8 NQ,
+        # and it forms the search direction itself, d = z + beta d_old, z = r / diag - it gathers r, d_old (dim
+        # components) and 1 / diag where 8(d) has a single input vector.  `compulsory` is the unique footprint of those
+        # operands (every node vector once, the element output once): the least the launch can take from memory.
+        dim, D, N, NE, NQ = sz["dim"], sz["D1D"], sz["N"], sz["NE"], sz["NQ"]
+        form = ctypes.c_int(-1)
+        L.lgh_mass_data_form(ctx, ctypes.byref(form))
+        compact = form.value == 1 and KERNEL_NAMES[0].split(" ")[0] in ("vcg_apply_slab346", "vcg_apply_plane")
+        comp = 8 * (N * (2 * dim + 1) + NE * dim * D ** dim) + (8 * NE if compact else 8 * NE * NQ)
+        t = raw[0][1]
+        agg["k1_accounting"] = {
+            "achieved_counts": "SURVEY 8(d): 8 (NQ + 2 dim D1D^3) bytes per element and launch",
+            "sec8d_bytes_per_launch": bts[0],
+            "mass_data": "compact: one factor per element (8 NE bytes instead of 8 NQ NE)" if compact else "stored table",
+            "inputs": "r, d_old (dim components each) and 1/diag gathered; d = r/diag + beta d_old formed in the kernel",
+            "compulsory_bytes_per_launch": comp, "compulsory_GBs": 1e-9 * comp / t, "compulsory_frac": 1e-9 * comp / t / HBM_PEAK_GBS}
     return kern, agg
 
 
@@ -282,7 +302,7 @@ def run_leg(host_lib, args, steps, warmup, dev, force_multi=False):
     out = {"value": 1e-6 * dofs * 4 * rk / wall, "unit": "Mdofs*steps/s", "ms_per_step": 1e3 * wall / steps, "steps": steps,
            "elements": sz["global_NE"], "h1_dofs": sz["H1GTV"], "l2_dofs": sz["L2GTV"], "e_norm": sim.e_norm(), "t": sim.t,
            "kernels": {k: {"mean_us": v["mean_us"], "GBs": v["GBs"], "launches": v["launches"]} for k, v in kern.items()}}
-    out.update({k: ({"achieved": v["achieved"], "frac": v["frac"], "frac_of_achievable": v["frac_of_achievable"]} if isinstance(v, dict) else v)
+    out.update({k: ({"achieved": v["achieved"], "frac": v["frac"], "frac_of_achievable": v["frac_of_achievable"]} if (isinstance(v, dict) and "achieved" in v) else v)
                 for k, v in agg.items()})
     if force_multi:
         out["comm"] = measure_comm(sim, 1)

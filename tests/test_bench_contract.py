@@ -14,7 +14,7 @@ def _line(name):
 
 
 def test_bench_line_has_the_contract_fields():
-    d = _line("r2_bench.json")
+    d = _line("r3_bench.json")
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in d, key
@@ -38,21 +38,36 @@ def test_bench_line_has_the_contract_fields():
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["mean_launch_us"] * 1e-6) / 1e9) < 1e-6 * r["achieved"]
-    assert r["traffic"] is None or r["traffic"] >= r["algorithmic_bytes_per_launch"]
     assert "traffic_source" in r  # a counter figure is only reported for the build it was measured on
+    # `achieved` counts SURVEY 8(d)'s bytes; the line also says what the kernel that ran has to move (compact mass
+    # data: no quadrature table; three node vectors gathered): the counter traffic must cover that footprint, and with
+    # the table gone it lies BELOW the 8(d) figure
+    acc = r["k1_accounting"]
+    assert acc["sec8d_bytes_per_launch"] == r["algorithmic_bytes_per_launch"]
+    assert acc["compulsory_bytes_per_launch"] < r["algorithmic_bytes_per_launch"] and "compact" in acc["mass_data"]
+    assert abs(acc["compulsory_frac"] - acc["compulsory_bytes_per_launch"] / (r["mean_launch_us"] * 1e-6) / 1e9 / r["peak"]) < 1e-9
+    assert r["traffic"] is not None and acc["compulsory_bytes_per_launch"] <= r["traffic"] <= 1.5 * acc["compulsory_bytes_per_launch"]
+    assert abs(r["frac_of_achievable"] - r["achieved"] / r["achievable"]) < 1e-12
     # north_star quotes its target on the Force+Mass operator apply: F.1 + F^T v + the mass applies of the H1 CG
     for key in ("force_mass_aggregate", "force_mass_cg_aggregate"):
         a = r[key]
         assert abs(a["frac"] - a["achieved"] / r["peak"]) < 1e-12
         assert abs(a["achieved"] - 1e-9 * a["algorithmic_bytes_per_rk_step"] / a["seconds_per_rk_step"]) < 1e-6 * a["achieved"]
-    assert r["force_mass_aggregate"]["kernels"] == ["force_mult_3d", "force_mult_t_3d", "vcg_apply_plane"]
+    assert r["force_mass_aggregate"]["kernels"] == ["force_mult_3d", "force_mult_t_3d", "vcg_apply_slab346"]
     # the other single-GPU configs of BASELINE.json as extra legs: 64^3 Sedov (HBM-resident) and 64^3 Taylor-Green
     for leg in ("c3", "tg"):
         g = d["legs"][leg]
         assert g["elements"] == 262144 and g["value"] > 0 and 0 < g["force_mass_aggregate"]["frac"] < 1
     assert "Taylor-Green" in d["legs"]["tg"]["workload"] and "-rs 5" in d["legs"]["c3"]["workload"]
+    # 64^3 is HBM-resident: its K1 carries counter traffic of its own, from the same sha-matched source
+    assert d["legs"]["c3"]["roofline_traffic"]["k1_bytes_per_launch"] >= d["legs"]["c3"]["k1_accounting"]["compulsory_bytes_per_launch"]
+    # config 5 (Q5Q4) on one GPU, the developed-flow view of C2 and the N-rank code path on one rank
+    assert d["legs"]["c5"]["elements"] == 65536 and d["legs"]["c5"]["value"] > 0
+    assert d["legs"]["c2dev"]["value"] > 0
+    m = d["legs"]["c2multi"]
+    assert m["comm"]["ranks"] == 1 and m["comm"]["allreduce"]["per_rk_step"] > 0 and abs(m["ms_per_step_minus_single_rank_path"]) < 1.0
     b = d["cpu_baseline"]
-    for key in ("value", "unit", "cores", "kind", "sample"):
+    for key in ("value", "unit", "cores", "kind", "sample", "cpu_model"):
         assert key in b, key
     assert b["kind"] in ("port", "reference") and b["unit"] == d["unit"] and b["cores"] >= 1
 
@@ -60,7 +75,7 @@ def test_bench_line_has_the_contract_fields():
 def test_profiled_run_agrees_with_the_plain_run():
     """The same command under rocprofv3 --kernel-trace --stats: same workload, throughput within
     the profiler's overhead."""
-    a, b = _line("r2_bench.json"), _line("r2_bench_under_rocprofv3.json")
+    a, b = _line("r3_bench.json"), _line("r3_bench_under_rocprofv3.json")
     assert a["config"]["workload"] == b["config"]["workload"]
     assert 0.8 * a["value"] < b["value"] <= 1.05 * a["value"]
 
