@@ -2,6 +2,7 @@
 // timers, and the operator-level entry points declared in include/laghos_hip.h.
 #include <cstdarg>
 #include <cstdlib>
+#include <cmath>
 #include <algorithm>
 #include <limits>
 
@@ -282,6 +283,34 @@ static int create_impl(const lgh_config *cfg, lgh_ctx *c, const int kid)
    LGH_TRY(dev_alloc_copy(&c->G, cfg->G_h1, (size_t)c->Q1D * c->D1D));
    LGH_TRY(dev_alloc_copy(&c->Bl, cfg->B_l2, (size_t)c->Q1D * c->L1D));
    LGH_TRY(dev_alloc_copy(&c->W, cfg->weights, (size_t)c->NQ));
+   {
+      // Tensor-product rule?  w[i] = W[i, 0, 0] / w[0]^(dim - 1) with w[0] = W[0]^(1/dim); every entry of W must be the
+      // product of its three factors to 8 ulp.  The plane-form L2 mass apply then takes the weights from Q scalars
+      // instead of NQ loads per element batch (compact mass data only: value(q, e) = s_e w[qx] w[qy] w[qz]).
+      const int Q = c->Q1D, dim = c->dim;
+      std::vector<double> w1((size_t)Q);
+      const double w0 = (dim == 3) ? cbrt(cfg->weights[0]) : sqrt(cfg->weights[0]);
+      bool ok = std::isfinite(w0) && w0 > 0.0;
+      for (int i = 0; ok && i < Q; i++)
+      {
+         w1[i] = cfg->weights[i] / ((dim == 3) ? w0 * w0 : w0);
+         ok = std::isfinite(w1[i]) && w1[i] > 0.0;
+      }
+      // (the kernels keep half of them in scalar registers: w[i] = w[Q - 1 - i], as every rule on symmetric points has it)
+      for (int i = 0; ok && i < Q / 2; i++)
+      {
+         ok = std::fabs(w1[i] - w1[Q - 1 - i]) <= 8.9e-16 * w1[i];
+         w1[Q - 1 - i] = w1[i];
+      }
+      for (int q = 0; ok && q < c->NQ; q++)
+      {
+         const int qx = q % Q, qy = (q / Q) % Q, qz = q / (Q * Q);
+         const double prod = (dim == 3) ? w1[qx] * w1[qy] * w1[qz] : w1[qx] * w1[qy];
+         ok = std::fabs(prod - cfg->weights[q]) <= 1.8e-15 * std::fabs(cfg->weights[q]);
+      }
+      const char *senv = getenv("LGH_MASS_SEP"); // A/B: 0 = weights from the NQ-entry table
+      if (ok && !(senv && senv[0] == '0')) { LGH_TRY(dev_alloc_copy(&c->w1d, w1.data(), (size_t)Q)); }
+   }
    LGH_TRY(dev_alloc_copy(&c->gamma, cfg->gamma, (size_t)c->NE));
    const size_t nmap = (size_t)c->NE * c->ND;
    LGH_TRY(dev_alloc_copy(&c->h1map, cfg->h1_map, nmap));
@@ -382,7 +411,7 @@ int lgh_destroy(lgh_ctx *c)
    if (!c) { return LGH_OK; }
    (void)hipSetDevice(c->device);
    (void)hipStreamSynchronize(c->stream);
-   void *ptrs[] = {c->B, c->G, c->Bl, c->W, c->gamma, c->h1map, c->t_off, c->t_idx, c->t_ell, c->essmask[0],
+   void *ptrs[] = {c->B, c->G, c->Bl, c->W, c->w1d, c->gamma, c->h1map, c->t_off, c->t_idx, c->t_ell, c->essmask[0],
                    c->essmask[1], c->essmask[2], c->ess[0], c->ess[1], c->ess[2], c->owner,
                    c->stressJinvT, c->Jac0inv, c->Jac0inv_soa, c->rho0DetJ0w, c->massD, c->diagV, c->dinvV,
                    c->dt_est_dev, c->erhs_q, c->v_snap, c->dev_flags, c->ones_l2, c->massS, c->ones_ne, c->force_e_q, c->XE, c->YE, c->cg_r, c->cg_z, c->cg_d0, c->cg_d1, c->cg_y,

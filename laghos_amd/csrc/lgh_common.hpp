@@ -115,6 +115,7 @@ struct lgh_ctx
    // the mass kernels then read 8 bytes per element instead of 8 NQ.  -1: not looked at yet (set-up, lgh_mass_D handed
    // out), 0: no (massD as stored), 1: yes (lgh_mass.hip mass_data).  LGH_MASS_RANK1=0 keeps massD.
    double *massS, *ones_ne;
+   double *w1d = nullptr;   // one-dimensional weights when the rule is a tensor product, W[qx + Q (qy + Q qz)] = w[qx] w[qy] w[qz] (checked by lgh_create; nullptr otherwise)
    int mass_rank1;
    double *dt_est_dev;   // 1 double: running min of the point-wise estimate
    // Force products formed inside the fused QUpdate.  Validity is by construction, not by address: `fused_*_valid` says

@@ -41,6 +41,7 @@ struct MassArgs
    const double *Dq;  // [q + NQ*e] - mass_apply_l2_plane: value(q, e) = Dq[q + dqs e] * Se[e] (mass_data)
    const double *Se;
    int dqs;
+   const double *w1;  // mass_apply_l2_plane<.., SEP = true>: one-dimensional weights, value(q, e) = Se[e] w1[qx] w1[qy] w1[qz] (compact data of a tensor-product rule)
    const double *x;   // MODE 0/1 input; MODE 2/3: z (H1) or r (L2)
    const int *map;    // NE*ND or null
    double *y;         // E-vector (H1) or L2 vector output
@@ -292,7 +293,16 @@ mass_apply_3d(const MassArgs a)
 // The quadrature data is read straight from memory, one qy row of Q values ahead of its use (each value is
 // needed by exactly one thread: LDS staging would only add traffic); rows of Q consecutive doubles.
 // MODE 0: y = M x.  MODE 3: CG K1 of the L2 solve (d = r + beta d stored in place, den = (d, M d)).
-template <int L, int Q, int HY, int NEB, int MODE>
+// value of the other lane of an adjacent pair (quad_perm [1,0,3,2], as lane_pair_swap of lgh_vcg.hip)
+__device__ __forceinline__ double pair_swap(const double v)
+{
+   int lo = __double2loint(v), hi = __double2hiint(v);
+   lo = __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xF, 0xF, true);
+   hi = __builtin_amdgcn_mov_dpp(hi, 0xB1, 0xF, 0xF, true);
+   return __hiloint2double(hi, lo);
+}
+
+template <int L, int Q, int HY, int NEB, int MODE, bool SEP>
 __global__ void __launch_bounds__(Q *HY *NEB, 2)
 mass_apply_l2_plane(const MassArgs a)
 {
@@ -300,12 +310,13 @@ mass_apply_l2_plane(const MassArgs a)
    constexpr int TE = Q * HY, NT = TE * NEB, QH = Q / HY;
    static_assert(Q % HY == 0, "qy rows split evenly");
    constexpr int CS = NL | 1;            // odd strides: the broadcast reads of different elements hit different banks
-   constexpr int CE = (HY * LL * Q) | 1; // [h][dy,dz][qx]
+   static_assert(HY == 1 || HY == 2, "one lane or a pair of adjacent lanes per plane");
+   constexpr int CE = (LL * Q) | 1; // [dy,dz][qx]: the two lanes of a pair (HY = 2) hand over one summed plane (lane_pair_swap)
    __shared__ double sIn[NEB * CS], sE[NEB * CE], sB[Q * L];
    __shared__ double red[16];
    const int tid = threadIdx.x;
    const int eb = tid / TE, lt = tid - eb * TE;
-   const int h = lt / Q, qx = lt - h * Q;
+   const int qx = lt / HY, h = lt - qx * HY; // (the lanes of a pair are adjacent: TE is even, so h is the parity of the lane)
    const int e0 = blockIdx.x * NEB, e = e0 + eb;
    const bool active = (e < a.NE);
    double beta = 0.0;
@@ -336,9 +347,22 @@ mass_apply_l2_plane(const MassArgs a)
    // first row of this thread's quadrature data, in flight across the barrier
    const double *Dp = a.Dq + (size_t)(active ? e : 0) * a.dqs + qx + Q * (h * QH);
    const double se = a.Se[active ? e : 0];
-   double dq[Q];
+   double dq[SEP ? 1 : Q];
+   if (!SEP)
+   {
 #pragma unroll
-   for (int qz = 0; qz < Q; qz++) { dq[qz] = Dp[Q * Q * qz] * se; }
+      for (int qz = 0; qz < Q; qz++) { dq[qz] = Dp[Q * Q * qz] * se; }
+   }
+   // SEP: value(q, e) = se w[qx] w[qy] w[qz] - the weights in scalar registers, no loads and no row held ahead
+   double ws[SEP ? (Q + 1) / 2 : 1]; // (mirror symmetric, checked by lgh_create: w[q] = w[Q - 1 - q])
+   auto wq = [&](const int q) -> double { return ws[SEP ? (q < (Q + 1) / 2 ? q : Q - 1 - q) : 0]; };
+   double wxe = 0.0;
+   if (SEP)
+   {
+#pragma unroll
+      for (int q = 0; q < (Q + 1) / 2; q++) { ws[q] = uniform_f64(a.w1[q]); }
+      wxe = a.w1[qx] * se;
+   }
    __syncthreads();
    const double *sI = sIn + eb * CS;
    // the 1-D table in scalar registers, in half: the Bernstein basis at Gauss-Legendre points is mirror symmetric,
@@ -370,11 +394,19 @@ mass_apply_l2_plane(const MassArgs a)
 #pragma unroll
    for (int r = 0; r < QH; r++)
    {
-      double dn[Q];
-      if (r + 1 < QH)
+      double dn[SEP ? 1 : Q];
+      if (!SEP && r + 1 < QH)
       {
 #pragma unroll
          for (int qz = 0; qz < Q; qz++) { dn[qz] = Dp[Q * (r + 1) + Q * Q * qz] * se; }
+      }
+      double wrow = 0.0; // SEP: se w[qx] w[qy] of this row
+      if (SEP)
+      {
+         double wy = wq(r);
+#pragma unroll
+         for (int hh = 1; hh < HY; hh++) { wy = (h == hh) ? wq(hh * QH + r) : wy; }
+         wrow = wxe * wy;
       }
       // the table row of qy = h*QH + r (h differs between lanes: select, not index)
       double by[L];
@@ -402,7 +434,7 @@ mass_apply_l2_plane(const MassArgs a)
          double u = 0.0;
 #pragma unroll
          for (int dz = 0; dz < L; dz++) { u = fma(Bt(qz + Q * dz), wr[dz], u); }
-         cz[qz] = u * dq[qz];
+         cz[qz] = SEP ? (u * wrow) * wq(qz) : u * dq[SEP ? 0 : qz];
       }
 #pragma unroll
       for (int dz = 0; dz < L; dz++)
@@ -413,15 +445,34 @@ mass_apply_l2_plane(const MassArgs a)
 #pragma unroll
          for (int dy = 0; dy < L; dy++) { acc[dy + L * dz] = fma(by[dy], u, acc[dy + L * dz]); }
       }
-      if (r + 1 < QH)
+      if (!SEP && r + 1 < QH)
       {
 #pragma unroll
          for (int qz = 0; qz < Q; qz++) { dq[qz] = dn[qz]; }
       }
    }
-   double *sEe = sE + eb * CE + h * (LL * Q);
+   // hand the plane over; HY = 2: lane h of a pair delivers the (dy,dz) entries k = h (mod 2), summed over both lanes
+   double *sEe = sE + eb * CE;
+   if (HY == 1)
+   {
 #pragma unroll
-   for (int k = 0; k < LL; k++) { sEe[qx + Q * k] = acc[k]; }
+      for (int k = 0; k < LL; k++) { sEe[qx + Q * k] = acc[k]; }
+   }
+   else
+   {
+#pragma unroll
+      for (int k = 0; k + 1 < LL; k += 2)
+      {
+         const double give = h ? acc[k] : acc[k + 1];
+         const double keep = h ? acc[k + 1] : acc[k];
+         sEe[qx + Q * (k + h)] = keep + pair_swap(give);
+      }
+      if (LL & 1)
+      {
+         const double tot = acc[LL - 1] + pair_swap(acc[LL - 1]);
+         if (h == 0) { sEe[qx + Q * (LL - 1)] = tot; }
+      }
+   }
    __syncthreads();
    // backward x: thread (lx = qx < L, h) sums the Q planes of both halves for its share of the (dy,dz) pairs
    double dot = 0.0;
@@ -440,11 +491,7 @@ mass_apply_l2_plane(const MassArgs a)
          {
             double u = 0.0;
 #pragma unroll
-            for (int hh = 0; hh < HY; hh++)
-            {
-#pragma unroll
-               for (int q = 0; q < Q; q++) { u = fma(bt[q], sEa[hh * (LL * Q) + q + Q * k], u); }
-            }
+            for (int q = 0; q < Q; q++) { u = fma(bt[q], sEa[q + Q * k], u); }
             a.y[(size_t)e * NL + qx + L * k] = u;
             if (MODE == 3) { dot = fma(sI[qx + L * k], u, dot); }
          }
@@ -592,9 +639,13 @@ template <int MODE> static int launch_mass(lgh_ctx *c, int space, const MassArgs
          MassArgs a = a0; // (the plane form takes the mass data in its compact form where it has one)
          const int rc_md = mass_data(c, &a.Dq, &a.dqs, &a.Se);
          if (rc_md) { return rc_md; }
-         if (id == 0x336) { hipLaunchKernelGGL((mass_apply_l2_plane<3, 6, 1, 42, M>), dim3(ceil_div(c->NE, 42)), dim3(252), 0, c->stream, a); }
-         else if (id == 0x348) { hipLaunchKernelGGL((mass_apply_l2_plane<4, 8, 1, 32, M>), dim3(ceil_div(c->NE, 32)), dim3(256), 0, c->stream, a); }
-         else { hipLaunchKernelGGL((mass_apply_l2_plane<5, 10, 2, 12, M>), dim3(ceil_div(c->NE, 12)), dim3(240), 0, c->stream, a); }
+         a.w1 = (a.dqs == 0) ? c->w1d : nullptr;
+#define LGH_L2P(L_, Q_, HY_, NEB_) do { if (a.w1) { hipLaunchKernelGGL((mass_apply_l2_plane<L_, Q_, HY_, NEB_, M, true>), dim3(ceil_div(c->NE, NEB_)), dim3(Q_ * HY_ * NEB_), 0, c->stream, a); } \
+                                        else { hipLaunchKernelGGL((mass_apply_l2_plane<L_, Q_, HY_, NEB_, M, false>), dim3(ceil_div(c->NE, NEB_)), dim3(Q_ * HY_ * NEB_), 0, c->stream, a); } } while (0)
+         if (id == 0x336) { LGH_L2P(3, 6, 1, 42); }
+         else if (id == 0x348) { LGH_L2P(4, 8, 1, 32); }
+         else { LGH_L2P(5, 10, 2, 12); }
+#undef LGH_L2P
          LGH_HIP_CHECK(hipGetLastError());
          return LGH_OK;
       }

@@ -552,7 +552,7 @@ __device__ __forceinline__ double lane_pair_swap(const double v)
    return __hiloint2double(hi, lo);
 }
 
-template <int D, int Q, int HY, int NEB>
+template <int D, int Q, int HY, int NEB, bool SEP>
 __global__ void __launch_bounds__(kVC *Q *HY *NEB, 2)
 vcg_apply_plane_ho(const VcgArgs a)
 {
@@ -567,6 +567,8 @@ vcg_apply_plane_ho(const VcgArgs a)
    constexpr int GPT = (NEB * ND + NT - 1) / NT;
    constexpr int DPT = (NEB * NQ + NT - 1) / NT;
    static_assert(kVC * CE >= NQ, "the quadrature data of an element is staged where its x-contracted planes go later");
+   // SEP (compact mass data of a tensor-product rule): value(q, e) = Se[e] w[qx] w[qy] w[qz] with the weights in scalar
+   // registers - no sweep over the quadrature data, nothing staged in LDS, one barrier less
    __shared__ double smem[NEB * PER];
    __shared__ double sB[QD];
    __shared__ double red[48];
@@ -590,12 +592,24 @@ vcg_apply_plane_ho(const VcgArgs a)
    }
    if (a.s->all_done) { return; }
    // quadrature data of the batch: one coalesced sweep while the registers are still free
-   double dst[DPT];
-#pragma unroll
-   for (int k = 0; k < DPT; k++)
+   double dst[SEP ? 1 : DPT];
+   if (!SEP)
    {
-      const int i = tid + k * NT, ei = i / NQ;
-      dst[k] = (i < nel * NQ) ? a.Dq[(size_t)(e0 + ei) * a.dqs + (i - ei * NQ)] * a.Se[e0 + ei] : 0.0;
+#pragma unroll
+      for (int k = 0; k < DPT; k++)
+      {
+         const int i = tid + k * NT, ei = i / NQ;
+         dst[k] = (i < nel * NQ) ? a.Dq[(size_t)(e0 + ei) * a.dqs + (i - ei * NQ)] * a.Se[e0 + ei] : 0.0;
+      }
+   }
+   double ws[SEP ? (Q + 1) / 2 : 1]; // (mirror symmetric, checked by lgh_create: w[q] = w[Q - 1 - q])
+   auto wq = [&](const int q) -> double { return ws[SEP ? (q < (Q + 1) / 2 ? q : Q - 1 - q) : 0]; };
+   double wxe = 0.0;
+   if (SEP)
+   {
+#pragma unroll
+      for (int q = 0; q < (Q + 1) / 2; q++) { ws[q] = uniform_f64(a.w1[q]); }
+      wxe = a.w1[qx] * a.Se[min(e, a.NE - 1)];
    }
    const bool first = a.s->first != 0;
    bool todo[kVC];
@@ -614,14 +628,17 @@ vcg_apply_plane_ho(const VcgArgs a)
       return idx < HB ? Bs[idx] : Bs[QD - 1 - idx];
    };
    for (int i = tid; i < QD; i += NT) { sB[i] = a.B[i]; }
-#pragma unroll
-   for (int k = 0; k < DPT; k++)
+   if (!SEP)
    {
-      const int i = tid + k * NT;
-      if (i < NEB * NQ)
+#pragma unroll
+      for (int k = 0; k < DPT; k++)
       {
-         const int el = i / NQ, j = i - el * NQ;
-         smem[el * PER + kVC * CS + j] = dst[k];
+         const int i = tid + k * NT;
+         if (i < NEB * NQ)
+         {
+            const int el = i / NQ, j = i - el * NQ;
+            smem[el * PER + kVC * CS + j] = dst[k];
+         }
       }
    }
    // directions d = z + beta d of the three components (K2 stores the same values)
@@ -683,6 +700,13 @@ vcg_apply_plane_ho(const VcgArgs a)
          for (int dy = 0; dy < D; dy++) { u = fma(by[dy], t[dy + D * dz], u); }
          wr[dz] = u;
       }
+      double wrow = 0.0; // SEP: s_e w[qx] w[qy] of this row
+      if (SEP)
+      {
+         double wy = wq(r);
+         if (HY == 2) { wy = h ? wq(QH + r) : wy; }
+         wrow = wxe * wy;
+      }
       double cz[Q];
 #pragma unroll
       for (int qz = 0; qz < Q; qz++)
@@ -690,7 +714,7 @@ vcg_apply_plane_ho(const VcgArgs a)
          double u = 0.0;
 #pragma unroll
          for (int dz = 0; dz < D; dz++) { u = fma(Bc(qz, dz), wr[dz], u); }
-         cz[qz] = u * sD[qx + Q * (h * QH + r) + Q * Q * qz];
+         cz[qz] = SEP ? (u * wrow) * wq(qz) : u * sD[qx + Q * (h * QH + r) + Q * Q * qz];
       }
 #pragma unroll
       for (int dz = 0; dz < D; dz++)
@@ -702,7 +726,7 @@ vcg_apply_plane_ho(const VcgArgs a)
          for (int dy = 0; dy < D; dy++) { acc[dy + D * dz] = fma(by[dy], u, acc[dy + D * dz]); }
       }
    }
-   __syncthreads(); // every lane of the element has read its quadrature data
+   if (!SEP) { __syncthreads(); } // every lane of the element has read its quadrature data
    // hand the plane over: lane h of a pair delivers the (dy,dz) entries k = h (mod 2)
    if (HY == 1)
    {
@@ -1509,7 +1533,8 @@ template <int D, int Q> static void launch_vcg_plane(lgh_ctx *c, const VcgArgs &
 
 template <int D, int Q, int HY, int NEB> static void launch_vcg_plane_ho(lgh_ctx *c, const VcgArgs &a)
 {
-   hipLaunchKernelGGL((vcg_apply_plane_ho<D, Q, HY, NEB>), dim3(ceil_div(c->NE, NEB)), dim3(kVC * Q * HY * NEB), 0, c->stream, a);
+   if (a.w1) { hipLaunchKernelGGL((vcg_apply_plane_ho<D, Q, HY, NEB, true>), dim3(ceil_div(c->NE, NEB)), dim3(kVC * Q * HY * NEB), 0, c->stream, a); }
+   else { hipLaunchKernelGGL((vcg_apply_plane_ho<D, Q, HY, NEB, false>), dim3(ceil_div(c->NE, NEB)), dim3(kVC * Q * HY * NEB), 0, c->stream, a); }
 }
 
 template <int D, int Q> static void launch_vcg_apply(lgh_ctx *c, const VcgArgs &a)
@@ -1653,6 +1678,7 @@ int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
    a.B = c->B;
    a.DqFull = c->massD;
    rc = mass_data(c, &a.Dq, &a.dqs, &a.Se);
+   a.w1 = (a.dqs == 0) ? c->w1d : nullptr;
    if (rc) { return rc; }
    a.map = c->h1map;
    a.ell = c->t_ell;

@@ -185,6 +185,7 @@ struct VcgArgs
    int NE, N;
    const double *B, *Dq;  // Dq: quadrature data of the mass operator, value(q, e) = Dq[q + dqs e] * Se[e] (mass_data, lgh_mass.hip) in the
    const double *Se;      // plane and slab forms of K1; the column and matrix-core forms read DqFull[q + NQ e]
+   const double *w1;      // vcg_apply_plane_ho<.., SEP = true>: one-dimensional weights of a tensor-product rule (compact data only), nullptr otherwise
    const double *DqFull;
    int dqs;
    const int *map;

@@ -758,6 +758,10 @@ KERNEL_SWITCHES = [
     ((3, 2), {"LGH_K2_NODE_WEIGHT": "-1"}, "tol"),
     ((3, 2), {"LGH_MASS_RANK1": "0"}, "tol"),
     ((4, 3), {"LGH_MASS_RANK1": "0"}, "tol"),
+    ((3, 2), {"LGH_MASS_SEP": "0"}, "tol"),
+    ((4, 3), {"LGH_MASS_SEP": "0"}, "tol"),
+    ((5, 4), {"LGH_MASS_SEP": "0"}, "tol"),
+    ((5, 4), {"LGH_MASS_RANK1": "0"}, "tol"),
     ((4, 3), {"LGH_L2_PLANE": "0"}, "tol"),
     ((4, 3), {"LGH_K2P": "0"}, "tol"),
 ]
@@ -776,10 +780,14 @@ def test_kernel_switches(order, switches, claim, monkeypatch):
     S = deformed_state(prob, seed=45)
     H1V = prob.H1V
 
+    # (order 4 Bernstein mass matrix without preconditioner: the energy CG needs more than the reference's cap of 300
+    #  iterations to converge, and an iteration cut off unconverged amplifies every rounding difference - let it finish)
+    max_iter = 300 if order != (5, 4) else 4000
+
     def run():
         g = make_gpu(prob)
         try:
-            g.cg_tol = 1e-14
+            g.cg_tol, g.cg_max_iter = 1e-14, max_iter
             Sd = g.ctx.to_dev(S)
             dS = g.ctx.zeros(S.size)
             g.reset_quadrature_data()
@@ -792,7 +800,7 @@ def test_kernel_switches(order, switches, claim, monkeypatch):
     if order not in _switch_default:
         o = make_oracle(prob)
         try:
-            o.cg_tol = 1e-14
+            o.cg_tol, o.cg_max_iter = 1e-14, max_iter
             dS_o = np.empty_like(S)
             o.qdata_is_current = False
             o.mult(S, dS_o)
@@ -805,6 +813,6 @@ def test_kernel_switches(order, switches, claim, monkeypatch):
         monkeypatch.setenv(k, v)
     dS = run()
     assert rel_err(dS[H1V:2 * H1V], dS_o[H1V:2 * H1V]) < 1e-10
-    assert rel_err(dS[2 * H1V:], dS_o[2 * H1V:]) < 1e-10
+    assert rel_err(dS[2 * H1V:], dS_o[2 * H1V:]) < (1e-10 if order != (5, 4) else 1e-8)  # (cond ~ 1e6 at order 4)
     if claim == "bits":
         assert np.array_equal(dS, dS_def)
