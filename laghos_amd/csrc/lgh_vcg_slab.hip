@@ -161,6 +161,7 @@ vcg_apply_slab346(const VcgArgs a, const int nset)
    __shared__ double red[48];
 
    const int tid = threadIdx.x, lane = tid & 63;
+   const unsigned long long t_enter = TRACE ? wall_clock64() : 0ull; // debug: the workgroup is on its CU
    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6); // wave-uniform: set indices and their base addresses stay in scalar registers
    const int g = lane >> 4, n = lane & 15;
    const int ni = min(n, 14), el = ni / 3, c = ni - 3 * el;
@@ -183,11 +184,12 @@ vcg_apply_slab346(const VcgArgs a, const int nset)
    int s0, s1, s2;
    if (DYN)
    {
-      if (tid == 0) { s_next = 0; }
-      __syncthreads();
-      s0 = draw();
-      s1 = draw();
-      s2 = draw();
+      // the first three sets of a wavefront are fixed (no LDS round trips and no barrier in front of the first load of
+      // the kernel); the queue takes over from there - its counter is in place long before anybody draws (barrier below)
+      if (tid == 0) { s_next = 3u * NW; }
+      s0 = (wid < wg_len) ? wg_base + wid : -1;
+      s1 = (NW + wid < wg_len) ? wg_base + NW + wid : -1;
+      s2 = (2 * NW + wid < wg_len) ? wg_base + 2 * NW + wid : -1;
    }
    else
    {
@@ -222,24 +224,9 @@ vcg_apply_slab346(const VcgArgs a, const int nset)
    };
    load_map(s, mo); // in flight while the scalars are read
 
-   if (a.s->all_done) { return; }
-   const bool first = a.s->first != 0;
-   bool todo[kVC];
-   double beta[kVC];
-#pragma unroll
-   for (int k = 0; k < kVC; k++) { todo[k] = a.s->done[k] == 0; }
-   if (a.multi && !first && !vcg_pending_update(a.s, a.iter, blockIdx.x == 0 && tid == 0, todo)) { return; }
-#pragma unroll
-   for (int k = 0; k < kVC; k++) { beta[k] = (first || !todo[k]) ? 0.0 : a.s->rz[k] / a.s->rz_prev[k]; }
-   const bool mine = (c == 0) ? todo[0] : (c == 1) ? todo[1] : todo[2];
-   const double betac = (c == 0) ? beta[0] : (c == 1) ? beta[1] : beta[2];
-
-   double Bsr[HB];
-#pragma unroll
-   for (int i = 0; i < HB; i++) { Bsr[i] = uniform_f64(a.B[i]); }
-   auto Bs = [&](const int idx) -> double { return (SYM && idx >= HB) ? Bsr[QD - 1 - idx] : Bsr[idx]; };
    // node vectors: one scalar base + 32-bit byte offsets (vcg_slab_available checks kVC * N * 8 < 2^32).  In the first
    // iteration (beta = 0) the old direction is not defined: r is read in its place and multiplied by zero.
+   const bool first = (a.iter == 1); // (= a.s->first, without a memory round trip in front of the gathers)
    const unsigned coff = 8u * (unsigned)c * (unsigned)a.N;
    const double *dsrc = first ? a.r : a.d;
    __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): the one-time loads are complete before the pipelined loop (see vcg_apply_plane)
@@ -300,6 +287,25 @@ vcg_apply_slab346(const VcgArgs a, const int nset)
          __builtin_amdgcn_global_load_lds(a.Dq + t, (__attribute__((address_space(3))) void *)(sDa + wid * SBUF + 128 * k), 16, 0, 0);
       }
    }
+   load_gather();
+   load_dq(s, sDa + wid * SBUF);
+   load_map(DYN ? max(s1, 0) : s1, mo);
+   // (the scalars of the solve are looked at with the first loads of the kernel already in flight)
+   if (a.s->all_done) { __builtin_amdgcn_s_waitcnt(0x0F70); return; } // (nothing in flight into the LDS of a workgroup that is gone)
+   bool todo[kVC];
+   double beta[kVC];
+#pragma unroll
+   for (int k = 0; k < kVC; k++) { todo[k] = a.s->done[k] == 0; }
+   if (a.multi && !first && !vcg_pending_update(a.s, a.iter, blockIdx.x == 0 && tid == 0, todo)) { __builtin_amdgcn_s_waitcnt(0x0F70); return; }
+#pragma unroll
+   for (int k = 0; k < kVC; k++) { beta[k] = (first || !todo[k]) ? 0.0 : a.s->rz[k] / a.s->rz_prev[k]; }
+   const bool mine = (c == 0) ? todo[0] : (c == 1) ? todo[1] : todo[2];
+   const double betac = (c == 0) ? beta[0] : (c == 1) ? beta[1] : beta[2];
+
+   double Bsr[HB];
+#pragma unroll
+   for (int i = 0; i < HB; i++) { Bsr[i] = uniform_f64(a.B[i]); }
+   auto Bs = [&](const int idx) -> double { return (SYM && idx >= HB) ? Bsr[QD - 1 - idx] : Bsr[idx]; };
    // (RANK1: A d = s_e (B^T W B d) - the element factor multiplies the 16 outputs and the partial of (d, A d) at the
    //  end of the pass, not the 54 point values; loaded with the gathers of the pass, two registers)
    // direction d = z + beta d (K2 stores the same values)
@@ -333,11 +339,9 @@ vcg_apply_slab346(const VcgArgs a, const int nset)
    long long acc[kLimbs] = {0, 0, 0, 0};
    bool acc_bad = false;
    const int accE = exact_scale((c == 0) ? a.s->rz[0] : (c == 1) ? a.s->rz[1] : a.s->rz[2]);
-   load_gather();
-   load_dq(s, sDa + wid * SBUF);
-   load_map(DYN ? max(s1, 0) : s1, mo);
    __builtin_amdgcn_s_waitcnt(0x0F70);
    convert();
+   if (DYN) { __syncthreads(); } // s_next is in place (the first draw is a pass away)
    // debug (LGH_VCG_TRACE): wall-clock stamps of wave 0 and the shader cycles it spends waiting for the loads of a set
    unsigned long long t_start = 0, t_loop = 0, c_wait = 0, c_loop = 0;
    unsigned long long c_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, c_prev = 0; // shader cycles per phase of the loop body (wave 0)
@@ -589,6 +593,7 @@ vcg_apply_slab346(const VcgArgs a, const int nset)
             a.trace[kTraceRec * blockIdx.x + 0] = t_start;
             a.trace[kTraceRec * blockIdx.x + 1] = t_loop;
             a.trace[kTraceRec * blockIdx.x + 2] = wall_clock64();
+            a.trace[kTraceRec * blockIdx.x + 12] = t_enter;
             a.trace[kTraceRec * blockIdx.x + 3] = (c_wait << 32) | (c_loop & 0xffffffffull);
             for (int k = 0; k < 8; k++) { a.trace[kTraceRec * blockIdx.x + 4 + k] = (TRACE == 1) ? (k < NW ? s_twave[k] : 0ull) : c_ph[k]; }
          }
@@ -640,6 +645,7 @@ vcg_apply_slab346(const VcgArgs a, const int nset)
          a.trace[kTraceRec * blockIdx.x + 0] = t_start;
          a.trace[kTraceRec * blockIdx.x + 1] = t_loop;
          a.trace[kTraceRec * blockIdx.x + 2] = wall_clock64();
+            a.trace[kTraceRec * blockIdx.x + 12] = t_enter;
          a.trace[kTraceRec * blockIdx.x + 3] = (c_wait << 32) | (c_loop & 0xffffffffull);
          for (int k = 0; k < 8; k++) { a.trace[kTraceRec * blockIdx.x + 4 + k] = c_ph[k]; }
       }
@@ -654,6 +660,7 @@ vcg_apply_slab346(const VcgArgs a, const int nset)
       a.trace[kTraceRec * blockIdx.x + 0] = t_start;
       a.trace[kTraceRec * blockIdx.x + 1] = t_loop;
       a.trace[kTraceRec * blockIdx.x + 2] = wall_clock64();
+            a.trace[kTraceRec * blockIdx.x + 12] = t_enter;
       a.trace[kTraceRec * blockIdx.x + 3] = (c_wait << 32) | (c_loop & 0xffffffffull); // cycles waiting | cycles in the loop
       for (int k = 0; k < 8; k++) { a.trace[kTraceRec * blockIdx.x + 4 + k] = c_ph[k]; }
    }

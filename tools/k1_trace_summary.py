@@ -14,6 +14,9 @@ print(len(a), "workgroups")
 print("start   ", q(us(a[:, 1])))
 print("loop end", q(us(a[:, 2])))
 print("end     ", q(us(a[:, 3])))
+if a.shape[1] >= 14 and a[:, 13].min() > 0:
+    print("enter   ", q(us(a[:, 13])), " (workgroup on its CU; `start` is the first pass: the difference is the prologue)")
+    print("prologue", q((a[:, 1] - a[:, 13]) / 100.0))
 if len(sys.argv) > 2 and sys.argv[2] == "mfma":
     wait, loop = a[:, 4] >> 32, a[:, 4] & 0xffffffff
     print("loop cycles (wave 0)   ", q(loop))
