@@ -510,11 +510,22 @@ vcg_apply_slab346(const VcgArgs a, const int nset)
          const int nel = min(ES, a.NE - ES * s0c); // elements of this set (the last one may be short)
          const unsigned set_off = 8u * (unsigned)ND * (unsigned)(ES * s0c);
          const v2d *rp = (const v2d *)(tl + (lane & ~7) * TP) + (lane & 7);
+         // (all eight reads first, pinned: inside the predicated blocks each of them would be followed by a wait for
+         //  the LDS - eight round trips in a row, a seventh of the pass)
+         double vlo[8], vhi[8];
 #pragma unroll
          for (int k = 0; k < 8; k++)
          {
             const v2d val = rp[k * (TP / 2)];
-            if (((st_ok >> k) & 1u) && (int)((st_el >> (3 * k)) & 7u) < nel) { *(v2d *)((char *)a.YE + (st_off[k] + set_off)) = val; }
+            vlo[k] = val[0];
+            vhi[k] = val[1];
+         }
+#pragma unroll
+         for (int k = 0; k < 8; k++) { asm volatile("" : "+v"(vlo[k]), "+v"(vhi[k])); }
+#pragma unroll
+         for (int k = 0; k < 8; k++)
+         {
+            if (((st_ok >> k) & 1u) && (int)((st_el >> (3 * k)) & 7u) < nel) { *(v2d *)((char *)a.YE + (st_off[k] + set_off)) = v2d{vlo[k], vhi[k]}; }
          }
       }
       if (a.store_wait) { __builtin_amdgcn_s_waitcnt(0x0F70); }
