@@ -350,7 +350,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="skip the extra legs (64^3 Sedov / Taylor-Green, Q5Q4, developed flow, N-rank path)")
     ap.add_argument("--legs", default="c3,tg,c5,c2dev,c2multi", help="comma-separated extra legs of a single-GPU run")
-    ap.add_argument("--watchdog", type=float, default=900.0,
+    ap.add_argument("--watchdog", type=float, default=300.0,
                     help="several ranks: seconds a rank may spend without finishing a step before it reports and exits (a mismatched collective would otherwise hang silently)")
     a = ap.parse_args()
 
