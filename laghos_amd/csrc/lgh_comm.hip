@@ -238,7 +238,7 @@ bool halo_can_piggyback(const lgh_ctx *c)
 
 // extra != nullptr (device, nextra <= 3 doubles, requires halo_can_piggyback): replaced
 // by its sum over all ranks, carried by the same messages
-int halo_sum(lgh_ctx *c, double *v, int ncomp, double *extra, int nextra)
+int halo_sum(lgh_ctx *c, double *v, int ncomp, double *extra, int nextra, bool packed)
 {
    Comm *cm = c->comm;
    if (!cm || cm->n_nbr == 0) { return LGH_OK; }
@@ -255,10 +255,14 @@ int halo_sum(lgh_ctx *c, double *v, int ncomp, double *extra, int nextra)
    // ncomp == 0 (v unused): the messages carry the scalars only - a sum over the ranks as one
    // exchange with every peer (allreduce_dev uses it in all-pairs partitions)
    const long npack = std::max((long)tot * ncomp, (long)cm->n_nbr * nx);
-   hipLaunchKernelGGL(halo_pack_k, dim3(ceil_div(npack, 256)), dim3(256), 0, c->stream, tot,
-                      ncomp, c->N, cm->nodes, cm->pos, cm->cnt, v, sbuf, cm->n_nbr, nx, cm->d_base, cm->d_cnt,
-                      extra);
-   LGH_HIP_CHECK(hipGetLastError());
+   if (packed && ch2) { set_error("halo_sum: pre-packed messages use the main channel"); return LGH_ERR_ARG; }
+   if (!packed)
+   {
+      hipLaunchKernelGGL(halo_pack_k, dim3(ceil_div(npack, 256)), dim3(256), 0, c->stream, tot,
+                         ncomp, c->N, cm->nodes, cm->pos, cm->cnt, v, sbuf, cm->n_nbr, nx, cm->d_base, cm->d_cnt,
+                         extra);
+      LGH_HIP_CHECK(hipGetLastError());
+   }
    auto combine = [&]() {
       const long ncomb = std::max((long)cm->n_shared * ncomp, (long)nx);
       hipLaunchKernelGGL(halo_combine_k, dim3(ceil_div(ncomb, 256)), dim3(256), 0,
@@ -308,6 +312,15 @@ int halo_sum(lgh_ctx *c, double *v, int ncomp, double *extra, int nextra)
 // may the energy solve run its reductions on the context's second stream?
 bool comm_second_channel(const lgh_ctx *c) { return c->comm && c->comm->channel2; }
 
+bool comm_pack_tables(const lgh_ctx *c, HaloPackTables *t)
+{
+   const Comm *cm = c->comm;
+   if (!cm || cm->n_nbr == 0 || !cm->sh_off || !cm->sendbuf) { return false; }
+   t->sh_off = cm->sh_off; t->sh_src = cm->sh_src; t->pos = cm->pos; t->cnt = cm->cnt;
+   t->base = cm->d_base; t->ncnt = cm->d_cnt; t->sbuf = cm->sendbuf; t->n_nbr = cm->n_nbr;
+   return true;
+}
+
 void comm_shared_nodes(const lgh_ctx *c, const uint8_t **hmask, const int **sh_node, int *n_shared)
 {
    const Comm *cm = c->comm;
@@ -316,7 +329,7 @@ void comm_shared_nodes(const lgh_ctx *c, const uint8_t **hmask, const int **sh_n
    *n_shared = (cm && cm->hmask) ? cm->n_shared : 0;
 }
 
-int allreduce_dev(lgh_ctx *c, double *dev, int count, int op)
+int allreduce_dev(lgh_ctx *c, double *dev, int count, int op, bool packed)
 {
    Comm *cm = c->comm;
    // Sums of up to three scalars in an all-pairs partition (the CG dot products on <= 2x2x2 ranks):
@@ -324,8 +337,9 @@ int allreduce_dev(lgh_ctx *c, double *dev, int count, int op)
    // messages, instead of a ring / tree all-reduce - one hop, bit-identical on every rank.
    if (op == 0 && count >= 1 && count <= 3 && cm && cm->n_nbr > 0 && halo_can_piggyback(c))
    {
-      return halo_sum(c, nullptr, 0, dev, count);
+      return halo_sum(c, nullptr, 0, dev, count, packed && !c->on_stream2);
    }
+   if (packed) { set_error("allreduce_dev: pre-packed sums need the all-pairs exchange"); return LGH_ERR_ARG; }
    if (cm && cm->local)
    {
       LocalGroup *g = cm->local.get();

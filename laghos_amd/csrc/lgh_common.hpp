@@ -446,10 +446,21 @@ int vec_axpby(lgh_ctx *c, double *z, double a, const double *x, double b, const 
 int vec_neg_inplace(lgh_ctx *c, double *y, long n);
 int vec_zero_list(lgh_ctx *c, double *y, const int *list, int n);
 int vec_dot(lgh_ctx *c, const double *x, const double *y, const double *w, long n, double *dev_out);
-int halo_sum(lgh_ctx *c, double *v, int ncomp, double *extra = nullptr, int nextra = 0);
+// packed: the caller's own kernel has already put the node values / scalars into the send buffer of the main channel
+// (HaloPackTables: what it needs for that) - the exchange then starts without a pack kernel
+int halo_sum(lgh_ctx *c, double *v, int ncomp, double *extra = nullptr, int nextra = 0, bool packed = false);
+struct HaloPackTables
+{
+   const int *sh_off, *sh_src; // CSR over the unique shared nodes: entries of the concatenated neighbour lists (-1: own value)
+   const int *pos, *cnt;       // entry j -> offset of its node value in the buffer (component c at + c * cnt[j])
+   const int *base, *ncnt;     // neighbour k -> start of its block, nodes in it (scalars sit behind ncomp * ncnt[k] values)
+   double *sbuf;
+   int n_nbr;
+};
+bool comm_pack_tables(const lgh_ctx *c, HaloPackTables *t); // false: no neighbours / no tables
 bool halo_can_piggyback(const lgh_ctx *c);
 bool comm_second_channel(const lgh_ctx *c); // reductions may run on the context's second stream as well
-int allreduce_dev(lgh_ctx *c, double *dev, int count, int op);
+int allreduce_dev(lgh_ctx *c, double *dev, int count, int op, bool packed = false); // packed: as halo_sum (sums that travel as one exchange with every peer only)
 
 // bracket one launch of kernel `id` with an event pair when sampling is on
 inline void kt_begin(lgh_ctx *c, int id)

@@ -1150,7 +1150,12 @@ vcg_update_p_k(const VcgArgs a)
 {
    constexpr int NT = 512;
    __shared__ double red[48];
-   if (a.s->all_done) { return; }
+   if (a.s->all_done)
+   {
+      // (several ranks, pack_rz: the exchange that follows must not carry the sums of an earlier iteration)
+      if (a.pack_rz && blockIdx.x == 0 && threadIdx.x < a.hp.n_nbr * kVC) { a.hp.sbuf[(size_t)a.hp.base[threadIdx.x / kVC] + threadIdx.x % kVC] = 0.0; }
+      return;
+   }
    const int it = a.iter;
    const bool first = (it == 1);
    const int tid = threadIdx.x;
@@ -1322,6 +1327,14 @@ vcg_update_p_k(const VcgArgs a)
             all = all && s->done[k];
          }
          if (!a.multi) { s->all_done = all; }
+         if (a.pack_rz)
+         {
+            // the local (r, z) straight into the send buffer of the exchange that sums it over the ranks
+            for (int k = 0; k < a.hp.n_nbr; k++)
+            {
+               for (int e = 0; e < kVC; e++) { a.hp.sbuf[(size_t)a.hp.base[k] + e] = s->rz[e]; }
+            }
+         }
       }
    }
 }
@@ -1365,7 +1378,7 @@ vcg_gather_k(const VcgArgs a)
 __device__ __forceinline__ void vcg_fold_den(const VcgArgs &a)
 {
    const int tid = threadIdx.x, it = a.iter;
-   if (tid < kVC && !a.s->done[tid]) { a.s->den[tid] = exact_den(a.limbs + (it & 1) * kLimbWords, tid, a.s->rz[tid]); }
+   if (tid < kVC && !a.s->done[tid]) { __hip_atomic_store(&a.s->den[tid], exact_den(a.limbs + (it & 1) * kLimbWords, tid, a.s->rz[tid]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
    if (tid < kLimbWords) { a.limbs[((it + 1) & 1) * kLimbWords + tid] = 0; }
    if (tid == 0) { a.s->first = 0; }
 }
@@ -1373,24 +1386,48 @@ __global__ void __launch_bounds__(256)
 vcg_fold_den_k(const VcgArgs a) { vcg_fold_den(a); }
 
 // E -> L sum at the listed (rank-shared) nodes only: what the halo exchange needs
+// pack_halo: every sum also goes to its places in the send buffer (one per neighbour that shares the node: the CSR the
+// combine kernel reads), and workgroup 0 puts the local (d, A d) behind every neighbour's block (nx_den) - the exchange
+// then starts without the pack kernel (halo_sum(..., packed)).  Components that are done send zeros.
 __global__ void __launch_bounds__(256)
 vcg_gather_list_k(const VcgArgs a)
 {
-   if (a.den_limbs == 2 && blockIdx.x == 0) { vcg_fold_den(a); }
+   if (blockIdx.x == 0 && (a.den_limbs == 2 || a.nx_den > 0))
+   {
+      if (a.den_limbs == 2) { vcg_fold_den(a); }
+      __syncthreads(); // (den of this workgroup's own fold: visible to its other threads)
+      const int t = threadIdx.x;
+      if (t < a.hp.n_nbr * a.nx_den)
+      {
+         const int k = t / a.nx_den, e = t - k * a.nx_den;
+         a.hp.sbuf[(size_t)a.hp.base[k] + (size_t)kVC * a.hp.ncnt[k] + e] = __hip_atomic_load(&a.s->den[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+   }
    const int u = blockIdx.x * blockDim.x + threadIdx.x;
    if (u >= a.n_shared) { return; }
    const int n = a.sh_node[u];
    for (int c = 0; c < kVC; c++)
    {
-      if (a.s->done[c]) { continue; }
-      const double *yc = a.YE + (size_t)c * a.ye_stride;
+      const bool live = a.s->done[c] == 0;
       double s = 0.0;
-      for (int j = 0; j < a.deg; j++)
+      if (live)
       {
-         const int p = a.ell[(size_t)j * a.N + n];
-         if (p >= 0) { s += yc[p]; }
+         const double *yc = a.YE + (size_t)c * a.ye_stride;
+         for (int j = 0; j < a.deg; j++)
+         {
+            const int p = a.ell[(size_t)j * a.N + n];
+            if (p >= 0) { s += yc[p]; }
+         }
+         a.yL[(size_t)c * a.N + n] = s;
       }
-      a.yL[(size_t)c * a.N + n] = s;
+      if (a.pack_halo)
+      {
+         for (int k = a.hp.sh_off[u]; k < a.hp.sh_off[u + 1]; k++)
+         {
+            const int j = a.hp.sh_src[k];
+            if (j >= 0) { a.hp.sbuf[(size_t)a.hp.pos[j] + (size_t)c * a.hp.cnt[j]] = s; }
+         }
+      }
    }
 }
 
@@ -1721,6 +1758,20 @@ int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
    a.trace = trace_dev;
    if (trace_dev) { (void)hipMemsetAsync(trace_dev, 0, kTraceRec * 4096 * sizeof(unsigned long long), c->stream); }
    if (multi) { comm_shared_nodes(c, &a.hmask, &a.sh_node, &a.n_shared); }
+   {
+      // several ranks, bounded-grid K2: the shared-node gather fills the send buffer of the halo exchange itself (and
+      // the local (d, A d) with it where the sums ride on the messages), the last workgroup of K2 the one of the
+      // (r, z) exchange - two launches less per iteration (A/B: LGH_HALO_FUSED_PACK=0)
+      const char *e0 = getenv("LGH_HALO_FUSED_PACK");
+      const bool want = !(e0 && e0[0] == '0');
+      const bool mixed0 = multi && c->t_deg <= 8;
+      if (want && mixed0 && k2p && a.n_shared > 0 && comm_pack_tables(c, &a.hp))
+      {
+         a.pack_halo = 1;
+         a.nx_den = halo_can_piggyback(c) ? kVC : 0;
+         a.pack_rz = halo_can_piggyback(c) ? 1 : 0;
+      }
+   }
    const int nb = ceil_div((long)N, 256);
 
    // init (vector kernels use reduction slot 0, the element kernel slot 1)
@@ -1838,12 +1889,12 @@ int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
                // rank is a neighbour of every other, by an all-reduce otherwise
                if (halo_can_piggyback(c))
                {
-                  rc = halo_sum(c, a.yL, kVC, ds->den, kVC);
+                  rc = halo_sum(c, a.yL, kVC, ds->den, kVC, a.pack_halo != 0);
                   if (rc) { return rc; }
                }
                else
                {
-                  rc = halo_sum(c, a.yL, kVC);
+                  rc = halo_sum(c, a.yL, kVC, nullptr, 0, a.pack_halo != 0);
                   if (rc) { return rc; }
                   rc = allreduce_dev(c, ds->den, kVC, 0);
                   if (rc) { return rc; }
@@ -1855,7 +1906,7 @@ int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
             else { hipLaunchKernelGGL((vcg_update_k<false, 0>), dim3(nb), dim3(256), 0, c->stream, a); }
             if (multi)
             {
-               rc = allreduce_dev(c, ds->rz, kVC, 0); // convergence is looked at by the next K1 (vcg_pending_update)
+               rc = allreduce_dev(c, ds->rz, kVC, 0, a.pack_rz != 0 && mixed && k2p); // convergence is looked at by the next K1 (vcg_pending_update)
                if (rc) { return rc; }
             }
          }

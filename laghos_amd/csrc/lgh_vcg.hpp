@@ -221,6 +221,12 @@ struct VcgArgs
    const int *nstart;         // node range of block w: [nstart[w], nstart[w+1]), balanced by cost
    int k2_skip;               // vcg_update_p_k: skip ELL slots no node of the wavefront uses (LGH_K2_SKIP=0: fetch all 8)
    int store_wait;        // slab-form K1 (A/B, LGH_SLAB_STORE_WAIT): every wavefront waits for the stores of a pass before it starts the next one
+   // several ranks: kernels that fill the send buffer themselves (one launch less per exchange)
+   HaloPackTables hp;
+   const int *sh_off;     // (= hp.sh_off: CSR of the unique shared nodes over the entries of the neighbour lists)
+   int pack_halo;         // vcg_gather_list_k also writes every shared-node sum to its places in the send buffer
+   int nx_den;            // ... and its workgroup 0 the local (d, A d) behind every neighbour's block (piggy-backed sums)
+   int pack_rz;           // the last workgroup of vcg_update_p_k puts the local (r, z) into the send buffer of the scalar exchange
 };
 
 // ---- exact, order-independent sums of doubles (the (d, A d) of the slab-form K1) -------------------------------
