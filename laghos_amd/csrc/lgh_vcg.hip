@@ -1730,6 +1730,7 @@ int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
    a.yL = c->vcg_vec + 2 * kVC * N;
    a.YE = aux->ye;
    a.ye_stride = (size_t)c->NE * c->ND + kYePad;
+   a.ye_wide = (a.ye_stride * 8 * kVC >= 0xffffffffull) ? 1 : 0;
    a.ellz = aux->ellz;
    a.essbits = aux->essbits;
    a.nstart = aux->nstart;

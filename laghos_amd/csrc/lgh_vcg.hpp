@@ -221,6 +221,7 @@ struct VcgArgs
    const int *nstart;         // node range of block w: [nstart[w], nstart[w+1]), balanced by cost
    int k2_skip;               // vcg_update_p_k: skip ELL slots no node of the wavefront uses (LGH_K2_SKIP=0: fetch all 8)
    int store_wait;        // slab-form K1 (A/B, LGH_SLAB_STORE_WAIT): every wavefront waits for the stores of a pass before it starts the next one
+   int ye_wide;           // slab-form K1: the three planes of Y_E exceed 4 GB - per-set 64-bit store base instead of 32-bit offsets from Y_E
    // several ranks: kernels that fill the send buffer themselves (one launch less per exchange)
    HaloPackTables hp;
    const int *sh_off;     // (= hp.sh_off: CSR of the unique shared nodes over the entries of the neighbour lists)

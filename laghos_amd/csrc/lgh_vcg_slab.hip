@@ -508,7 +508,10 @@ vcg_apply_slab346(const VcgArgs a, const int nset)
          __builtin_amdgcn_wave_barrier(); // (one wavefront: its LDS instructions execute in order; this only pins the compiler)
          const int s0c = max(s0, 0);
          const int nel = min(ES, a.NE - ES * s0c); // elements of this set (the last one may be short)
+         // one scalar base + 32-bit byte offsets while the three planes of Y_E fit 4 GB (every mesh up to 140^3 zones);
+         // beyond that (a.ye_wide) the set's offset goes into the base and only the per-lane part has to fit
          const unsigned set_off = 8u * (unsigned)ND * (unsigned)(ES * s0c);
+         char *const set_base = (char *)a.YE + (size_t)8 * ND * ES * (size_t)s0c;
          const v2d *rp = (const v2d *)(tl + (lane & ~7) * TP) + (lane & 7);
          // (all eight reads first, pinned: inside the predicated blocks each of them would be followed by a wait for
          //  the LDS - eight round trips in a row, a seventh of the pass)
@@ -525,7 +528,11 @@ vcg_apply_slab346(const VcgArgs a, const int nset)
 #pragma unroll
          for (int k = 0; k < 8; k++)
          {
-            if (((st_ok >> k) & 1u) && (int)((st_el >> (3 * k)) & 7u) < nel) { *(v2d *)((char *)a.YE + (st_off[k] + set_off)) = v2d{vlo[k], vhi[k]}; }
+            if (((st_ok >> k) & 1u) && (int)((st_el >> (3 * k)) & 7u) < nel) 
+            {
+               if (a.ye_wide) { *(v2d *)(set_base + st_off[k]) = v2d{vlo[k], vhi[k]}; }
+               else { *(v2d *)((char *)a.YE + (st_off[k] + set_off)) = v2d{vlo[k], vhi[k]}; }
+            }
          }
       }
       if (a.store_wait) { __builtin_amdgcn_s_waitcnt(0x0F70); }
@@ -694,7 +701,7 @@ vcg_apply_slab346(const VcgArgs a, const int nset)
 bool vcg_slab_available(lgh_ctx *c)
 {
    // (node vectors are addressed by one scalar base + a 32-bit byte offset)
-   return c->dim == 3 && c->kid == 0x346 && (size_t)c->N * 8 * kVC < 0xffffffffull && ((size_t)c->NE * c->ND + kYePad) * 8 * kVC < 0xffffffffull && slab_swaps_ok(c);
+   return c->dim == 3 && c->kid == 0x346 && (size_t)c->N * 8 * kVC < 0xffffffffull && ((size_t)c->NE * c->ND + kYePad) * 8 * (kVC - 1) + 65536 < 0xffffffffull && slab_swaps_ok(c); // (per-lane store offsets: the last component's plane + a set)
 }
 
 void launch_vcg_slab(lgh_ctx *c, const VcgArgs &a)
