@@ -170,20 +170,25 @@ __device__ __forceinline__ double qpoint_body(const QArgs &a, const int e, const
 // Jac0inv / rho0DetJ0w) are issued before the first barrier, so a workgroup pays
 // one global-memory latency, not five; the L2 (energy) interpolation shares the
 // barrier intervals of the H1 stages.
-template <int DIM, int D, int Q, int L, int NEB, int NFMAX, int MODE>
-__global__ void __launch_bounds__((DIM == 3 ? Q * Q * Q : Q * Q) * NEB)
+// PPT = 2 (3D update mode, all fields in one LDS pass): two quadrature points per thread, tz and tz + Q/2 - the
+// 1000-thread workgroups of Q5Q4 are capped at 128 registers per thread (16 wavefronts on one CU) and spill 41; with
+// 500 threads the cap is 256.  The second point's z stage and body run after the first one's, on the same registers.
+template <int DIM, int D, int Q, int L, int NEB, int NFMAX, int MODE, int PPT = 1>
+__global__ void __launch_bounds__((DIM == 3 ? Q * Q * Q : Q * Q) * NEB / PPT)
 qpoint_kernel(const QArgs a)
 {
    constexpr int ND = (DIM == 3) ? D * D * D : D * D;
    constexpr int NQ = (DIM == 3) ? Q * Q * Q : Q * Q;
    constexpr int NL = (DIM == 3) ? L * L * L : L * L;
-   constexpr int NTE = NQ; // threads per element
-   constexpr bool HOIST = (NQ * NEB <= 256); // per-thread-constant table rows kept in registers (below)
+   constexpr int NTE = NQ / PPT; // threads per element
+   static_assert(PPT == 1 || (PPT == 2 && DIM == 3 && MODE == QMODE_UPDATE && Q % 2 == 0), "two points per thread: 3D update only");
+   constexpr bool HOIST = (NQ * NEB <= 256) && PPT == 1; // per-thread-constant table rows kept in registers (below)
    constexpr bool NEED_X = (MODE == QMODE_UPDATE || MODE == QMODE_SETUP);
    constexpr bool NEED_V = (MODE == QMODE_UPDATE || MODE == QMODE_KE);
    constexpr bool NEED_E = (MODE != QMODE_KE);
    constexpr int NFIELD = (NEED_X ? DIM : 0) + (NEED_V ? DIM : 0);
    constexpr int NF = (NFIELD == 0) ? 1 : (NFMAX < NFIELD ? NFMAX : NFIELD);
+   static_assert(PPT == 1 || NF == NFIELD, "two points per thread: all fields in one LDS pass");
    // LDS per element
    constexpr int SU = NF * ND;
    constexpr int SXs = (DIM == 3) ? 2 * NF * D * D * Q : 2 * NF * D * Q; // B,G applied in x
@@ -245,11 +250,19 @@ qpoint_kernel(const QArgs a)
    }
    double J0i[DIM * DIM];
    double rdw = 0.0;
+   double J0i_b[PPT > 1 ? DIM * DIM : 1]; // (PPT = 2: the point lt + NTE)
+   double rdw_b = 0.0;
    if (MODE == QMODE_UPDATE)
    {
 #pragma unroll
       for (int k = 0; k < DIM * DIM; k++) { J0i[k] = a.Jac0inv_soa[eq + (size_t)a.NE * NQ * k]; } // plane-major copy: coalesced
       rdw = a.rho0DetJ0w_in[eq];
+      if constexpr (PPT > 1)
+      {
+#pragma unroll
+         for (int k = 0; k < DIM * DIM; k++) { J0i_b[k] = a.Jac0inv_soa[eq + NTE + (size_t)a.NE * NQ * k]; }
+         rdw_b = a.rho0DetJ0w_in[eq + NTE];
+      }
    }
    else if (MODE == QMODE_IE || MODE == QMODE_KE) { rdw = a.rho0DetJ0w_in[eq]; }
 
@@ -258,6 +271,37 @@ qpoint_kernel(const QArgs a)
    (void)grad;
    (void)val;
    double e_val = 0.0;
+   // 3D z stage of the point (tx, ty, tzp): values and gradients of the fields of the pass, and e
+   auto zstage3 = [&](const int f0, const bool first_pass, const int tzp, double *grad_, double *val_, double &ev_) __attribute__((always_inline)) {
+#pragma unroll
+      for (int fl = 0; fl < NF; fl++)
+      {
+         if (NFIELD > 0 && f0 + fl < NFIELD)
+         {
+            double vv = 0.0, d0 = 0.0, d1 = 0.0, d2 = 0.0;
+#pragma unroll
+            for (int dz = 0; dz < D; dz++)
+            {
+               const int j = tx + Q * (ty + Q * (dz + D * fl));
+               const double b = sB[tzp + Q * dz], g = sG[tzp + Q * dz];
+               const double bb = sY[j];
+               vv += b * bb;
+               d0 += b * sY[j + NF * D * Q * Q];
+               d1 += b * sY[j + 2 * NF * D * Q * Q];
+               d2 += g * bb;
+            }
+            val_[f0 + fl] = vv;
+            grad_[(f0 + fl) * DIM + 0] = d0;
+            grad_[(f0 + fl) * DIM + 1] = d1;
+            grad_[(f0 + fl) * DIM + (DIM - 1)] = d2;
+         }
+      }
+      if (NEED_E && first_pass)
+      {
+#pragma unroll
+         for (int lz = 0; lz < L; lz++) { ev_ += sBl[tzp + Q * lz] * sE2[tx + Q * (ty + Q * lz)]; }
+      }
+   };
 
    for (int f0 = 0; f0 < (NFIELD > 0 ? NFIELD : 1); f0 += NF)
    {
@@ -363,35 +407,8 @@ qpoint_kernel(const QArgs a)
             }
          }
          __syncthreads();
-         // z stage: this thread's point
-#pragma unroll
-         for (int fl = 0; fl < NF; fl++)
-         {
-            if (NFIELD > 0 && f0 + fl < NFIELD)
-            {
-               double vv = 0.0, d0 = 0.0, d1 = 0.0, d2 = 0.0;
-#pragma unroll
-               for (int dz = 0; dz < D; dz++)
-               {
-                  const int j = tx + Q * (ty + Q * (dz + D * fl));
-                  const double b = sB[tz + Q * dz], g = sG[tz + Q * dz];
-                  const double bb = sY[j];
-                  vv += b * bb;
-                  d0 += b * sY[j + NF * D * Q * Q];
-                  d1 += b * sY[j + 2 * NF * D * Q * Q];
-                  d2 += g * bb;
-               }
-               val[f0 + fl] = vv;
-               grad[(f0 + fl) * DIM + 0] = d0;
-               grad[(f0 + fl) * DIM + 1] = d1;
-               grad[(f0 + fl) * DIM + (DIM - 1)] = d2;
-            }
-         }
-         if (NEED_E && first_pass)
-         {
-#pragma unroll
-            for (int lz = 0; lz < L; lz++) { e_val += sBl[tz + Q * lz] * sE2[tx + Q * (ty + Q * lz)]; }
-         }
+         // z stage: this thread's point (PPT = 2: both points after the loop, one after the other - update section)
+         if constexpr (PPT == 1) { zstage3(f0, first_pass, tz, grad, val, e_val); }
       }
       else
       {
@@ -468,9 +485,39 @@ qpoint_kernel(const QArgs a)
             dV[c + DIM * d] = grad[(DIM + c) * DIM + d];
          }
       double cand = INFINITY, ftv = 0.0, sjw[DIM * DIM];
+      double ftv_b = 0.0, sjw_b[PPT > 1 ? DIM * DIM : 1]; // (PPT = 2: the point lt + NTE)
 #pragma unroll
       for (int k = 0; k < DIM * DIM; k++) { sjw[k] = 0.0; }
-      if (active) { cand = qpoint_body<DIM>(a, e, eq, weight, J, dV, e_val, plane, J0i, rdw, ftv, sjw); }
+      if constexpr (PPT == 1)
+      {
+         if (active) { cand = qpoint_body<DIM>(a, e, eq, weight, J, dV, e_val, plane, J0i, rdw, ftv, sjw); }
+      }
+      else
+      {
+#pragma unroll
+         for (int k = 0; k < DIM * DIM; k++) { sjw_b[k] = 0.0; }
+#pragma unroll
+         for (int p = 0; p < PPT; p++)
+         {
+            double g2[NFIELD * DIM], v2[NFIELD], ev = 0.0;
+            zstage3(0, true, tz + p * (Q / PPT), g2, v2, ev);
+#pragma unroll
+            for (int c = 0; c < DIM; c++)
+#pragma unroll
+               for (int d = 0; d < DIM; d++)
+               {
+                  J[c + DIM * d] = g2[c * DIM + d];
+                  dV[c + DIM * d] = g2[(DIM + c) * DIM + d];
+               }
+            if (active)
+            {
+               const double c_p = (p == 0) ? qpoint_body<DIM>(a, e, eq, weight, J, dV, ev, plane, J0i, rdw, ftv, sjw)
+                                           : qpoint_body<DIM>(a, e, eq + NTE, a.W[lt + NTE], J, dV, ev, plane, J0i_b, rdw_b, ftv_b, sjw_b);
+               cand = fmin(cand, c_p);
+            }
+            __builtin_amdgcn_sched_barrier(0); // (one point after the other: interleaved, the two bodies need twice the registers)
+         }
+      }
       // ---- the two force products of this state, from the values still in registers -------------------
       // F^T v (ForcePAOperator::MultTranspose, laghos_assembly.cpp:859-921: the point integrand above tested
       // with the L2 basis) is SolveEnergy's right-hand side for the velocity block of THIS state, and F.1
@@ -506,11 +553,19 @@ qpoint_kernel(const QArgs a)
                   for (int cc = 0; cc < CP; cc++)
                   {
 #pragma unroll
-                     for (int gd = 0; gd < 3; gd++) { sF[lt + NQ * (gd + 3 * cc)] = sjw[gd + 3 * (c0 + cc)]; }
+                     for (int gd = 0; gd < 3; gd++)
+                     {
+                        sF[lt + NQ * (gd + 3 * cc)] = sjw[gd + 3 * (c0 + cc)];
+                        if constexpr (PPT > 1) { sF[lt + NTE + NQ * (gd + 3 * cc)] = sjw_b[gd + 3 * (c0 + cc)]; }
+                     }
                   }
                }
             }
-            if (t_now) { sS[lt] = active ? ftv : 0.0; }
+            if (t_now)
+            {
+               sS[lt] = active ? ftv : 0.0;
+               if constexpr (PPT > 1) { sS[lt + NTE] = active ? ftv_b : 0.0; }
+            }
             __syncthreads();
             if constexpr (DIM == 3)
             {
@@ -776,7 +831,18 @@ template <int MODE> static int launch_q(lgh_ctx *c, const QArgs &a)
       // gradients do not have to survive across passes): 234 -> 158 VGPRs at Q4Q3, 70 -> 41 spilled registers under
       // the 128-register cap of the 1000-thread workgroup at Q5Q4, where the update takes 10.4 instead of 17 ms
       case 0x358: LGH_Q3(5, 8, 4, 6);
-      case 0x36A: LGH_Q3(6, 10, 5, 6); // extension: not in the reference table
+      case 0x36A: // extension: not in the reference table
+         if constexpr (MODE == QMODE_UPDATE)
+         {
+            // two points per thread: 500-thread workgroups under a cap of 256 registers instead of 1000 under 128 (41 spilled)
+            static const char *penv = getenv("LGH_Q_PPT"); // A/B: 1 = one point per thread
+            if (!(penv && penv[0] == '1'))
+            {
+               hipLaunchKernelGGL((qpoint_kernel<3, 6, 10, 5, 1, 6, MODE, 2>), dim3(c->NE), dim3(500), 0, c->stream, a);
+               break;
+            }
+         }
+         LGH_Q3(6, 10, 5, 6);
       default: return unknown_kernel(c->kid);
    }
 #undef LGH_Q3

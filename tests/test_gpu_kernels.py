@@ -762,6 +762,7 @@ KERNEL_SWITCHES = [
     ((4, 3), {"LGH_MASS_SEP": "0"}, "tol"),
     ((5, 4), {"LGH_MASS_SEP": "0"}, "tol"),
     ((5, 4), {"LGH_MASS_RANK1": "0"}, "tol"),
+    ((5, 4), {"LGH_Q_PPT": "1"}, "tol"),
     ((4, 3), {"LGH_L2_PLANE": "0"}, "tol"),
     ((4, 3), {"LGH_K2P": "0"}, "tol"),
 ]
