@@ -1730,7 +1730,10 @@ int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
    a.yL = c->vcg_vec + 2 * kVC * N;
    a.YE = aux->ye;
    a.ye_stride = (size_t)c->NE * c->ND + kYePad;
-   a.ye_wide = (a.ye_stride * 8 * kVC >= 0xffffffffull) ? 1 : 0;
+   {
+      const char *w0 = getenv("LGH_SLAB_YE_WIDE"); // test hook: 1 = the per-set 64-bit store base of the slab K1 on a mesh that does not need it
+      a.ye_wide = (a.ye_stride * 8 * kVC >= 0xffffffffull || (w0 && w0[0] == '1')) ? 1 : 0;
+   }
    a.ellz = aux->ellz;
    a.essbits = aux->essbits;
    a.nstart = aux->nstart;

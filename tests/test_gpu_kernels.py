@@ -610,6 +610,7 @@ SLAB_SWITCHES = [
     {"LGH_SLAB_WPS": "1", "LGH_SLAB_WIDE": "0", "LGH_SLAB_DYN": "0"},
     {"LGH_SLAB_DEFER": "0"},
     {"LGH_SLAB_STORE_WAIT": "1"},
+    {"LGH_SLAB_YE_WIDE": "1"},
     {"LGH_SLAB_WPS": "2", "LGH_SLAB_WIDE": "0"},
 ]
 
