@@ -120,6 +120,7 @@ def cpu_baseline(threads):
     h.reset_time_step_estimate()
     dt = h.get_time_step_estimate(S)
     steps, wall, t = 0, 0.0, 0.0
+    ref = None
     while wall < 12.0 and steps < 40:
         t0 = time.time()
         h.reset_time_step_estimate()
@@ -127,21 +128,57 @@ def cpu_baseline(threads):
         dt_est = h.get_time_step_estimate(S)
         wall += time.time() - t0
         steps += 1
+        if dt_est < dt and ref is None:
+            ref = {"error": "the oracle's step %d would be repeated with a smaller dt: no parity sample" % steps}
         if dt_est > 1.25 * dt:
             dt *= 1.02
+        if steps == PARITY_STEPS and ref is None:
+            # the checker's state after PARITY_STEPS whole RK4 steps of the bench problem: main() holds the HIP path's against it
+            ref = {"steps": steps, "t": t, "dt": dt, "e_norm": h.e_norm(S), "S": S.copy(), "H1V": prob.H1V}
     dofs = prob.dim * prob.N + prob.L2V
     tm = h.timers()
     h.close()
     return dict(value=1e-6 * dofs * 4 * steps / wall, unit="Mdofs*steps/s", cores=threads, cpu_model=cpu_model(), kind="port",
                 sample="%d RK4 steps from t=0 of the same 3D Sedov Q3Q2 32^3 problem (oracle/ C++ kernels, "
                        "OpenMP %d threads), %.1f s" % (steps, threads, wall),
-                seconds=wall, rk4_steps=steps, h1_cg_iters=tm["H1iter"])
+                seconds=wall, rk4_steps=steps, h1_cg_iters=tm["H1iter"]), ref
+
+
+PARITY_STEPS = 3
+
+
+def parity_block(host_lib, args, dev, ref):
+    """`parity` of the bench line: PARITY_STEPS RK4 steps of the bench's own problem from t = 0 through the HIP path
+    (a fresh simulation, outside every timed region) against the oracle's state after the same steps (the ones the
+    cpu_baseline leg ran anyway).  tests/test_gpu_pipeline.py::test_config2_full_size_vs_oracle asserts the same
+    comparison; here it is printed with the number it belongs to."""
+    import numpy as np
+    if ref is None or "error" in ref:
+        return {"error": (ref or {}).get("error", "no oracle sample")}
+    sim = host_lib.Sim(args + ["-dev", dev, "-q"])
+    sim.enable_timers(False)
+    for _ in range(ref["steps"]):
+        sim.step()
+    sim.sync()
+    out = {"checker": "oracle/ (CPU restatement of the reference -pa path, pinned to the reference's --checks table and README runs)",
+           "rk4_steps": ref["steps"], "rk4_steps_executed_hip": sim.rk_steps, "t_hip": sim.t, "t_oracle": ref["t"],
+           "dt_hip": sim.dt, "dt_oracle": ref["dt"], "e_norm_hip": sim.e_norm(), "e_norm_oracle": ref["e_norm"]}
+    S, So, H1V = sim.state(), ref["S"], ref["H1V"]
+    sim.close()
+    out["e_norm_rel_diff"] = abs(out["e_norm_hip"] - ref["e_norm"]) / abs(ref["e_norm"])
+    out["dt_rel_diff"] = abs(out["dt_hip"] - ref["dt"]) / ref["dt"]
+    for name, sl in (("x", slice(0, H1V)), ("v", slice(H1V, 2 * H1V)), ("e", slice(2 * H1V, None))):
+        out["state_%s_max_rel_diff" % name] = float(np.abs(S[sl] - So[sl]).max() / np.abs(So[sl]).max())
+    out["tolerances"] = {"e_norm": 1e-9, "state": 1e-8, "dt": 1e-12}
+    out["pass"] = bool(out["rk4_steps_executed_hip"] == ref["steps"] and out["e_norm_rel_diff"] <= 1e-9 and out["dt_rel_diff"] <= 1e-12
+                       and all(out["state_%s_max_rel_diff" % n] <= 1e-8 for n in "xve"))
+    return out
 
 
 KERNEL_NAMES = {0: "vcg_apply_plane (H1 CG K1, 3 velocity components per launch)",
-                1: "vcg_update_k (H1 CG K2, 3 velocity components per launch)",
-                2: "qpoint_kernel (fused QUpdate)", 3: "force_mult_3d", 4: "force_mult_t_3d",
-                5: "mass_apply_3d (L2 CG K1)",
+                1: "vcg_update_p_k (H1 CG K2, 3 velocity components per launch)",
+                2: "qpoint_kernel (fused QUpdate + both force products)", 3: "force_mult_3d", 4: "force_mult_t_3d",
+                5: "mass_apply_l2 (L2 CG K1)",
                 6: "halo_sum (pack + grouped ncclSend/Recv + combine)", 7: "ncclAllReduce of device scalars"}
 K1_FORMS = {0: "vcg_apply_3d", 2: "vcg_apply_plane", 3: "vcg_apply_mfma346", 4: "vcg_apply_slab346"}
 
@@ -152,11 +189,13 @@ def kernel_names(L, ctx):
     L.lgh_k1_form(ctx, ctypes.byref(f))
     names = dict(KERNEL_NAMES)
     names[0] = K1_FORMS.get(f.value, "vcg_apply") + " (H1 CG K1, 3 velocity components per launch)"
+    if os.environ.get("LGH_K2P") == "0":
+        names[1] = names[1].replace("vcg_update_p_k", "vcg_update_k")
     return names
 
 
 def algorithmic_bytes(sz):
-    """Algorithmic bytes per launch, fp64 (SURVEY §8d / DESIGN.md "Roofline accounting")."""
+    """SURVEY §8(d)'s algorithmic bytes per launch, fp64: what the REFERENCE's form of each kernel has to move."""
     dim, D, Q, Ld = sz["dim"], sz["D1D"], sz["Q1D"], sz["L1D"]
     NQ, ND, NL, NE, N = sz["NQ"], D ** dim, Ld ** dim, sz["NE"], sz["N"]
     return {
@@ -170,14 +209,41 @@ def algorithmic_bytes(sz):
     }
 
 
+def moved_bytes(sz, L, ctx, k1_name):
+    """Bytes per launch the kernel form that RAN has to move (its operand footprint: every array it reads or writes
+    counted once) - what `GBs`, `roofline.achieved` and the aggregates are priced with, so that no figure can exceed
+    what the memory system delivered.  Differs from SURVEY §8(d)'s figure (kept beside it as `sec8d_*`) where this
+    implementation departs from the reference's kernel:
+      K1 (lockstep mass apply): gathers r, d_old (dim components) and 1/diag from node vectors instead of reading one
+         E-vector, and with compact mass data (lgh_mass_data_form) reads one double per element instead of NQ;
+      L2 mass apply: compact data likewise (plane form);
+    everything else moves what §8(d) says."""
+    dim, D, Ld = sz["dim"], sz["D1D"], sz["L1D"]
+    NQ, ND, NL, NE, N = sz["NQ"], D ** dim, Ld ** dim, sz["NE"], sz["N"]
+    b = dict(algorithmic_bytes(sz))
+    form = ctypes.c_int(-1)
+    L.lgh_mass_data_form(ctx, ctypes.byref(form))
+    h1s, l2s = ctypes.c_int(0), ctypes.c_int(0)
+    L.lgh_table_symmetry(ctx, ctypes.byref(h1s), ctypes.byref(l2s))
+    k1_compact = form.value == 1 and k1_name.split(" ")[0] in ("vcg_apply_slab346", "vcg_apply_plane", "vcg_apply_plane_ho")
+    l2_compact = form.value == 1 and dim == 3 and l2s.value == 1 and os.environ.get("LGH_L2_PLANE", "1") != "0" and D >= 4
+    b[0] = 8 * (N * (2 * dim + 1) + NE * dim * ND) + (8 * NE if k1_compact else 8 * NE * NQ)
+    b[5] = NE * 8 * ((1 if l2_compact else NQ) + 2 * NL)
+    notes = {0: "r, d_old (dim components) and 1/diag gathered from node vectors, E-vector out; mass data: %s"
+                % ("compact, one factor per element" if k1_compact else "stored table, NQ per element"),
+             5: "mass data: %s" % ("compact, one factor per element" if l2_compact else "stored table")}
+    return b, notes, k1_compact
+
+
 def measure_kernels(sim, sz):
     """HIP-event timing (on the library's stream) of every launch of each hot kernel during one RK step per
-    kernel, after the timed region.  Returns (per-kernel dict, aggregates)."""
+    kernel, after the timed region.  Returns (per-kernel dict, aggregates, raw)."""
     from laghos_amd import _lib
     L = _lib.load()
     ctx = sim.L.laghos_sim_context(sim.h)
-    bts = algorithmic_bytes(sz)
     KERNEL_NAMES = kernel_names(L, ctx)
+    sec8d = algorithmic_bytes(sz)
+    bts, notes, k1_compact = moved_bytes(sz, L, ctx, KERNEL_NAMES[0])
     kern, raw = {}, {}
     for kid in (0, 1, 2, 3, 4, 5):
         # In production the two force products come out of the fused QUpdate; the ForcePAOperator kernels are
@@ -191,42 +257,31 @@ def measure_kernels(sim, sz):
         _lib.check(L.lgh_set_fused_forces(ctx, 1))
         if n.value:
             raw[kid] = (n.value, mean.value)
-            kern[KERNEL_NAMES[kid]] = {"launches": n.value, "mean_us": 1e6 * mean.value, "algorithmic_bytes": bts[kid],
-                                       "GBs": 1e-9 * bts[kid] / mean.value}
+            kern[KERNEL_NAMES[kid]] = {"launches": n.value, "mean_us": 1e6 * mean.value, "bytes_per_launch": bts[kid],
+                                       "GBs": 1e-9 * bts[kid] / mean.value, "frac": 1e-9 * bts[kid] / mean.value / HBM_PEAK_GBS,
+                                       "sec8d_bytes_per_launch": sec8d[kid], "sec8d_GBs": 1e-9 * sec8d[kid] / mean.value,
+                                       "us_per_rk_step": 1e6 * mean.value * n.value}
+            if kid in notes:
+                kern[KERNEL_NAMES[kid]]["moves"] = notes[kid]
 
     def aggregate(ids):
         if any(k not in raw for k in ids):
             return None
-        b = sum(raw[k][0] * bts[k] for k in ids)
         t = sum(raw[k][0] * raw[k][1] for k in ids)
+        b = sum(raw[k][0] * bts[k] for k in ids)
+        b8 = sum(raw[k][0] * sec8d[k] for k in ids)
         return {"kernels": [KERNEL_NAMES[k].split(" ")[0] for k in ids], "launches_per_rk_step": {KERNEL_NAMES[k].split(" ")[0]: raw[k][0] for k in ids},
-                "algorithmic_bytes_per_rk_step": b, "seconds_per_rk_step": t, "achieved": 1e-9 * b / t,
-                "frac": 1e-9 * b / t / HBM_PEAK_GBS, "frac_of_achievable": 1e-9 * b / t / HBM_ACHIEVABLE_GBS}
+                "bytes_per_rk_step": b, "seconds_per_rk_step": t, "achieved": 1e-9 * b / t,
+                "frac": 1e-9 * b / t / HBM_PEAK_GBS, "frac_of_achievable": 1e-9 * b / t / HBM_ACHIEVABLE_GBS,
+                # the same with SURVEY 8(d)'s bytes (the reference's kernels: quadrature table and E-vector in for every mass apply)
+                "sec8d_bytes_per_rk_step": b8, "sec8d_achieved": 1e-9 * b8 / t, "sec8d_frac": 1e-9 * b8 / t / HBM_PEAK_GBS}
     # north_star: "Force+Mass operator apply" = ForceMult + ForceMultTranspose + the mass applies of the H1 CG (K1);
     # the node kernel of the CG (K2) listed with it in a second figure
     agg = {"force_mass_aggregate": aggregate((3, 4, 0)), "force_mass_cg_aggregate": aggregate((3, 4, 0, 1)),
-           "force_products_in_production": "formed inside qpoint_kernel (fused QUpdate): no force kernel runs in the timed steps"}
-    if 0 in raw:
-        # What `achieved` counts and what the kernel that ran really has to move (DESIGN.md "Roofline accounting").
-        # `achieved` is SURVEY 8(d)'s figure for the mass apply, 8 (NQ + 2 dim D1D^3) bytes per element: the quadrature
-        # data once, one E-vector in, one out.  The lockstep K1 departs from it on both sides: with compact mass data
-        # (lgh_mass_data_form: D[q, e] = W[q] s_e) it reads 8 bytes of quadrature data per element instead of 8 NQ,
-        # and it forms the search direction itself, d = z + beta d_old, z = r / diag - it gathers r, d_old (dim
-        # components) and 1 / diag where 8(d) has a single input vector.  `compulsory` is the unique footprint of those
-        # operands (every node vector once, the element output once): the least the launch can take from memory.
-        dim, D, N, NE, NQ = sz["dim"], sz["D1D"], sz["N"], sz["NE"], sz["NQ"]
-        form = ctypes.c_int(-1)
-        L.lgh_mass_data_form(ctx, ctypes.byref(form))
-        compact = form.value == 1 and KERNEL_NAMES[0].split(" ")[0] in ("vcg_apply_slab346", "vcg_apply_plane")
-        comp = 8 * (N * (2 * dim + 1) + NE * dim * D ** dim) + (8 * NE if compact else 8 * NE * NQ)
-        t = raw[0][1]
-        agg["k1_accounting"] = {
-            "achieved_counts": "SURVEY 8(d): 8 (NQ + 2 dim D1D^3) bytes per element and launch",
-            "sec8d_bytes_per_launch": bts[0],
-            "mass_data": "compact: one factor per element (8 NE bytes instead of 8 NQ NE)" if compact else "stored table",
-            "inputs": "r, d_old (dim components each) and 1/diag gathered; d = r/diag + beta d_old formed in the kernel",
-            "compulsory_bytes_per_launch": comp, "compulsory_GBs": 1e-9 * comp / t, "compulsory_frac": 1e-9 * comp / t / HBM_PEAK_GBS}
-    return kern, agg
+           "force_products_in_production": "formed inside qpoint_kernel (fused QUpdate): no force kernel runs in the timed steps",
+           "accounting": "achieved / frac / GBs: bytes the kernel form that ran has to move (operand footprint, moved_bytes() in bench.py); "
+                         "sec8d_*: SURVEY 8(d)'s bytes of the reference's kernels, for comparison"}
+    return kern, agg, raw, KERNEL_NAMES
 
 
 def measure_comm(sim, world):
@@ -250,39 +305,92 @@ def measure_comm(sim, world):
     return out
 
 
-def k1_sources_sha():
+def kernel_sources_sha():
+    """sha-256 over the HIP sources of the library: counter figures are quoted only for the build they were taken on"""
+    import glob
     import hashlib
     h = hashlib.sha256()
-    for f in ("lgh_vcg.hpp", "lgh_vcg.hip", "lgh_vcg_slab.hip"):
-        h.update(open(os.path.join(ROOT, "laghos_amd", "csrc", f), "rb").read())
+    for f in sorted(glob.glob(os.path.join(ROOT, "laghos_amd", "csrc", "*.h*"))):
+        h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(workload="c2"):
-    """Memory-side bytes per K1 launch from the committed rocprofv3 PMC passes (profiles/r3_pmc_traffic.json, written by
-    tools/update_pmc_traffic.py) - only if they were taken with the K1 sources this build has; otherwise null."""
-    pj = os.path.join(ROOT, "profiles", "r3_pmc_traffic.json")
+PMC_FILE = "r4_pmc_traffic.json"
+
+
+def pmc_traffic(workload, kernel):
+    """Memory-side bytes per launch of `kernel` (substring of its name) from the committed rocprofv3 PMC passes
+    (profiles/r4_pmc_traffic.json, written by tools/update_pmc_traffic.py) - only if they were taken with the kernel
+    sources this build has; otherwise null."""
+    pj = os.path.join(ROOT, "profiles", PMC_FILE)
     try:
         d = json.load(open(pj))
-        sha = k1_sources_sha()
-        if d.get("k1_sources_sha16") != sha:
-            return None, "profiles/r3_pmc_traffic.json is from another build of the K1 sources (%s != %s): not reported" % (d.get("k1_sources_sha16"), sha)
-        w = d["workloads"][workload]
-        return w["k1_bytes_per_launch"], ("profiles/r3_pmc_traffic.json[%s] (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, 2*FETCH + WRITE per "
-                                          "launch of %s, K1 sources @%s)" % (workload, w["k1_kernel"], sha))
+        sha = kernel_sources_sha()
+        if d.get("kernel_sources_sha16") != sha:
+            return None, "profiles/%s is from another build of the kernel sources (%s != %s): not reported" % (PMC_FILE, d.get("kernel_sources_sha16"), sha)
+        ks = d["workloads"][workload]["kernels"]
+        hits = [k for k in ks if kernel in k]
+        if not hits:
+            return None, "no launch of %s in profiles/%s[%s]" % (kernel, PMC_FILE, workload)
+        k = max(hits, key=lambda k: ks[k]["launches"])
+        return ks[k]["bytes_per_launch"], ("profiles/%s[%s] (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, 2*FETCH + WRITE per "
+                                           "launch of %s, kernel sources @%s)" % (PMC_FILE, workload, k, sha))
     except Exception as e:
         return None, "unavailable: %r" % (e,)
 
 
-def run_leg(host_lib, args, steps, warmup, dev, force_multi=False):
+def roofline_block(kern, agg, raw, names, workload_key):
+    """`roofline` of the bench line: the kernel with the largest share of the RK step (by sampled launches x mean
+    duration), priced with the bytes its form moves; the other CG kernel and the QUpdate beside it."""
+    ids = [k for k in (0, 1, 2, 5) if k in raw]
+    if not ids:
+        return None
+    dom = max(ids, key=lambda k: raw[k][0] * raw[k][1])
+    short = {k: names[k].split(" ")[0] for k in ids}
+    d = kern[names[dom]]
+    traffic, src = pmc_traffic(workload_key, short[dom].split("<")[0]) if workload_key else (None, "not collected for this workload")
+    r = {"bound": "hbm", "kernel": names[dom], "achieved": d["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": d["GBs"] / HBM_PEAK_GBS,
+         "achievable": HBM_ACHIEVABLE_GBS, "frac_of_achievable": d["GBs"] / HBM_ACHIEVABLE_GBS,
+         "traffic": traffic, "traffic_source": src, "mean_launch_us": d["mean_us"], "launches_sampled": d["launches"],
+         "bytes_per_launch": d["bytes_per_launch"], "sec8d_bytes_per_launch": d["sec8d_bytes_per_launch"],
+         "sec8d_achieved": d["sec8d_GBs"], "sec8d_frac": d["sec8d_GBs"] / HBM_PEAK_GBS,
+         "dominant_by": "largest launches x mean duration of one sampled RK step",
+         "time_share_us_per_rk_step": {short[k]: 1e6 * raw[k][0] * raw[k][1] for k in ids}}
+    beside = {}
+    for k in ids:
+        if k == dom:
+            continue
+        e = kern[names[k]]
+        t, tsrc = pmc_traffic(workload_key, short[k].split("<")[0]) if workload_key else (None, None)
+        beside[short[k]] = {"achieved": e["GBs"], "frac": e["frac"], "mean_launch_us": e["mean_us"], "launches_sampled": e["launches"],
+                            "bytes_per_launch": e["bytes_per_launch"], "sec8d_bytes_per_launch": e["sec8d_bytes_per_launch"],
+                            "sec8d_frac": e["sec8d_GBs"] / HBM_PEAK_GBS, "traffic": t}
+    r["other_kernels"] = beside
+    r.update(agg)
+    return r
+
+
+def run_leg(host_lib, args, steps, warmup, dev, force_multi=False, env=None, pmc_key=None):
     """One extra single-GPU workload (a BASELINE.json config other than the one `value` is quoted on)."""
     import torch
+    env = dict(env or {})
     if force_multi:
-        os.environ["LGH_FORCE_MULTI"] = "1"  # read by the host layer when it builds the operator
+        env["LGH_FORCE_MULTI"] = "1"  # read by the host layer when it builds the operator
+    saved = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
     try:
-        sim = host_lib.Sim(args + ["-dev", dev, "-q"])
+        return _run_leg(host_lib, args, steps, warmup, dev, force_multi, pmc_key)
     finally:
-        os.environ.pop("LGH_FORCE_MULTI", None)
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def _run_leg(host_lib, args, steps, warmup, dev, force_multi, pmc_key):
+    import torch
+    sim = host_lib.Sim(args + ["-dev", dev, "-q"])
     sim.enable_timers(False)
     sz = sim.sizes()
     for _ in range(warmup):
@@ -298,12 +406,16 @@ def run_leg(host_lib, args, steps, warmup, dev, force_multi=False):
     wall = time.perf_counter() - t0
     rk = sim.rk_steps - r0
     dofs = sz["H1GTV"] + sz["L2GTV"]
-    kern, agg = measure_kernels(sim, sz)
+    kern, agg, raw, names = measure_kernels(sim, sz)
     out = {"value": 1e-6 * dofs * 4 * rk / wall, "unit": "Mdofs*steps/s", "ms_per_step": 1e3 * wall / steps, "steps": steps,
            "elements": sz["global_NE"], "h1_dofs": sz["H1GTV"], "l2_dofs": sz["L2GTV"], "e_norm": sim.e_norm(), "t": sim.t,
-           "kernels": {k: {"mean_us": v["mean_us"], "GBs": v["GBs"], "launches": v["launches"]} for k, v in kern.items()}}
-    out.update({k: ({"achieved": v["achieved"], "frac": v["frac"], "frac_of_achievable": v["frac_of_achievable"]} if (isinstance(v, dict) and "achieved" in v) else v)
-                for k, v in agg.items()})
+           "kernels": {k: {kk: v[kk] for kk in ("mean_us", "GBs", "frac", "sec8d_GBs", "launches", "bytes_per_launch")} for k, v in kern.items()}}
+    out.update({k: ({kk: v[kk] for kk in ("achieved", "frac", "frac_of_achievable", "sec8d_achieved", "sec8d_frac")} if (isinstance(v, dict) and "achieved" in v) else v)
+                for k, v in agg.items() if k != "accounting"})
+    rl = roofline_block(kern, agg, raw, names, pmc_key)
+    if rl:
+        out["roofline"] = {k: rl[k] for k in ("kernel", "achieved", "frac", "traffic", "traffic_source", "mean_launch_us", "bytes_per_launch",
+                                               "sec8d_frac", "time_share_us_per_rk_step")}
     if force_multi:
         out["comm"] = measure_comm(sim, 1)
     sim.close()
@@ -334,6 +446,10 @@ LEGS = {
                workload="3D triple point -p 3 -m box01_hex -rs 4 -ok 5 -ot 4 -pa (65 536 zones, Q5/Q4; BASELINE config 5 on one GPU)"),
     "c2dev": dict(args=WORKLOADS["c2"][0], order=(3, 2), steps=10, warmup=300,
                   workload=WORKLOADS["c2"][1] + ", after 300 time steps (developed flow)"),
+    # configs[1] with the STORED mass table (LGH_MASS_RANK1=0): what a mesh whose initial zones are not affine, or a
+    # density that varies inside a zone, takes - the reference's data makes no such assumption (laghos_assembly.cpp:92-95)
+    "c2stored": dict(args=WORKLOADS["c2"][0], order=(3, 2), steps=10, warmup=3, env={"LGH_MASS_RANK1": "0"},
+                     workload=WORKLOADS["c2"][1] + ", stored mass quadrature table (general-mesh path, LGH_MASS_RANK1=0)"),
     "c2multi": dict(args=WORKLOADS["c2"][0], order=(3, 2), steps=10, warmup=3, force_multi=True,
                     workload=WORKLOADS["c2"][1] + ", N-rank code path on one rank (LGH_FORCE_MULTI=1, RCCL communicator of size 1)"),
 }
@@ -349,7 +465,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="skip the extra legs (64^3 Sedov / Taylor-Green, Q5Q4, developed flow, N-rank path)")
-    ap.add_argument("--legs", default="c3,tg,c5,c2dev,c2multi", help="comma-separated extra legs of a single-GPU run")
+    ap.add_argument("--legs", default="c3,tg,c5,c2dev,c2stored,c2multi", help="comma-separated extra legs of a single-GPU run")
     ap.add_argument("--watchdog", type=float, default=300.0,
                     help="several ranks: seconds a rank may spend without finishing a step before it reports and exits (a mismatched collective would otherwise hang silently)")
     a = ap.parse_args()
@@ -486,18 +602,10 @@ def main():
             }
         sim.enable_timers(False)
         mark("per-kernel timing")
-        kern, agg = measure_kernels(sim, sz)
-        k1_name = [k for k in kern if k.startswith("vcg_apply")]
-        dom = kern.get(k1_name[0]) if k1_name else None
-        if dom:
-            traffic, traffic_source = pmc_traffic(a.workload) if (world == 1 and a.workload in ("c2", "c3")) else (None, "not collected for this workload")
-            out["roofline"] = {"bound": "hbm", "kernel": k1_name[0], "achieved": dom["GBs"], "peak": HBM_PEAK_GBS,
-                               "unit": "GB/s", "frac": dom["GBs"] / HBM_PEAK_GBS,
-                               "achievable": HBM_ACHIEVABLE_GBS, "frac_of_achievable": dom["GBs"] / HBM_ACHIEVABLE_GBS,
-                               "traffic": traffic, "traffic_source": traffic_source,
-                               "mean_launch_us": dom["mean_us"], "launches_sampled": dom["launches"],
-                               "algorithmic_bytes_per_launch": dom["algorithmic_bytes"]}
-            out["roofline"].update(agg)
+        kern, agg, raw, names = measure_kernels(sim, sz)
+        rl = roofline_block(kern, agg, raw, names, a.workload if (world == 1 and a.workload in ("c2", "c3", "tg")) else None)
+        if rl:
+            out["roofline"] = rl
         out["kernels"] = kern
         if world > 1 or os.environ.get("LGH_FORCE_MULTI") == "1":
             mark("exchange timing")
@@ -514,11 +622,9 @@ def main():
             leg = LEGS[name]
             try:
                 largs = list(leg["args"]) + ["-ok", leg["order"][0], "-ot", leg["order"][1], "-pa", "-tf", 1e9, "-ms", 10 ** 6, "-vs", 10 ** 9]
-                legs[name] = run_leg(host_lib, largs, steps=leg["steps"], warmup=leg["warmup"], dev=local_rank, force_multi=leg.get("force_multi", False))
+                legs[name] = run_leg(host_lib, largs, steps=leg["steps"], warmup=leg["warmup"], dev=local_rank, force_multi=leg.get("force_multi", False),
+                                     env=leg.get("env"), pmc_key=name if name in ("c3", "tg") else None)
                 legs[name]["workload"] = leg["workload"]
-                if name == "c3":
-                    t, src = pmc_traffic("c3")
-                    legs[name]["roofline_traffic"] = {"k1_bytes_per_launch": t, "source": src}
             except Exception as e:  # an extra leg must not cost the headline number
                 legs[name] = {"error": repr(e)}
         if "c2multi" in legs and "value" in legs["c2multi"]:
@@ -527,9 +633,12 @@ def main():
 
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         try:
-            out["cpu_baseline"] = cpu_baseline(min(usable_cpus(), 64))
+            out["cpu_baseline"], ref = cpu_baseline(min(usable_cpus(), 64))
+            if a.workload == "c2":
+                out["parity"] = parity_block(host_lib, list(WORKLOADS["c2"][0]) + common, local_rank, ref)
         except Exception as e:  # the checker is optional for the measurement
-            out["cpu_baseline"] = {"error": repr(e)}
+            out.setdefault("cpu_baseline", {"error": repr(e)})
+            out.setdefault("parity", {"error": repr(e)})
     flush_c_stdio()
     if dist is not None:
         dist.barrier()

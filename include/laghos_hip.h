@@ -85,6 +85,11 @@ double *lgh_mass_D(lgh_ctx *ctx);
  * on the device (every entry to 1e-12 relative, the size of the rounding of the stored entries; LGH_MASS_RANK1_TOL) at the first mass apply after lgh_setup_rho0detj0() or after lgh_mass_D() was
  * called: a caller that writes through the lgh_mass_D() pointer calls lgh_mass_D() again after its last write. */
 int lgh_mass_data_form(lgh_ctx *ctx, int *form);
+/* A caller that keeps the lgh_mass_D() pointer and writes the table after a mass apply has run says so with this call
+ * (calling lgh_mass_D() again does the first half too): the compact form is tested for again at the next apply,
+ * and the Jacobi diagonal (lgh_mass_diag, OperatorJacobiSmoother of laghos_solver.cpp:266-270) is reassembled from the
+ * new table, so that the operator every kernel form applies and its preconditioner stay the same matrix. */
+int lgh_mass_data_changed(lgh_ctx *ctx);
 double *lgh_mass_diag(lgh_ctx *ctx); /* Jacobi diagonal of the scalar H1 mass (N) */
 int lgh_set_h0(lgh_ctx *ctx, double h0);
 int lgh_get_h0(lgh_ctx *ctx, double *h0);
@@ -306,6 +311,16 @@ int lgh_allreduce(lgh_ctx *ctx, double *value, int op);
 int lgh_force_mult_E(lgh_ctx *ctx, const double *sJit, const double *x_E, double *y_E);
 int lgh_force_mult_transpose_E(lgh_ctx *ctx, const double *sJit, const double *v_E, double *y_E);
 int lgh_mass_apply_E(lgh_ctx *ctx, int space, const double *x_E, double *y_E);
+/* ONE launch of the mass-apply kernel K1 of the lockstep velocity solve - in whichever form lgh_k1_form() reports
+ * (column / plane / matrix-core / slab), i.e. the kernel lgh_solve_velocity spends most of its time in - exactly as
+ * the solve launches it: first != 0: the first iteration (d = r/diag), else a later one (d = r/diag + beta d_old,
+ * beta = rz[c] / rz_prev[c]).  r, d_old: H1 vectors of 3 components (byNODES, device); rz, rz_prev, den: 3 host
+ * doubles; y_E: 3 planes of NE*D1D^3 (device) = the element contributions A_e d_e (MassPAOperator::Mult before the
+ * E->L sum, laghos_assembly.cpp:117-121); den[c] = (d_c, A d_c).  rz[c] must be (r_c, r_c/diag) of the vectors
+ * given (the slab form scales its exact accumulators by it).  Single rank; synchronous; overwrites the solve's own
+ * work vectors only. */
+int lgh_test_vcg_k1(lgh_ctx *ctx, const double *r, const double *d_old, const double rz[3], const double rz_prev[3],
+                    int first, double *y_E, double den[3]);
 /* halo pieces without the RCCL transport (tests emulate the exchange between
  * several contexts on one GPU): rank bookkeeping, pack into / combine from caller
  * buffers of 3*total doubles laid out as the send / receive buffers are. */

@@ -87,6 +87,7 @@ SYMBOLS = {
     "lgh_table_symmetry": (_I, [_P, c_int_p, c_int_p]),
     "lgh_k1_form": (_I, [_P, c_int_p]),
     "lgh_mass_data_form": (_I, [_P, c_int_p]),
+    "lgh_mass_data_changed": (_I, [_P]),
     "lgh_comm_stats": (_I, [_P, c_int_p, ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_long), c_int_p, c_int_p]),
     "lgh_qupdate_set_tiny_grad": (_I, [_P, _D]),
     "lgh_set_fused_forces": (_I, [_P, _I]),
@@ -105,6 +106,7 @@ SYMBOLS = {
     "lgh_force_mult_E": (_I, [_P, _P, _P, _P]),
     "lgh_force_mult_transpose_E": (_I, [_P, _P, _P, _P]),
     "lgh_mass_apply_E": (_I, [_P, _I, _P, _P]),
+    "lgh_test_vcg_k1": (_I, [_P, _P, _P, c_dbl_p, c_dbl_p, _I, _P, c_dbl_p]),
     "lgh_test_set_rank": (_I, [_P, _I, _I]),
     "lgh_test_halo_pack": (_I, [_P, _P, _I, _P]),
     "lgh_test_halo_combine": (_I, [_P, _P, _P, _I]),

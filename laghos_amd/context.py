@@ -178,6 +178,16 @@ class Context:
         self._write(self.lib.lgh_mass_D(self.h), np.ascontiguousarray(arr, dtype=np.float64))
         self.lib.lgh_mass_D(self.h)
 
+    def write_massD_in_place(self, arr):
+        """overwrite the table through the pointer as a caller that kept it would (no second lgh_mass_D call);
+        lgh_mass_data_changed() is then the caller's duty"""
+        if not hasattr(self, "_massD_ptr"):
+            self._massD_ptr = self.lib.lgh_mass_D(self.h)
+        self._write(self._massD_ptr, np.ascontiguousarray(arr, dtype=np.float64))
+
+    def mass_data_changed(self):
+        check(self.lib.lgh_mass_data_changed(self.h))
+
     @property
     def mass_diag(self):
         return self._view(self.lib.lgh_mass_diag(self.h), self.N)
@@ -238,6 +248,14 @@ class Context:
         f = ctypes.c_int(-2)
         check(self.lib.lgh_k1_form(self.h, ctypes.byref(f)))
         return {0: "column", 2: "plane", 3: "mfma", 4: "slab"}.get(f.value)
+
+    def test_vcg_k1(self, r, d_old, rz, rz_prev, first):
+        """One launch of the lockstep solve's K1 (lgh_test_vcg_k1): (E-vector planes [3, NE*ND] tensor, den[3])."""
+        y = self.empty(3 * self.NE * self.ND)
+        rz, rzp, den = _np_f64(rz), _np_f64(rz_prev), np.zeros(3)
+        check(self.lib.lgh_test_vcg_k1(self.h, _ptr(r), _ptr(d_old) if d_old is not None else None, _dbl(rz), _dbl(rzp),
+                                       int(bool(first)), _ptr(y), _dbl(den)))
+        return y.view(3, -1), den
 
     def mass_data_form(self):
         """'rank1' when the mass kernels read D[q, e] = W[q] s_e (one double per element), 'stored' otherwise."""

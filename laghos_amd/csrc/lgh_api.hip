@@ -511,6 +511,12 @@ int lgh_mass_data_form(lgh_ctx *c, int *form)
    *form = (c->mass_rank1 == 1) ? 1 : 0;
    return LGH_OK;
 }
+int lgh_mass_data_changed(lgh_ctx *c)
+{
+   LGH_CHECK_ARG(c);
+   c->mass_rank1 = -1;            // the compact form is looked for again at the next mass apply
+   return mass_assemble_diag(c);  // operator and Jacobi preconditioner stay consistent (laghos_solver.cpp:266-270)
+}
 double *lgh_mass_diag(lgh_ctx *c) { return c->diagV; }
 int lgh_set_h0(lgh_ctx *c, double h0) { LGH_CHECK_ARG(c); c->h0 = h0; return LGH_OK; }
 int lgh_get_h0(lgh_ctx *c, double *h0) { LGH_CHECK_ARG(c && h0); *h0 = c->h0; return LGH_OK; }
@@ -1021,6 +1027,12 @@ int lgh_k1_form(lgh_ctx *c, int *form)
    return LGH_OK;
 }
 
+int lgh_test_vcg_k1(lgh_ctx *c, const double *r, const double *d_old, const double rz[3], const double rz_prev[3], int first,
+                    double *y_E, double den[3])
+{
+   LGH_CHECK_ARG(c && r && (first || d_old) && rz && rz_prev && y_E && den);
+   return vcg_test_k1(c, r, d_old, rz, rz_prev, first, y_E, den);
+}
 int lgh_force_mult_E(lgh_ctx *c, const double *sJit, const double *x_E, double *y_E)
 {
    LGH_CHECK_ARG(c && sJit && x_E && y_E);

@@ -251,11 +251,11 @@ int halo_sum(lgh_ctx *c, double *v, int ncomp, double *extra, int nextra, bool p
    double *const sbuf = ch2 ? cm->sendbuf2 : cm->sendbuf;
    double *const rbuf = ch2 ? cm->recvbuf2 : cm->recvbuf;
    const ncclComm_t ncomm = ch2 ? cm->comm2 : cm->comm;
-   kt_begin(c, LGH_KERNEL_HALO); // (sampling on: one event pair around pack + exchange + combine)
+   if (packed && ch2) { set_error("halo_sum: pre-packed messages use the main channel"); return LGH_ERR_ARG; }
+   KtScope sample(c, LGH_KERNEL_HALO); // (sampling on: one event pair around pack + exchange + combine, closed on error returns too)
    // ncomp == 0 (v unused): the messages carry the scalars only - a sum over the ranks as one
    // exchange with every peer (allreduce_dev uses it in all-pairs partitions)
    const long npack = std::max((long)tot * ncomp, (long)cm->n_nbr * nx);
-   if (packed && ch2) { set_error("halo_sum: pre-packed messages use the main channel"); return LGH_ERR_ARG; }
    if (!packed)
    {
       hipLaunchKernelGGL(halo_pack_k, dim3(ceil_div(npack, 256)), dim3(256), 0, c->stream, tot,
@@ -291,7 +291,6 @@ int halo_sum(lgh_ctx *c, double *v, int ncomp, double *extra, int nextra, bool p
       if (!g->barrier()) { set_error("local communicator: barrier timed out (halo)"); return LGH_ERR_COMM; } // peers may repack
       combine();
       LGH_HIP_CHECK(hipGetLastError());
-      kt_end(c, LGH_KERNEL_HALO);
       return LGH_OK;
    }
    LGH_NCCL_CHECK(g_nccl.GroupStart());
@@ -305,7 +304,6 @@ int halo_sum(lgh_ctx *c, double *v, int ncomp, double *extra, int nextra, bool p
    LGH_NCCL_CHECK(g_nccl.GroupEnd());
    combine();
    LGH_HIP_CHECK(hipGetLastError());
-   kt_end(c, LGH_KERNEL_HALO);
    return LGH_OK;
 }
 

@@ -149,6 +149,7 @@ struct lgh_ctx
    int vcg_last;
    int vcg_grid;         // persistent grid size of the K1 kernel (one resident wave)
    int b_h1_sym, b_l2_sym; // the 1-D H1 / L2 table is mirror symmetric, B[q,d] = B[Q-1-q, D-1-d] (to 1e-14: the round-off of its evaluation): kernels may hold half of it
+   int ncu;              // CUs of this context's device (0: not asked yet)
    int vcg_variant;      // LGH_VCG_VARIANT: which K1 form vcg_solve launches (lgh_vcg.hip); -1: by kernel id and mesh size
    int slab_wps, slab_wide, slab_exact, slab_dyn; // A/B switches of the slab-form K1 (LGH_SLAB_WPS / _WIDE / _EXACT / _DYN, read by lgh_create)
    void *vcg_aux;        // tables of the node kernel K2 (lgh_vcg.hip VcgAux), allocated on first use
@@ -425,6 +426,8 @@ int make_essbits(lgh_ctx *c, uint8_t **out);
 void vcg_free(lgh_ctx *c);
 constexpr int kYePad = 16; // doubles behind every Y_E plane of the CG; the first one (slot NE*ND) stays 0.0
 bool vcg_available(const lgh_ctx *c);
+int vcg_test_k1(lgh_ctx *c, const double *r, const double *d_old, const double rz[3], const double rz_prev[3], int first,
+                double *YE_out, double den_out[3]); // one launch of K1 (test hook)
 int vcg_k1_form(lgh_ctx *c); // 0 column, 2 plane, 3 matrix cores, 4 slab, -1 none
 // multi-rank: flags / list of the nodes shared with other ranks (nullptr / 0 without neighbours)
 void comm_shared_nodes(const lgh_ctx *c, const uint8_t **hmask, const int **sh_node, int *n_shared);
@@ -473,6 +476,17 @@ inline void kt_end(lgh_ctx *c, int id)
    KTime *k = c->ktime;
    if (k && k->which == id && k->n < k->max) { (void)hipEventRecord(k->ev[2 * k->n + 1], c->stream); k->n++; }
 }
+
+// one sample around a scope: closed on every way out (error returns included)
+struct KtScope
+{
+   lgh_ctx *c;
+   int id;
+   KtScope(lgh_ctx *c_, int id_) : c(c_), id(id_) { kt_begin(c, id); }
+   ~KtScope() { kt_end(c, id); }
+   KtScope(const KtScope &) = delete;
+   KtScope &operator=(const KtScope &) = delete;
+};
 
 void timer_start(lgh_ctx *c);
 void timer_stop(lgh_ctx *c, int which);

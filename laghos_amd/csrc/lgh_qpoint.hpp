@@ -835,7 +835,7 @@ template <int MODE> static int launch_q(lgh_ctx *c, const QArgs &a)
          if constexpr (MODE == QMODE_UPDATE)
          {
             // two points per thread: 500-thread workgroups under a cap of 256 registers instead of 1000 under 128 (41 spilled)
-            static const char *penv = getenv("LGH_Q_PPT"); // A/B: 1 = one point per thread
+            const char *penv = getenv("LGH_Q_PPT"); // A/B: 1 = one point per thread (read per launch: tests switch it)
             if (!(penv && penv[0] == '1'))
             {
                hipLaunchKernelGGL((qpoint_kernel<3, 6, 10, 5, 1, 6, MODE, 2>), dim3(c->NE), dim3(500), 0, c->stream, a);

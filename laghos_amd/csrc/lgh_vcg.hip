@@ -1626,9 +1626,20 @@ bool vcg_fused_init_ok(const lgh_ctx *c)
 // force_E != nullptr: B and X are outputs - the init kernel forms B = -(H1R^T force_E) with the
 // essential rows zeroed and X = 0 itself (single rank only; see vcg_init_force_k).
 // iters[c] = GetNumIterations() of component c.
-int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, int iters[3], const double *force_E)
+// Everything a launch of the lockstep kernels needs: work vectors, tables of K2, the argument block (vcg_solve, and the
+// one-launch test hook vcg_test_k1 below).  Launches vcg_set_tol_k on the context stream.
+static const char *trace_path = nullptr; // debug: LGH_VCG_TRACE=<file>
+static bool trace_asked = false;
+static unsigned long long *trace_dev = nullptr;
+struct VcgPlan
 {
-   if (!vcg_supported(c)) { return LGH_ERR_UNSUPPORTED; }
+   VcgArgs a;
+   VcgAux *aux;
+   int k1form;
+   bool k2p;
+};
+static int vcg_prepare(lgh_ctx *c, double *B, double *X, double rel_tol, VcgPlan &plan)
+{
    const bool multi = c->multi != 0;
    const size_t N = (size_t)c->N;
    int rc;
@@ -1756,8 +1767,7 @@ int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
    a.multi = multi ? 1 : 0;
    // debug: LGH_VCG_TRACE=<file> dumps "block start loop_end end (xcc<<32|hw_id)" of the
    // last K1 launch of every solve, in 10 ns ticks
-   static const char *trace_path = getenv("LGH_VCG_TRACE");
-   static unsigned long long *trace_dev = nullptr;
+   if (!trace_asked) { trace_path = getenv("LGH_VCG_TRACE"); trace_asked = true; }
    if (trace_path && !trace_dev) { (void)hipMalloc((void **)&trace_dev, kTraceRec * 4096 * sizeof(unsigned long long)); (void)hipMemset(trace_dev, 0, kTraceRec * 4096 * sizeof(unsigned long long)); }
    a.trace = trace_dev;
    if (trace_dev) { (void)hipMemsetAsync(trace_dev, 0, kTraceRec * 4096 * sizeof(unsigned long long), c->stream); }
@@ -1776,6 +1786,51 @@ int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
          a.pack_rz = halo_can_piggyback(c) ? 1 : 0;
       }
    }
+   plan.a = a;
+   plan.aux = aux;
+   plan.k1form = k1form;
+   plan.k2p = k2p;
+   return LGH_OK;
+}
+
+// one launch of K1 in the form vcg_k1_form() names (a.iter, a.partials, a.ticket set by the caller)
+static void vcg_launch_k1(lgh_ctx *c, const VcgPlan &plan, const VcgArgs &a)
+{
+   VcgAux *aux = plan.aux;
+   const int k1form = plan.k1form;
+   switch (c->kid)
+   {
+      case 0x322: VCG_DISPATCH(2, 2); break;
+      case 0x334: VCG_DISPATCH(3, 4); break;
+      case 0x346:
+         if (aux->mapb && k1form == 4) { launch_vcg_slab(c, a); } // slab form: all in registers (lgh_vcg_slab.hip)
+         else if (aux->mapb && k1form == 3) { launch_vcg_mfma(c, a); } // LGH_VCG_VARIANT=3: x contractions on the matrix cores (lgh_vcg_mfma.hip)
+         else { VCG_DISPATCH(4, 6); }
+         break;
+      case 0x358: // LGH_VCG_VARIANT=1: the two-lanes-per-plane split at Q1D = 8 as well (A/B, tests)
+         if (c->vcg_variant == 0 || !c->b_h1_sym) { launch_vcg_apply<5, 8>(c, a); } // (the plane form uses half a table)
+         else if (c->vcg_variant == 1) { launch_vcg_plane_ho<5, 8, 2, 5>(c, a); }
+         else { launch_vcg_plane_ho<5, 8, 1, 5>(c, a); }
+         break;
+      case 0x36A:
+         if (c->vcg_variant == 0 || !c->b_h1_sym) { launch_vcg_apply<6, 10>(c, a); }
+         else { launch_vcg_plane_ho<6, 10, 2, 4>(c, a); }
+         break;
+   }
+}
+
+int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, int iters[3], const double *force_E)
+{
+   if (!vcg_supported(c)) { return LGH_ERR_UNSUPPORTED; }
+   VcgPlan plan;
+   int rc = vcg_prepare(c, B, X, rel_tol, plan);
+   if (rc) { return rc; }
+   VcgArgs &a = plan.a;
+   VcgAux *aux = plan.aux;
+   const bool k2p = plan.k2p;
+   const bool multi = c->multi != 0;
+   const size_t N = (size_t)c->N;
+   VcgScalars *ds = (VcgScalars *)c->vcg_s;
    const int nb = ceil_div((long)N, 256);
 
    // init (vector kernels use reduction slot 0, the element kernel slot 1)
@@ -1828,25 +1883,7 @@ int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
          a.partials = c->vcg_partials + (size_t)kVC * c->vcg_stride;
          a.ticket = c->vcg_tickets + kTicketSlot;
          kt_begin(c, LGH_KERNEL_MASS_CG_H1);
-         switch (c->kid)
-         {
-            case 0x322: VCG_DISPATCH(2, 2); break;
-            case 0x334: VCG_DISPATCH(3, 4); break;
-            case 0x346:
-               if (aux->mapb && k1form == 4) { launch_vcg_slab(c, a); } // slab form: all in registers (lgh_vcg_slab.hip)
-               else if (aux->mapb && k1form == 3) { launch_vcg_mfma(c, a); } // LGH_VCG_VARIANT=3: x contractions on the matrix cores (lgh_vcg_mfma.hip)
-               else { VCG_DISPATCH(4, 6); }
-               break;
-            case 0x358: // LGH_VCG_VARIANT=1: the two-lanes-per-plane split at Q1D = 8 as well (A/B, tests)
-               if (c->vcg_variant == 0 || !c->b_h1_sym) { launch_vcg_apply<5, 8>(c, a); } // (the plane form uses half a table)
-               else if (c->vcg_variant == 1) { launch_vcg_plane_ho<5, 8, 2, 5>(c, a); }
-               else { launch_vcg_plane_ho<5, 8, 1, 5>(c, a); }
-               break;
-            case 0x36A:
-               if (c->vcg_variant == 0 || !c->b_h1_sym) { launch_vcg_apply<6, 10>(c, a); }
-               else { launch_vcg_plane_ho<6, 10, 2, 4>(c, a); }
-               break;
-         }
+         vcg_launch_k1(c, plan, a);
          kt_end(c, LGH_KERNEL_MASS_CG_H1);
          LGH_HIP_CHECK(hipGetLastError());
          a.partials = c->vcg_partials;
@@ -1950,6 +1987,49 @@ int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
       mx = std::max(mx, fin);
    }
    c->vcg_last = mx;
+   return LGH_OK;
+}
+
+// Test hook (lgh_test_vcg_k1): ONE launch of K1, in whichever form vcg_solve dispatches for this context, exactly as
+// the solve would launch it in its first iteration (first != 0: d = r/diag) or in a later one (d = r/diag + beta d_old
+// with beta = rz / rz_prev), on the caller's vectors.  Returns what K1 hands to K2: the element contributions
+// A_e d_e of the three components as E-vectors (kVC planes of NE*ND, element-local lexicographic) and (d, A d).
+// Single rank.  The vectors of the lockstep solve (r, d) are overwritten; nothing else of the context changes.
+int vcg_test_k1(lgh_ctx *c, const double *r, const double *d_old, const double rz[3], const double rz_prev[3],
+                int first, double *YE_out, double den_out[3])
+{
+   if (!vcg_supported(c)) { set_error("lgh_test_vcg_k1: no lockstep solve for kernel 0x%x", c->kid); return LGH_ERR_UNSUPPORTED; }
+   if (c->multi != 0) { set_error("lgh_test_vcg_k1: single rank only"); return LGH_ERR_ARG; }
+   VcgPlan plan;
+   int rc = vcg_prepare(c, nullptr, nullptr, 0.0, plan);
+   if (rc) { return rc; }
+   VcgArgs &a = plan.a;
+   const size_t N = (size_t)c->N, nE = (size_t)c->NE * c->ND;
+   VcgScalars *ds = (VcgScalars *)c->vcg_s;
+   LGH_HIP_CHECK(hipMemcpyAsync(a.r, r, kVC * N * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+   if (first) { LGH_HIP_CHECK(hipMemsetAsync(a.d, 0, kVC * N * sizeof(double), c->stream)); }
+   else { LGH_HIP_CHECK(hipMemcpyAsync(a.d, d_old, kVC * N * sizeof(double), hipMemcpyDeviceToDevice, c->stream)); }
+   LGH_HIP_CHECK(hipStreamSynchronize(c->stream)); // (vcg_set_tol_k has cleared the accumulators and the set counters)
+   VcgScalars h;
+   memset(&h, 0, sizeof(h));
+   for (int k = 0; k < kVC; k++) { h.rz[k] = rz[k]; h.rz_prev[k] = rz_prev[k]; }
+   h.first = first ? 1 : 0;
+   LGH_HIP_CHECK(hipMemcpy(ds, &h, sizeof(h), hipMemcpyHostToDevice));
+   a.iter = first ? 1 : 2;
+   a.partials = c->vcg_partials + (size_t)kVC * c->vcg_stride;
+   a.ticket = c->vcg_tickets + kTicketSlot;
+   vcg_launch_k1(c, plan, a);
+   LGH_HIP_CHECK(hipGetLastError());
+   // (slab form with deferred fold: K2 would form den from the accumulators - the one-workgroup fold of the several-rank path does the same)
+   if (a.den_limbs) { hipLaunchKernelGGL(vcg_fold_den_k, dim3(1), dim3(256), 0, c->stream, a); }
+   LGH_HIP_CHECK(hipGetLastError());
+   LGH_HIP_CHECK(hipStreamSynchronize(c->stream));
+   LGH_HIP_CHECK(hipMemcpy(&h, ds, sizeof(h), hipMemcpyDeviceToHost));
+   for (int k = 0; k < kVC; k++)
+   {
+      den_out[k] = h.den[k];
+      LGH_HIP_CHECK(hipMemcpy(YE_out + (size_t)k * nE, a.YE + (size_t)k * a.ye_stride, nE * sizeof(double), hipMemcpyDeviceToDevice));
+   }
    return LGH_OK;
 }
 

@@ -706,12 +706,12 @@ bool vcg_slab_available(lgh_ctx *c)
 
 void launch_vcg_slab(lgh_ctx *c, const VcgArgs &a)
 {
-   static int ncu = 0;
-   if (ncu == 0)
+   if (c->ncu <= 0) // (per context: contexts of one process may sit on different devices)
    {
       hipDeviceProp_t prop;
-      ncu = (hipGetDeviceProperties(&prop, c->device) == hipSuccess) ? prop.multiProcessorCount : 256;
+      c->ncu = (hipGetDeviceProperties(&prop, c->device) == hipSuccess) ? prop.multiProcessorCount : 256;
    }
+   const int ncu = c->ncu;
    const int wps = c->slab_wps; // wavefronts per SIMD (workgroup of 256 or 512 threads, one per CU)
    const int nset = ceil_div(c->NE, 5);
    const int grid = std::min(ceil_div(nset, 4 * wps), ncu); // one workgroup of 4 wps wavefronts per CU
@@ -724,8 +724,10 @@ void launch_vcg_slab(lgh_ctx *c, const VcgArgs &a)
                                                else if (wide) { LGH_SLAB_LAUNCH(SYM_, WPS_, TR_, true, false, false); } \
                                                else if (exact) { LGH_SLAB_LAUNCH(SYM_, WPS_, TR_, false, true, false); } else { LGH_SLAB_LAUNCH(SYM_, WPS_, TR_, false, false, false); } } while (0)
    static const bool trace_full = getenv("LGH_VCG_TRACE_PHASES") != nullptr; // per-phase cycle counters as well (more registers: not the shipped schedule)
-   if (a.trace && trace_full) { if (wps == 2) { LGH_SLAB_LAUNCH2(true, 2, 2); } else { LGH_SLAB_LAUNCH2(true, 1, 2); } }
-   else if (a.trace) { if (wps == 2) { LGH_SLAB_LAUNCH2(true, 2, 1); } else { LGH_SLAB_LAUNCH2(true, 1, 1); } } // debug (LGH_VCG_TRACE): wall-clock stamps per workgroup
+   // (the traced instantiations exist for the mirror-symmetric table only: a context without the symmetry runs untraced)
+   const bool tr = a.trace != nullptr && c->b_h1_sym;
+   if (tr && trace_full) { if (wps == 2) { LGH_SLAB_LAUNCH2(true, 2, 2); } else { LGH_SLAB_LAUNCH2(true, 1, 2); } }
+   else if (tr) { if (wps == 2) { LGH_SLAB_LAUNCH2(true, 2, 1); } else { LGH_SLAB_LAUNCH2(true, 1, 1); } } // debug (LGH_VCG_TRACE): wall-clock stamps per workgroup
    else if (wps == 2) { if (c->b_h1_sym) { LGH_SLAB_LAUNCH2(true, 2, 0); } else { LGH_SLAB_LAUNCH2(false, 2, 0); } }
    else { if (c->b_h1_sym) { LGH_SLAB_LAUNCH2(true, 1, 0); } else { LGH_SLAB_LAUNCH2(false, 1, 0); } }
 #undef LGH_SLAB_LAUNCH2

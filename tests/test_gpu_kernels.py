@@ -708,6 +708,63 @@ def test_mass_data_forms(variant, monkeypatch):
     assert rel_err(dS_t[H1V:], dS_c[H1V:]) < 1e-10
 
 
+@pytest.mark.parametrize("variant", ["2", "4"], ids=["plane", "slab"])
+def test_mass_data_changed_keeps_operator_and_diagonal_consistent(variant, monkeypatch):
+    """A caller that keeps the lgh_mass_D() pointer and rewrites the table AFTER a mass apply has run (round-3 advisor:
+    the compact form would stay stale in the plane / slab kernels while the column kernels and the Jacobi diagonal
+    see other data) announces it with lgh_mass_data_changed(): the form is detected again and the diagonal is
+    reassembled.  A table scaled by 2 (exact in binary) must double the product, the diagonal and K1's E-vector bit
+    for bit and stay compact; a factor that varies inside the elements must switch every kernel to the stored table."""
+    from oracle.fem import Problem
+    prob = Problem(mesh="box01_hex", rs=1, order_v=3, order_e=2, problem=1)
+    monkeypatch.setenv("LGH_VCG_VARIANT", variant)
+    xv = seeded(prob.N, 61)
+    r = seeded(3 * prob.N, 62)
+    g = make_gpu(prob)
+    try:
+        ctx = g.ctx
+        D0 = ctx.massD.cpu().numpy().copy()
+        diag0 = ctx.mass_diag.cpu().numpy().copy()
+        xvd, rd = ctx.to_dev(xv), ctx.to_dev(r)
+        ctx.mass_set_ess(-1)
+
+        def products():
+            y = ctx.empty(prob.N)
+            ctx.mass_mult(0, xvd, y)
+            ctx.sync()
+            dinv = 1.0 / ctx.mass_diag.cpu().numpy()
+            rz = np.array([float(np.dot(r[c * prob.N:(c + 1) * prob.N] ** 2, dinv)) for c in range(3)])
+            yE, den = ctx.test_vcg_k1(rd, None, rz, rz, True)
+            return y.cpu().numpy(), yE.cpu().numpy().copy(), den, rz
+
+        y0, yE0, den0, rz0 = products()
+        assert ctx.mass_data_form() == "rank1"
+        ctx.write_massD_in_place(2.0 * D0)      # pointer kept, no lgh_mass_D() afterwards
+        ctx.mass_data_changed()
+        y1, yE1, den1, rz1 = products()
+        assert ctx.mass_data_form() == "rank1"
+        assert np.array_equal(ctx.mass_diag.cpu().numpy(), 2.0 * diag0)
+        assert np.array_equal(y1, 2.0 * y0)
+        # d = r/diag halves, A doubles: the E-vector is unchanged, (d, A d) halves - exactly
+        assert np.array_equal(yE1, yE0) and np.array_equal(den1, 0.5 * den0)
+        factor = 1.0 + 0.25 * np.abs(seeded(prob.NE * prob.NQ, 63))
+        ctx.write_massD_in_place(D0 * factor)
+        ctx.mass_data_changed()
+        y2, yE2, den2, rz2 = products()
+        assert ctx.mass_data_form() == "stored"
+        assert rel_err(y2, y0) > 1e-3
+        # the preconditioner belongs to the new operator: diag = diagonal of the matrix the kernels apply
+        e = np.zeros(prob.N)
+        n0 = prob.N // 2
+        e[n0] = 1.0
+        col = ctx.empty(prob.N)
+        ctx.mass_mult(0, ctx.to_dev(e), col)
+        ctx.sync()
+        assert abs(col.cpu().numpy()[n0] - ctx.mass_diag.cpu().numpy()[n0]) < 1e-13 * abs(diag0[n0])
+    finally:
+        g.close()
+
+
 @pytest.mark.parametrize("order", [(3, 2), (4, 3)], ids=["Q3Q2", "Q4Q3"])
 def test_mass_kernels_without_table_symmetry(order, monkeypatch):
     """LGH_B_SYM=0: lgh_create treats the 1-D tables as not mirror symmetric, as it would for a basis on asymmetric

@@ -200,6 +200,27 @@ def test_full_size_sedov_steps(full_size):
     assert abs(e0 - 0.125) < 1e-12  # E0/2^dim (laghos.cpp:603-604)
 
 
+def test_config2_full_size_vs_oracle():
+    """BASELINE configs[1] at FULL size against the oracle, not only through size-independent properties: 3 RK4 steps
+    of the 32^3 Q3Q2 Sedov problem from t = 0 on both sides (12 stages: QUpdate, both force products, three H1 PCG
+    solves and the L2 CG solve each, through the kernels the bench times - slab K1, bounded-grid K2, fused QUpdate -
+    and the dt controller).  Same step count, same dt, |e| to 1e-9, every block of the state to 1e-8 of its largest
+    entry (the solves stop at cg_tol = 1e-8 on both sides with dot products summed in different orders)."""
+    from laghos_amd import hydro
+    from oracle.driver import run as oracle_run
+    from oracle.fem import Problem
+    prob = Problem(mesh="cube01_hex", rs=4, order_v=3, order_e=2, problem=1)
+    ro = oracle_run(prob, max_steps=3, probe_steps=(1, 2, 3))
+    rg = hydro.run(prob, max_steps=3, probe_steps=(1, 2, 3), timers=False)
+    assert rg["steps"] == ro["steps"] >= 3 and rg["repeats"] == ro["repeats"]  # (laghos.cpp:716: the step after max_steps still runs)
+    assert abs(rg["dt"] - ro["last"]["dt"]) <= 1e-12 * ro["last"]["dt"]
+    for ti in (1, 2, 3):
+        assert abs(rg["probes"][ti] - ro["probes"][ti]) <= 1e-9 * ro["probes"][ti], ti
+    H1V = prob.H1V
+    for name, sl in (("x", slice(0, H1V)), ("v", slice(H1V, 2 * H1V)), ("e", slice(2 * H1V, None))):
+        assert rel_err(rg["S"][sl], ro["S"][sl]) < 1e-8, name
+
+
 # ---- the C++ host layer (laghos_amd/host): reference API mirror + driver --------------------
 @pytest.mark.parametrize("mesh,prob", [(m, p) for p in range(8) for m in ("data/cube01_hex.mesh", "data/square01_quad.mesh")])
 def test_cpp_driver_checks(mesh, prob):
