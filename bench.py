@@ -169,8 +169,8 @@ def parity_block(host_lib, args, dev, ref):
     out["dt_rel_diff"] = abs(out["dt_hip"] - ref["dt"]) / ref["dt"]
     for name, sl in (("x", slice(0, H1V)), ("v", slice(H1V, 2 * H1V)), ("e", slice(2 * H1V, None))):
         out["state_%s_max_rel_diff" % name] = float(np.abs(S[sl] - So[sl]).max() / np.abs(So[sl]).max())
-    out["tolerances"] = {"e_norm": 1e-9, "state": 1e-8, "dt": 1e-12}
-    out["pass"] = bool(out["rk4_steps_executed_hip"] == ref["steps"] and out["e_norm_rel_diff"] <= 1e-9 and out["dt_rel_diff"] <= 1e-12
+    out["tolerances"] = {"e_norm": 1e-9, "state": 1e-8, "dt": 1e-9}
+    out["pass"] = bool(out["rk4_steps_executed_hip"] == ref["steps"] and out["e_norm_rel_diff"] <= 1e-9 and out["dt_rel_diff"] <= 1e-9
                        and all(out["state_%s_max_rel_diff" % n] <= 1e-8 for n in "xve"))
     return out
 
