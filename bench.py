@@ -466,6 +466,10 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="skip the extra legs (64^3 Sedov / Taylor-Green, Q5Q4, developed flow, N-rank path)")
     ap.add_argument("--legs", default="c3,tg,c5,c2dev,c2stored,c2multi", help="comma-separated extra legs of a single-GPU run")
+    ap.add_argument("--transport", choices=("rccl", "shm"), default="rccl",
+                    help="several ranks: rccl = the product transport (one GPU per rank, RCCL over xGMI); shm = the cross-process loopback "
+                         "transport of lgh_comm.hip (ranks may share one GPU: the torchrun / id broadcast / N-rank code path on a one-GPU box)")
+    ap.add_argument("--block", type=int, default=32, help="several ranks: zones per rank and axis (32 = BASELINE.json's weak-scaling block; smaller: tests)")
     ap.add_argument("--watchdog", type=float, default=300.0,
                     help="several ranks: seconds a rank may spend without finishing a step before it reports and exits (a mismatched collective would otherwise hang silently)")
     a = ap.parse_args()
@@ -482,30 +486,35 @@ def main():
         a.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X GPU (no CPU fallback)")
+    shm = a.transport == "shm"
+    if shm:
+        local_rank = local_rank % torch.cuda.device_count()  # the ranks may share a GPU
     torch.cuda.set_device(local_rank)
     nccl_id = None
     dist = None
+    ddev = "cpu" if shm else "cuda"  # (gloo carries the rendezvous data of the shm transport: RCCL refuses two ranks on one GPU)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
-        buf = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        dist.init_process_group("gloo" if shm else "nccl", rank=rank, world_size=world)
+        buf = torch.zeros(128, dtype=torch.uint8, device=ddev)
         if rank == 0:
             cid = ctypes.create_string_buffer(128)
-            _lib.check(_lib.load().lgh_comm_unique_id(cid))
+            _lib.check(_lib.load().lgh_comm_unique_id_shm(cid) if shm else _lib.load().lgh_comm_unique_id(cid))
             buf.copy_(torch.tensor(list(cid.raw), dtype=torch.uint8))
         dist.broadcast(buf, 0)
         nccl_id = bytes(buf.cpu().tolist())
 
-    px, py, pz = block_grid(world)
+    B = a.block
+    px, py, pz = block_grid(world, B)
     if world == 1:
         args, workload = WORKLOADS[a.workload]
         args = list(args)
     else:
-        args = ["-dim", 3, "-nx", 32 * px, "-ny", 32 * py, "-nz", 32 * pz, "-Sx", px, "-Sy", py, "-Sz", pz,
+        args = ["-dim", 3, "-nx", B * px, "-ny", B * py, "-nz", B * pz, "-Sx", px, "-Sy", py, "-Sz", pz,
                 "-rs", 0, "-p", 1]
-        workload = ("3D Sedov -p 1 Cartesian %dx%dx%d elements (32^3 per GPU, h = 1/32), -ok 3 -ot 2 -pa"
-                    % (32 * px, 32 * py, 32 * pz))
+        workload = ("3D Sedov -p 1 Cartesian %dx%dx%d elements (%d^3 per GPU, h = 1/%d), -ok 3 -ot 2 -pa"
+                    % (B * px, B * py, B * pz, B, B))
     common = ["-ok", 3, "-ot", 2, "-pa", "-tf", 1e9, "-ms", a.warmup + a.steps + 64, "-vs", 10 ** 9]
     sim = host_lib.Sim(args + common + ["-dev", local_rank, "-q"], nranks=world, rank=rank, nccl_id=nccl_id)
     flush_c_stdio()  # RCCL's banner (C stdio) out now, on every rank, not at process exit after the JSON line
@@ -514,7 +523,7 @@ def main():
     if world > 1:
         # the library's own process grid and per-rank block: what the line reports must be what ran
         assert tuple(sz["pgrid"]) == (px, py, pz), (sz["pgrid"], (px, py, pz))
-        assert tuple(sz["local_ne"]) == (32, 32, 32), sz["local_ne"]
+        assert tuple(sz["local_ne"]) == (B, B, B), sz["local_ne"]
 
     def barrier():
         sim.sync()
@@ -556,7 +565,7 @@ def main():
     barrier()
     wall = time.perf_counter() - t0
     if dist is not None:
-        w = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        w = torch.tensor([wall], dtype=torch.float64, device=ddev)
         dist.all_reduce(w, op=dist.ReduceOp.MAX)
         wall = float(w.item())
     rk_steps = sim.rk_steps - rk0
@@ -569,7 +578,9 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
         # no dataset: the state the kernels run on is the live flow evolved from the problem's initial condition
         "data": "synthetic (live Sedov state evolved from the analytic initial condition; no dataset)",
-        "config": {"workload": workload, "elements": sz["global_NE"], "h1_dofs": sz["H1GTV"],
+        "config": {"workload": workload, "transport": ("shm: cross-process loopback through shared memory, ranks share GPUs (NOT the product transport; "
+                                                        "exercises the N-rank code path only)" if shm else "rccl") if world > 1 else "none (one rank)",
+                   "elements": sz["global_NE"], "h1_dofs": sz["H1GTV"],
                    "l2_dofs": sz["L2GTV"], "quad_points_per_element": sz["NQ"], "rk_stages_executed": 4 * rk_steps,
                    "ode": "RK4", "cg_rel_tol": 1e-8, "parallelism": "elements%dx%dx%d" % tuple(sz["pgrid"]),
                    "zones_per_gpu": "%dx%dx%d" % tuple(sz["local_ne"]),

@@ -278,6 +278,10 @@ int lgh_k1_form(lgh_ctx *ctx, int *form);
  * sides (global lexicographic order). */
 int lgh_comm_unique_id(char id_out[128]);
 int lgh_comm_init(lgh_ctx *ctx, int nranks, int rank, const char unique_id[128]);
+/* An id for the cross-process loopback transport instead of RCCL (tests, `bench.py --transport shm`): the ranks are
+ * processes as on a node, but may share one GPU (RCCL refuses that); exchanges are staged through a POSIX
+ * shared-memory segment named by the id.  Everything above the transport is the code a multi-GPU node runs. */
+int lgh_comm_unique_id_shm(char id_out[128]);
 int lgh_comm_set_neighbors(lgh_ctx *ctx, int n_nbr, const int *nbr_rank, const int *nbr_count,
                            const int *const *nbr_nodes);
 /* What the exchanges of this rank look like (bench.py's `comm` block): neighbours, nodes of the largest message,

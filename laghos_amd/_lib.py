@@ -97,6 +97,7 @@ SYMBOLS = {
     "lgh_quadrature_generation": (_I, [_P, ctypes.POINTER(ctypes.c_ulong), c_int_p, c_int_p]),
     "lgh_get_fused_forces": (_I, [_P, c_int_p, c_int_p]),
     "lgh_comm_unique_id": (_I, [ctypes.c_char_p]),
+    "lgh_comm_unique_id_shm": (_I, [ctypes.c_char_p]),
     "lgh_comm_init": (_I, [_P, _I, _I, ctypes.c_char_p]),
     "lgh_comm_set_neighbors": (_I, [_P, _I, c_int_p, c_int_p, ctypes.POINTER(c_int_p)]),
     "lgh_groups_to_neighbors": (_I, [_I, _I, _I, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p, c_dbl_p, c_int_p, c_int_p,

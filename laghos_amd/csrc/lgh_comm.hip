@@ -14,10 +14,15 @@
 // RCCL is resolved with dlopen at lgh_comm_init time so that the same library
 // loads on a host without RCCL (and reuses torch's copy when already loaded).
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <cstdlib>
 #include <cmath>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <map>
@@ -139,6 +144,132 @@ struct LocalGroup
 static std::mutex g_local_m;
 static std::map<std::string, std::shared_ptr<LocalGroup>> g_local;
 
+// ---- cross-process loopback communicator (test vehicle, bench.py --transport shm) ---------------
+// A unique id that starts with "LGHSHM" names a POSIX shared-memory segment: the ranks are PROCESSES (what torchrun
+// starts: one per rank, as on a multi-GPU node) that may all sit on one GPU - RCCL refuses two ranks on one device, so
+// the one-GPU box cannot run the product transport with N > 1.  The exchanges are staged through the segment (device ->
+// segment -> device) between process-shared barriers with a time-out.  Everything above the transport - torchrun
+// rendezvous, broadcast of the id, lgh_comm_init / lgh_comm_set_neighbors, partition, owner masks, pack / canonical
+// combine, piggy-backed sums, the sequencing of the solves, bench.py's rank-0 line - is the code a node runs.
+// Not a product path: RCCL over xGMI is.
+struct ShmHeader
+{
+   std::atomic<unsigned> magic;    // kShmMagic once rank 0 has initialised the segment
+   std::atomic<int> arrived;       // sense-reversing barrier
+   std::atomic<int> gen;
+   std::atomic<int> broken;
+   int nranks;
+   size_t cap;                     // bytes of message area per rank and channel
+   size_t off_slots, off_tables, off_msg;
+};
+constexpr unsigned kShmMagic = 0x4C474853u; // "LGHS"
+static std::chrono::seconds shm_timeout() // how long a rank waits for its peers (LGH_SHM_TIMEOUT seconds, default 120)
+{
+   const char *e = getenv("LGH_SHM_TIMEOUT");
+   return std::chrono::seconds((e && atoi(e) > 0) ? atoi(e) : 120);
+}
+constexpr int kShmMaxNbr = 32;
+struct ShmTable // what a rank publishes about its send buffer: where the block of each neighbour starts
+{
+   int n_nbr;
+   int nbr_rank[kShmMaxNbr], nbr_base[kShmMaxNbr], nbr_count[kShmMaxNbr];
+};
+struct ShmGroup
+{
+   std::string name;
+   void *base = nullptr;
+   size_t bytes = 0;
+   int n = 0, rank = 0;
+   ShmHeader *hdr() const { return (ShmHeader *)base; }
+   double *slots(int r) const { return (double *)((char *)base + hdr()->off_slots) + (size_t)r * 8; }
+   ShmTable *table(int r) const { return (ShmTable *)((char *)base + hdr()->off_tables) + r; }
+   double *msg(int r, int ch) const { return (double *)((char *)base + hdr()->off_msg + ((size_t)r * 2 + ch) * hdr()->cap); }
+   bool barrier()
+   {
+      ShmHeader *h = hdr();
+      if (h->broken.load()) { return false; }
+      const int g = h->gen.load();
+      if (h->arrived.fetch_add(1) + 1 == n)
+      {
+         h->arrived.store(0);
+         h->gen.fetch_add(1);
+         return true;
+      }
+      const auto t0 = std::chrono::steady_clock::now();
+      long spins = 0;
+      while (h->gen.load() == g)
+      {
+         if (h->broken.load()) { return false; }
+         if ((++spins & 1023) == 0)
+         {
+            // a rank that never arrives (diverged control flow, dead process) must fail the run, not hang it
+            if (std::chrono::steady_clock::now() - t0 > shm_timeout()) { h->broken.store(1); return false; }
+            usleep(50);
+         }
+      }
+      return !h->broken.load();
+   }
+   ~ShmGroup()
+   {
+      if (base) { munmap(base, bytes); }
+      if (rank == 0 && !name.empty()) { shm_unlink(name.c_str()); }
+   }
+};
+static int shm_open_group(const char unique_id[128], int nranks, int rank, std::shared_ptr<ShmGroup> &out)
+{
+   auto g = std::make_shared<ShmGroup>();
+   g->name = std::string("/") + std::string(unique_id, strnlen(unique_id, 64));
+   g->n = nranks;
+   g->rank = rank;
+   const char *menv = getenv("LGH_SHM_MB"); // message area per rank and channel (a 32^3 Q3Q2 block sends 1.4 MB per exchange)
+   const size_t cap = (size_t)std::max(1, menv ? atoi(menv) : 16) << 20;
+   const size_t off_slots = 4096, off_tables = off_slots + ((size_t)nranks * 8 * sizeof(double) + 4095) / 4096 * 4096;
+   const size_t off_msg = off_tables + ((size_t)nranks * sizeof(ShmTable) + 4095) / 4096 * 4096;
+   g->bytes = off_msg + (size_t)nranks * 2 * cap;
+   int fd = -1;
+   if (rank == 0)
+   {
+      shm_unlink(g->name.c_str());
+      fd = shm_open(g->name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+      if (fd < 0 || ftruncate(fd, (off_t)g->bytes) != 0) { set_error("shm transport: cannot create %s", g->name.c_str()); if (fd >= 0) { close(fd); } return LGH_ERR_COMM; }
+   }
+   else
+   {
+      const auto t0 = std::chrono::steady_clock::now();
+      while (true)
+      {
+         fd = shm_open(g->name.c_str(), O_RDWR, 0600);
+         struct stat st;
+         if (fd >= 0 && fstat(fd, &st) == 0 && (size_t)st.st_size >= g->bytes) { break; }
+         if (fd >= 0) { close(fd); fd = -1; }
+         if (std::chrono::steady_clock::now() - t0 > shm_timeout()) { set_error("shm transport: %s did not appear (rank 0 missing?)", g->name.c_str()); return LGH_ERR_COMM; }
+         usleep(2000);
+      }
+   }
+   g->base = mmap(nullptr, g->bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+   close(fd);
+   if (g->base == MAP_FAILED) { g->base = nullptr; set_error("shm transport: mmap failed"); return LGH_ERR_COMM; }
+   ShmHeader *h = g->hdr();
+   if (rank == 0)
+   {
+      h->arrived.store(0); h->gen.store(0); h->broken.store(0);
+      h->nranks = nranks; h->cap = cap; h->off_slots = off_slots; h->off_tables = off_tables; h->off_msg = off_msg;
+      h->magic.store(kShmMagic);
+   }
+   else
+   {
+      const auto t0 = std::chrono::steady_clock::now();
+      while (h->magic.load() != kShmMagic)
+      {
+         if (std::chrono::steady_clock::now() - t0 > shm_timeout()) { set_error("shm transport: segment never initialised"); return LGH_ERR_COMM; }
+         usleep(1000);
+      }
+      if (h->nranks != nranks) { set_error("shm transport: segment is for %d ranks, not %d", h->nranks, nranks); return LGH_ERR_COMM; }
+   }
+   out = g;
+   return LGH_OK;
+}
+
 struct Comm
 {
    ncclComm_t comm = nullptr;
@@ -149,6 +280,8 @@ struct Comm
    bool channel2 = false;
    double *sendbuf2 = nullptr, *recvbuf2 = nullptr;
    std::shared_ptr<LocalGroup> local;
+   std::shared_ptr<ShmGroup> shm;
+   std::vector<double> stage; // shm transport: host staging of one receive buffer
    int n_nbr = 0;
    std::vector<int> nbr_rank, nbr_count, nbr_off, nbr_base; // node offsets / buffer bases of the neighbours
    int total = 0;        // sum of nbr_count
@@ -293,6 +426,33 @@ int halo_sum(lgh_ctx *c, double *v, int ncomp, double *extra, int nextra, bool p
       LGH_HIP_CHECK(hipGetLastError());
       return LGH_OK;
    }
+   if (cm->shm)
+   {
+      ShmGroup *g = cm->shm.get();
+      const int ch = ch2 ? 1 : 0;
+      if ((size_t)cm->bufsize * sizeof(double) > g->hdr()->cap) { set_error("shm transport: message of %zu bytes, room for %zu (LGH_SHM_MB)", (size_t)cm->bufsize * sizeof(double), g->hdr()->cap); return LGH_ERR_COMM; }
+      LGH_HIP_CHECK(hipStreamSynchronize(c->stream)); // my send buffer is packed
+      LGH_HIP_CHECK(hipMemcpy(g->msg(c->rank, ch), sbuf, (size_t)cm->bufsize * sizeof(double), hipMemcpyDeviceToHost));
+      if (!g->barrier()) { set_error("shm transport: barrier timed out (halo): a rank is missing or the ranks do not call the same exchanges"); return LGH_ERR_COMM; }
+      cm->stage.resize((size_t)cm->bufsize);
+      for (int k = 0; k < cm->n_nbr; k++)
+      {
+         const ShmTable *pt = g->table(cm->nbr_rank[k]);
+         int kk = -1;
+         for (int j = 0; j < pt->n_nbr; j++) { if (pt->nbr_rank[j] == c->rank) { kk = j; } }
+         if (kk < 0 || pt->nbr_count[kk] != cm->nbr_count[k])
+         {
+            set_error("shm transport: neighbour lists of ranks %d and %d do not match", c->rank, cm->nbr_rank[k]);
+            return LGH_ERR_COMM;
+         }
+         memcpy(cm->stage.data() + cm->nbr_base[k], g->msg(cm->nbr_rank[k], ch) + pt->nbr_base[kk], ((size_t)ncomp * cm->nbr_count[k] + nx) * sizeof(double));
+      }
+      LGH_HIP_CHECK(hipMemcpy(rbuf, cm->stage.data(), (size_t)cm->bufsize * sizeof(double), hipMemcpyHostToDevice));
+      if (!g->barrier()) { set_error("shm transport: barrier timed out (halo)"); return LGH_ERR_COMM; } // peers may repack
+      combine();
+      LGH_HIP_CHECK(hipGetLastError());
+      return LGH_OK;
+   }
    LGH_NCCL_CHECK(g_nccl.GroupStart());
    for (int k = 0; k < cm->n_nbr; k++)
    {
@@ -365,6 +525,25 @@ int allreduce_dev(lgh_ctx *c, double *dev, int count, int op, bool packed)
       LGH_HIP_CHECK(hipMemcpy(dev, res, count * sizeof(double), hipMemcpyHostToDevice));
       return LGH_OK;
    }
+   if (cm && cm->shm)
+   {
+      ShmGroup *g = cm->shm.get();
+      if (count > 8) { set_error("shm transport: count > 8"); return LGH_ERR_ARG; }
+      double mine[8], res[8];
+      LGH_HIP_CHECK(hipStreamSynchronize(c->stream));
+      LGH_HIP_CHECK(hipMemcpy(mine, dev, count * sizeof(double), hipMemcpyDeviceToHost));
+      for (int i = 0; i < count; i++) { g->slots(c->rank)[i] = mine[i]; }
+      if (!g->barrier()) { set_error("shm transport: barrier timed out (all-reduce)"); return LGH_ERR_COMM; }
+      for (int i = 0; i < count; i++)
+      {
+         double r = g->slots(0)[i];
+         for (int k = 1; k < g->n; k++) { const double x = g->slots(k)[i]; r = (op == 0) ? r + x : std::min(r, x); } // rank order: identical on every rank
+         res[i] = r;
+      }
+      if (!g->barrier()) { set_error("shm transport: barrier timed out (all-reduce)"); return LGH_ERR_COMM; }
+      LGH_HIP_CHECK(hipMemcpy(dev, res, count * sizeof(double), hipMemcpyHostToDevice));
+      return LGH_OK;
+   }
    if (!cm || !cm->comm) { return LGH_OK; }
    if (c->on_stream2 && !cm->comm2) { set_error("all-reduce on the second stream without a second communicator"); return LGH_ERR_COMM; }
    kt_begin(c, LGH_KERNEL_ALLREDUCE);
@@ -400,6 +579,7 @@ void lgh_comm_free(lgh_ctx *c)
          else { ++it; }
       }
    }
+   cm->shm.reset();
    if (cm->comm2 && g_nccl.CommDestroy) { g_nccl.CommDestroy(cm->comm2); }
    if (cm->comm && g_nccl.CommDestroy) { g_nccl.CommDestroy(cm->comm); }
    void *ptrs[] = {cm->nodes, cm->sendbuf, cm->recvbuf, cm->sendbuf2, cm->recvbuf2, cm->sh_node, cm->sh_off, cm->sh_src, cm->pos, cm->cnt, cm->hmask,
@@ -420,9 +600,32 @@ int lgh_comm_unique_id(char id_out[128])
    return LGH_OK;
 }
 
+int lgh_comm_unique_id_shm(char id_out[128])
+{
+   LGH_CHECK_ARG(id_out);
+   memset(id_out, 0, 128);
+   unsigned long long r = (unsigned long long)getpid() * 0x9E3779B97F4A7C15ull ^ (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count();
+   snprintf(id_out, 64, "LGHSHM_%d_%016llx", (int)getpid(), r);
+   return LGH_OK;
+}
+
 int lgh_comm_init(lgh_ctx *c, int nranks, int rank, const char unique_id[128])
 {
    LGH_CHECK_ARG(c && nranks >= 1 && rank >= 0 && rank < nranks && unique_id);
+   if (memcmp(unique_id, "LGHSHM", 6) == 0) // cross-process loopback communicator (bench.py --transport shm, tests)
+   {
+      if (!c->comm) { c->comm = new Comm(); }
+      int rc = shm_open_group(unique_id, nranks, rank, c->comm->shm);
+      if (rc) { return rc; }
+      // (the exchanges are synchronous on the host: the energy solve's sums may use the second channel's buffers safely)
+      c->comm->channel2 = !(getenv("LGH_COMM2") && getenv("LGH_COMM2")[0] == '0');
+      c->nranks = nranks;
+      c->rank = rank;
+      c->multi = 1;
+      vcg_free(c);
+      if (!c->comm->shm->barrier()) { set_error("shm transport: not all %d ranks arrived", nranks); return LGH_ERR_COMM; }
+      return LGH_OK;
+   }
    if (memcmp(unique_id, "LGHLOCAL", 8) == 0) // in-process loopback communicator (tests)
    {
       if (!c->comm) { c->comm = new Comm(); }
@@ -650,7 +853,14 @@ int lgh_comm_set_neighbors(lgh_ctx *c, int n_nbr, const int *nbr_rank, const int
    }();
    // the message sizes depend on it: every rank must come to the same decision (in a 3x1x1 partition
    // only the middle rank sees all others); a local failure travels in the same MIN-reduction
-   if (c->multi != 0 && (cm->comm || cm->local))
+   if (cm->shm)
+   {
+      if (n_nbr > kShmMaxNbr) { set_error("shm transport: more than %d neighbours", kShmMaxNbr); return LGH_ERR_ARG; }
+      ShmTable *t = cm->shm->table(c->rank);
+      t->n_nbr = rc_local ? 0 : n_nbr;
+      for (int k = 0; k < t->n_nbr; k++) { t->nbr_rank[k] = cm->nbr_rank[k]; t->nbr_base[k] = cm->nbr_base[k]; t->nbr_count[k] = cm->nbr_count[k]; }
+   }
+   if (c->multi != 0 && (cm->comm || cm->local || cm->shm))
    {
       double flag = rc_local ? -1.0 : (cm->allpairs ? 1.0 : 0.0);
       const int rc = lgh_allreduce(c, &flag, 1);

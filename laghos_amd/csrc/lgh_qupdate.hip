@@ -1,6 +1,7 @@
 // lgh_qupdate.hip — the update and energy-integral modes of the quadrature-point kernel (lgh_qpoint.hpp), the 2D
 // Taylor-Green source and the small-matrix probes.  This file is compiled with the relaxed fp64 division (Makefile).
 #include "lgh_qpoint.hpp"
+#include "lgh_qrows.hpp"
 
 namespace lgh
 {
@@ -12,7 +13,10 @@ int qupdate(lgh_ctx *c, const double *S)
    a.v = S + c->H1V;
    a.e = S + 2 * (size_t)c->H1V;
    a.result = c->dt_est_dev;
-   const int rc = launch_q<QMODE_UPDATE>(c, a);
+   // 3D up to Q4Q3: the form with row-owned contraction stages (lgh_qrows.hpp); LGH_Q_FORM=0: the point form (A/B, tests)
+   const char *fenv = getenv("LGH_Q_FORM");
+   const bool rows = qrows_available(c) && !(fenv && fenv[0] == '0');
+   const int rc = rows ? launch_qrows(c, a) : launch_q<QMODE_UPDATE>(c, a);
    // F^T v of this state's velocity block is now in c->erhs_q, F.1 in c->force_e_q; lgh_solve_energy compares the
    // velocity it is given with the one the product was formed from
    c->qgen++;

@@ -821,6 +821,9 @@ KERNEL_SWITCHES = [
     ((5, 4), {"LGH_MASS_SEP": "0"}, "tol"),
     ((5, 4), {"LGH_MASS_RANK1": "0"}, "tol"),
     ((5, 4), {"LGH_Q_PPT": "1"}, "tol"),
+    ((3, 2), {"LGH_Q_FORM": "0"}, "tol"),   # the point form of the quadrature update instead of the row form (lgh_qrows.hpp)
+    ((4, 3), {"LGH_Q_FORM": "0"}, "tol"),
+    ((3, 2), {"LGH_Q_FORM": "0", "LGH_FUSED_FTV": "0", "LGH_FUSED_F1": "0"}, "tol"),
     ((4, 3), {"LGH_L2_PLANE": "0"}, "tol"),
     ((4, 3), {"LGH_K2P": "0"}, "tol"),
 ]
