@@ -48,6 +48,7 @@ struct QArgs
    int visc, vort;
    double *force_e;  // update mode (3D): F.1 as E-vector (D1D^3, dim, NE), or nullptr (see below)
    double *erhs_q;   // update mode: F^T v of the SAME state (the velocity block of S), L2 vector, or nullptr (see below)
+   int q_swz;        // row form of the update (lgh_qrows.hpp): element -> XCD mapping
    double tiny_grad; // wave-uniform shortcut of the eigen-decomposition below this |sym grad v| (see qpoint_body); < 0: off
 };
 
@@ -875,6 +876,10 @@ static QArgs q_base(lgh_ctx *c)
    a.visc = c->visc;
    a.vort = c->vort;
    a.tiny_grad = c->q_tiny_grad;
+   {
+      const char *senv = getenv("LGH_Q_SWZ"); // A/B: -1 contiguous eighths, 0 none, n: runs of 2^n elements
+      a.q_swz = senv ? atoi(senv) : -1;
+   }
    a.erhs_q = c->fused_forces_off ? nullptr : c->erhs_q;
    a.force_e = (c->dim == 3 && !c->fused_forces_off) ? c->force_e_q : nullptr;
    return a;

@@ -27,6 +27,9 @@
 // consecutive index sit on different XCDs, i.e. behind different L2s (profiles/r3_pmc_traffic.json: 1.30 x the
 // algorithmic bytes fetched by the unswizzled kernel).
 #include "lgh_qpoint.hpp"
+#ifndef LGH_QR_WAVES
+#define LGH_QR_WAVES 3
+#endif
 
 namespace lgh
 {
@@ -76,8 +79,10 @@ template <int N> __device__ __forceinline__ void row_load(const double *__restri
    for (int i = 0; i < N; i++) { v[i] = p[i]; }
 }
 
+// (second launch bound = wavefronts per SIMD the register allocation must leave room for: the pipelined loop otherwise
+//  settles at ~250 registers, i.e. two wavefronts per SIMD at Q3Q2 where the LDS slice admits three workgroups per CU)
 template <int D, int Q, int L>
-__global__ void __launch_bounds__(Q *Q *Q)
+__global__ void __launch_bounds__(Q *Q *Q, (Q == 6) ? LGH_QR_WAVES : ((Q == 8) ? 2 : 1))
 qrows_kernel(const QArgs a)
 {
    using S = QRows<D, Q, L>;
@@ -100,52 +105,109 @@ qrows_kernel(const QArgs a)
    double *const sE1 = sE + NL;                  // [lz][ly][qx]   (F^T v: [lz][ly][qx] again, on the way back)
    double *const sE2 = sE1 + L * L * Q;          // [lz][qy][qx]
 
-   const int lt = threadIdx.x;
-   const int tx = lt % Q, ty = (lt / Q) % Q, tz = lt / QQ;
-   // element of this workgroup: workgroup b runs on XCD b % 8 (observed); swz = log2 of the run of consecutive elements
-   // that stay on one XCD (runs are dealt to the XCDs in turn); swz < 0: one contiguous eighth of the mesh per XCD
-   int e = blockIdx.x;
-   if (a.q_swz < 0) { e = xcd_swizzle(blockIdx.x, gridDim.x); }
-   else if (a.q_swz > 0)
-   {
-      const int R = 1 << a.q_swz, span = 8 * R, b = blockIdx.x;
-      if (b < (int)(gridDim.x / span) * span) { e = (b / span) * span + (b & 7) * R + ((b >> 3) & (R - 1)); }
-   }
-   const size_t eq = (size_t)e * NQ + lt;
+   const int lt0 = threadIdx.x;
    const size_t plane = (size_t)a.NE * NQ;
+   const int G = gridDim.x;
 
-   // ---- P0: tables (q-major), gathers, point data: every global read of the element before the first barrier
-   for (int i = lt; i < Q * D; i += NT)
+   // ---- tables (q-major), once per workgroup
+   for (int i = lt0; i < Q * D; i += NT)
    {
       const int q = i / D, d = i - q * D;
       sTB[i] = a.B[q + Q * d];
       sTG[i] = a.G[q + Q * d];
    }
-   for (int i = lt; i < Q * L; i += NT)
+   for (int i = lt0; i < Q * L; i += NT)
    {
       const int q = i / L, l = i - q * L;
       sTL[i] = a.Bl[q + Q * l];
    }
-   for (int i = lt; i < 3 * ND; i += NT)
-   {
-      const int c = i / ND, d = i - c * ND;
-      const size_t n = (size_t)c * a.N + a.map[(size_t)e * ND + d];
-      sU[i] = a.x[n];
-      sU[i + 3 * ND] = a.v[n];
-   }
-   for (int i = lt; i < NL; i += NT) { sE[i] = a.e[(size_t)e * NL + i]; }
-   double J0i[9];
+   const double weight = a.W[lt0];
+
+   // ---- software pipeline over the elements of this workgroup (virtual block vb = blockIdx + G j, element =
+   // xcd_swizzle(vb): the workgroups resident on one XCD sweep one contiguous eighth of the mesh side by side).
+   // A workgroup of the one-element-per-launch form spent a quarter of its life waiting for its first loads (map ->
+   // gathers: two dependent trips, then the point data) with only two other workgroups on the CU to cover for it.
+   // Here the loads of element j+1 are in flight while element j is computed: its node map is read one element
+   // ahead of its gathers (issued behind the first barrier of j), the point data (Jac0inv, rho0DetJ0w) after the
+   // body of j, where the register pressure has dropped again.
+   constexpr int GPT = (3 * ND + NT - 1) / NT; // gather items per thread (x and v share the node index)
+   constexpr int EPT = (NL + NT - 1) / NT;
+   int mi[GPT];
+   double gx[GPT], gv[GPT], ge[EPT], J0i[9], rdw;
+   auto load_map = [&](const int el) {
 #pragma unroll
-   for (int k = 0; k < 9; k++) { J0i[k] = a.Jac0inv_soa[eq + plane * k]; }
-   const double rdw = a.rho0DetJ0w_in[eq];
-   const double weight = a.W[lt];
+      for (int k = 0; k < GPT; k++)
+      {
+         const int i = lt0 + k * NT;
+         mi[k] = (i < 3 * ND) ? a.map[(size_t)el * ND + (i % ND)] : 0;
+      }
+   };
+   auto load_gather = [&](const int el) {
+#pragma unroll
+      for (int k = 0; k < GPT; k++)
+      {
+         const int i = lt0 + k * NT;
+         const size_t n = (size_t)((i < 3 * ND) ? i / ND : 0) * a.N + mi[k];
+         gx[k] = a.x[n];
+         gv[k] = a.v[n];
+      }
+#pragma unroll
+      for (int k = 0; k < EPT; k++)
+      {
+         const int i = lt0 + k * NT;
+         ge[k] = a.e[(size_t)el * NL + ((i < NL) ? i : 0)];
+      }
+   };
+   auto load_point = [&](const int el) {
+      const size_t q = (size_t)el * NQ + lt0;
+#pragma unroll
+      for (int k = 0; k < 9; k++) { J0i[k] = a.Jac0inv_soa[q + plane * k]; }
+      rdw = a.rho0DetJ0w_in[q];
+   };
+   int vb = blockIdx.x;
+   int e = xcd_swizzle(vb, a.NE);
+   load_map(e);
+   load_gather(e);
+   load_point(e);
+   if (vb + G < a.NE) { load_map(xcd_swizzle(vb + G, a.NE)); }
+   double cand = INFINITY;
+   const bool do_f = (a.force_e != nullptr), do_t = (a.erhs_q != nullptr);
+
+   for (; vb < a.NE; vb += G)
+   {
+   const int e_next = (vb + G < a.NE) ? xcd_swizzle(vb + G, a.NE) : -1;
+   // (the tables are the same for every element: without this the compiler hoists the table loads of every stage out
+   //  of the element loop and carries ~90 more registers through the body - 2 instead of 3 wavefronts per SIMD)
+   int opq = 0, lt = lt0;
+   asm volatile("" : "+v"(opq), "+v"(lt)); // (likewise the per-stage index arithmetic on the thread index: recomputed, not carried)
+   const int tx = lt % Q, ty = (lt / Q) % Q, tz = lt / QQ;
+   const double *const tB = sTB + opq, *const tL = sTL + opq;
+   const size_t eq = (size_t)e * NQ + lt;
+   // ---- P0: the gathered fields of this element to LDS; the next element's gathers go out behind the barrier
+#pragma unroll
+   for (int k = 0; k < GPT; k++)
+   {
+      const int i = lt + k * NT;
+      if (i < 3 * ND) { sU[i] = gx[k]; sU[i + 3 * ND] = gv[k]; }
+   }
+#pragma unroll
+   for (int k = 0; k < EPT; k++)
+   {
+      const int i = lt + k * NT;
+      if (i < NL) { sE[i] = ge[k]; }
+   }
    __syncthreads();
+   if (e_next >= 0)
+   {
+      load_gather(e_next);
+      if (vb + 2 * G < a.NE) { load_map(xcd_swizzle(vb + 2 * G, a.NE)); }
+   }
 
    // ---- P1: X stage, rows (which, f, dz, dy); the L2 field's x stage on the last threads
    for (int i = lt; i < 2 * NF * DD; i += NT)
    {
       const int which = i / (NF * DD), r = i - which * (NF * DD); // r = dy + D*(dz + D*f)
-      const double *T = sTB + which * (Q * D); // (one address, not a select between two loaded tables)
+      const double *T = tB + which * (Q * D); // (one address, not a select between two loaded tables)
       double u[D], o[Q];
       row_load<D>(sU + D * r, u);
       row_fwd<D, Q>(T, u, o);
@@ -160,7 +222,7 @@ qrows_kernel(const QArgs a)
       {
          double u[L], o[Q];
          row_load<L>(sE + L * j, u);
-         row_fwd<L, Q>(sTL, u, o);
+         row_fwd<L, Q>(tL, u, o);
 #pragma unroll
          for (int q = 0; q < Q; q++) { sE1[j * Q + q] = o[q]; }
       }
@@ -171,7 +233,7 @@ qrows_kernel(const QArgs a)
    for (int i = lt; i < 3 * NF * Q * D; i += NT)
    {
       const int part = i / (NF * Q * D), r = i - part * (NF * Q * D); // r = dz + D*(qx + Q*f)
-      const double *T = sTB + ((part == 1) ? Q * D : 0);
+      const double *T = tB + ((part == 1) ? Q * D : 0);
       double u[D], o[Q];
       row_load<D>(sX + (part == 0 ? S::SX : 0) + D * r, u);
       row_fwd<D, Q>(T, u, o);
@@ -188,7 +250,7 @@ qrows_kernel(const QArgs a)
          double u[L], o[Q];
 #pragma unroll
          for (int ly = 0; ly < L; ly++) { u[ly] = sE1[(lz * L + ly) * Q + qx]; }
-         row_fwd<L, Q>(sTL, u, o);
+         row_fwd<L, Q>(tL, u, o);
 #pragma unroll
          for (int q = 0; q < Q; q++) { sE2[(lz * Q + q) * Q + qx] = o[q]; }
       }
@@ -199,8 +261,8 @@ qrows_kernel(const QArgs a)
    double J[9], dV[9], e_val = 0.0;
    {
       double tb[D], tg[D];
-      row_load<D>(sTB + D * tz, tb);
-      row_load<D>(sTG + D * tz, tg);
+      row_load<D>(tB + D * tz, tb);
+      row_load<D>(tB + Q * D + D * tz, tg);
       const double *col = sY + (ty * Q + tx) * D;
 #pragma unroll
       for (int f = 0; f < NF; f++)
@@ -225,12 +287,12 @@ qrows_kernel(const QArgs a)
          M[c + 6] = d2;
       }
 #pragma unroll
-      for (int lz = 0; lz < L; lz++) { e_val = fma(sTL[tz * L + lz], sE2[(lz * Q + ty) * Q + tx], e_val); }
+      for (int lz = 0; lz < L; lz++) { e_val = fma(tL[tz * L + lz], sE2[(lz * Q + ty) * Q + tx], e_val); }
    }
    double ftv = 0.0, sjw[9];
-   const double cand = qpoint_body<3>(a, e, eq, weight, J, dV, e_val, plane, J0i, rdw, ftv, sjw);
+   cand = fmin(cand, qpoint_body<3>(a, e, eq, weight, J, dV, e_val, plane, J0i, rdw, ftv, sjw));
+   if (e_next >= 0) { load_point(e_next); } // (the body is done with this element's point data: same registers)
 
-   const bool do_f = (a.force_e != nullptr), do_t = (a.erhs_q != nullptr);
    if (do_f || do_t)
    {
       // the x-contracted arrays are dead since the barrier above: the stress goes straight to its place
@@ -249,7 +311,7 @@ qrows_kernel(const QArgs a)
          for (int i = lt; i < 9 * QQ; i += NT)
          {
             const int k = i / QQ, r = i - k * QQ; // r = qx + Q*qy
-            const double *T = sTB + (((k % 3) == 2) ? Q * D : 0);
+            const double *T = tB + (((k % 3) == 2) ? Q * D : 0);
             double u[Q], o[D];
             row_load<Q>(sF + (size_t)i * Q, u);
             row_bwd<Q, D>(T, u, o);
@@ -266,7 +328,7 @@ qrows_kernel(const QArgs a)
          {
             double u[Q], o[L];
             row_load<Q>(sS + j * Q, u);
-            row_bwd<Q, L>(sTL, u, o);
+            row_bwd<Q, L>(tL, u, o);
 #pragma unroll
             for (int l = 0; l < L; l++) { sE2[l * QQ + j] = o[l]; } // [lz][qy][qx]
          }
@@ -279,7 +341,7 @@ qrows_kernel(const QArgs a)
          for (int i = lt; i < 9 * D * Q; i += NT)
          {
             const int k = i / (D * Q);
-            const double *T = sTB + (((k % 3) == 1) ? Q * D : 0);
+            const double *T = tB + (((k % 3) == 1) ? Q * D : 0);
             double u[Q], o[D];
             row_load<Q>(sA + (size_t)i * Q, u);
             row_bwd<Q, D>(T, u, o);
@@ -298,7 +360,7 @@ qrows_kernel(const QArgs a)
             double u[Q], o[L];
 #pragma unroll
             for (int qy = 0; qy < Q; qy++) { u[qy] = sE2[(lz * Q + qy) * Q + qx]; }
-            row_bwd<Q, L>(sTL, u, o);
+            row_bwd<Q, L>(tL, u, o);
 #pragma unroll
             for (int l = 0; l < L; l++) { sE1[(lz * L + l) * Q + qx] = o[l]; }
          }
@@ -319,8 +381,9 @@ qrows_kernel(const QArgs a)
             row_load<Q>(sW + ((3 * c + 2) * DD + r) * Q, w2);
 #pragma unroll
             for (int q = 0; q < Q; q++) { w1[q] += w2[q]; }
-            row_bwd<Q, D>(sTG, wg, og);
-            row_bwd<Q, D>(sTB, w1, ob);
+            row_bwd<Q, D>(tB + Q * D, wg, og);
+            __builtin_amdgcn_sched_barrier(0); // (one table in registers at a time: both together are the register peak of the loop)
+            row_bwd<Q, D>(tB, w1, ob);
             double *dst = a.force_e + (size_t)ND * (c + 3 * (size_t)e) + D * r;
 #pragma unroll
             for (int d = 0; d < D; d++)
@@ -338,17 +401,20 @@ qrows_kernel(const QArgs a)
          {
             double u[Q], o[L];
             row_load<Q>(sE1 + j * Q, u);
-            row_bwd<Q, L>(sTL, u, o);
+            row_bwd<Q, L>(tL, u, o);
 #pragma unroll
             for (int l = 0; l < L; l++) { a.erhs_q[(size_t)e * NL + j * L + l] = o[l]; }
          }
       }
    }
+   e = e_next;
+   if (e_next >= 0) { __syncthreads(); } // the last readers of this element's LDS arrays are done before the next P0 writes
+   } // element loop
    const double bmin = block_min(cand, red);
    double total;
    if (grid_min_last_block(bmin, a.partials, a.ticket, red, total))
    {
-      if (lt == 0) { *a.result = fmin(*a.result, total); } // q_dt_est = qdata.dt_est; Min() (:1374, :1406)
+      if (lt0 == 0) { *a.result = fmin(*a.result, total); } // q_dt_est = qdata.dt_est; Min() (:1374, :1406)
    }
 }
 
@@ -363,14 +429,32 @@ static bool qrows_available(const lgh_ctx *c)
    }
    return false;
 }
+template <int D, int Q, int L> static void launch_qrows_t(lgh_ctx *c, const QArgs &a, int &grid_cache)
+{
+   if (grid_cache <= 0)
+   {
+      int per_cu = 0;
+      if (c->ncu <= 0)
+      {
+         hipDeviceProp_t prop;
+         c->ncu = (hipGetDeviceProperties(&prop, c->device) == hipSuccess) ? prop.multiProcessorCount : 256;
+      }
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, qrows_kernel<D, Q, L>, Q * Q * Q, 0) != hipSuccess || per_cu <= 0) { per_cu = 1; }
+      const char *genv = getenv("LGH_Q_GRID"); // A/B: workgroups per CU (0: one workgroup per element, no pipelining across elements)
+      if (genv) { per_cu = atoi(genv) > 0 ? atoi(genv) : (c->NE + c->ncu - 1) / c->ncu; }
+      grid_cache = std::max(8, (per_cu * c->ncu) & ~7); // (a multiple of 8: a workgroup's elements stay on its XCD's eighth)
+   }
+   const int grid = std::min(c->NE, grid_cache);
+   hipLaunchKernelGGL((qrows_kernel<D, Q, L>), dim3(grid), dim3(Q * Q * Q), 0, c->stream, a);
+}
 static int launch_qrows(lgh_ctx *c, const QArgs &a)
 {
    switch (c->kid)
    {
-      case 0x322: hipLaunchKernelGGL((qrows_kernel<2, 2, 1>), dim3(c->NE), dim3(8), 0, c->stream, a); break;
-      case 0x334: hipLaunchKernelGGL((qrows_kernel<3, 4, 2>), dim3(c->NE), dim3(64), 0, c->stream, a); break;
-      case 0x346: hipLaunchKernelGGL((qrows_kernel<4, 6, 3>), dim3(c->NE), dim3(216), 0, c->stream, a); break;
-      case 0x358: hipLaunchKernelGGL((qrows_kernel<5, 8, 4>), dim3(c->NE), dim3(512), 0, c->stream, a); break;
+      case 0x322: launch_qrows_t<2, 2, 1>(c, a, c->q_grid); break;
+      case 0x334: launch_qrows_t<3, 4, 2>(c, a, c->q_grid); break;
+      case 0x346: launch_qrows_t<4, 6, 3>(c, a, c->q_grid); break;
+      case 0x358: launch_qrows_t<5, 8, 4>(c, a, c->q_grid); break;
       default: return unknown_kernel(c->kid);
    }
    LGH_HIP_CHECK(hipGetLastError());
