@@ -310,6 +310,27 @@ static int create_impl(const lgh_config *cfg, lgh_ctx *c, const int kid)
       }
       const char *senv = getenv("LGH_MASS_SEP"); // A/B: 0 = weights from the NQ-entry table
       if (ok && !(senv && senv[0] == '0')) { LGH_TRY(dev_alloc_copy(&c->w1d, w1.data(), (size_t)Q)); }
+      // 1-D mass tiles of the two bases on this rule, M1[i + n j] = sum_q B[q, i] w[q] B[q, j] (long double sums, rounded
+      // once): with compact mass data the element matrices are s_e M1 (x) M1 (x) M1 (lgh_vcg_slab.hip, lgh_mass.hip)
+      const char *kenv = getenv("LGH_MASS_KRON"); // A/B: 0 = always contract through the quadrature points
+      if (c->w1d && !(kenv && kenv[0] == '0'))
+      {
+         auto tile = [&](const double *Bt, const int n, double **out) -> int {
+            std::vector<double> M((size_t)n * n);
+            for (int i = 0; i < n; i++)
+            {
+               for (int j = 0; j < n; j++)
+               {
+                  long double s = 0.0L;
+                  for (int q = 0; q < Q; q++) { s += (long double)Bt[q + Q * i] * (long double)w1[q] * (long double)Bt[q + Q * j]; }
+                  M[(size_t)i + (size_t)n * j] = (double)s;
+               }
+            }
+            return dev_alloc_copy(out, M.data(), M.size());
+         };
+         LGH_TRY(tile(cfg->B_h1, c->D1D, &c->M1h));
+         LGH_TRY(tile(cfg->B_l2, c->L1D, &c->M1l));
+      }
    }
    LGH_TRY(dev_alloc_copy(&c->gamma, cfg->gamma, (size_t)c->NE));
    const size_t nmap = (size_t)c->NE * c->ND;
@@ -411,7 +432,7 @@ int lgh_destroy(lgh_ctx *c)
    if (!c) { return LGH_OK; }
    (void)hipSetDevice(c->device);
    (void)hipStreamSynchronize(c->stream);
-   void *ptrs[] = {c->B, c->G, c->Bl, c->W, c->w1d, c->gamma, c->h1map, c->t_off, c->t_idx, c->t_ell, c->essmask[0],
+   void *ptrs[] = {c->B, c->G, c->Bl, c->W, c->w1d, c->M1h, c->M1l, c->gamma, c->h1map, c->t_off, c->t_idx, c->t_ell, c->essmask[0],
                    c->essmask[1], c->essmask[2], c->ess[0], c->ess[1], c->ess[2], c->owner,
                    c->stressJinvT, c->Jac0inv, c->Jac0inv_soa, c->rho0DetJ0w, c->massD, c->diagV, c->dinvV,
                    c->dt_est_dev, c->erhs_q, c->v_snap, c->dev_flags, c->ones_l2, c->massS, c->ones_ne, c->force_e_q, c->XE, c->YE, c->cg_r, c->cg_z, c->cg_d0, c->cg_d1, c->cg_y,

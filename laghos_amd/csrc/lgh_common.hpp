@@ -115,6 +115,8 @@ struct lgh_ctx
    // the mass kernels then read 8 bytes per element instead of 8 NQ.  -1: not looked at yet (set-up, lgh_mass_D handed
    // out), 0: no (massD as stored), 1: yes (lgh_mass.hip mass_data).  LGH_MASS_RANK1=0 keeps massD.
    double *massS, *ones_ne;
+   double *M1h = nullptr, *M1l = nullptr; // 1-D mass tiles B^T diag(w1d) B of the H1 (D1D x D1D) and L2 (L1D x L1D) bases: the Kronecker form of the
+                                          // mass operators for compact mass data on a tensor-product rule (nullptr: no such rule, or LGH_MASS_KRON=0)
    double *w1d = nullptr;   // one-dimensional weights when the rule is a tensor product, W[qx + Q (qy + Q qz)] = w[qx] w[qy] w[qz] (checked by lgh_create; nullptr otherwise)
    int mass_rank1;
    double *dt_est_dev;   // 1 double: running min of the point-wise estimate

@@ -1727,6 +1727,7 @@ static int vcg_prepare(lgh_ctx *c, double *B, double *X, double rel_tol, VcgPlan
    a.DqFull = c->massD;
    rc = mass_data(c, &a.Dq, &a.dqs, &a.Se);
    a.w1 = (a.dqs == 0) ? c->w1d : nullptr;
+   a.M1 = (a.dqs == 0 && c->w1d) ? c->M1h : nullptr; // (nullptr with LGH_MASS_KRON=0)
    if (rc) { return rc; }
    a.map = c->h1map;
    a.ell = c->t_ell;

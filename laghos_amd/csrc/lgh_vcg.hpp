@@ -185,6 +185,7 @@ struct VcgArgs
    int NE, N;
    const double *B, *Dq;  // Dq: quadrature data of the mass operator, value(q, e) = Dq[q + dqs e] * Se[e] (mass_data, lgh_mass.hip) in the
    const double *Se;      // plane and slab forms of K1; the column and matrix-core forms read DqFull[q + NQ e]
+   const double *M1;      // 1-D mass tile B^T diag(w) B (D1D x D1D) when the mass data is compact AND the rule a tensor product: the Kronecker form of K1 (lgh_vcg_slab.hip), nullptr otherwise
    const double *w1;      // vcg_apply_plane_ho<.., SEP = true>: one-dimensional weights of a tensor-product rule (compact data only), nullptr otherwise
    const double *DqFull;
    int dqs;

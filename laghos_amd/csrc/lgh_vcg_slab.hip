@@ -94,6 +94,39 @@ __device__ __forceinline__ void slab_to_slabs(double (&w)[36])
    }
 }
 
+// The same 4 x 4 block transpose for a slab of 16 values (the Kronecker form of the operator, below): w[4 b + i], block b
+// of four doubles "for lane group b"; afterwards register block sigma of lane group g holds what lane group sigma had for g.
+__device__ __forceinline__ void slab16_to_pairs(double (&w)[16])
+{
+#pragma unroll
+   for (int b0 = 0; b0 < 2; b0++)
+   {
+#pragma unroll
+      for (int i = 0; i < 4; i++) { slab_swap<32>(w[4 * b0 + i], w[4 * (2 + b0) + i]); }
+   }
+#pragma unroll
+   for (int s1 = 0; s1 < 2; s1++)
+   {
+#pragma unroll
+      for (int i = 0; i < 4; i++) { slab_swap<16>(w[4 * (2 * s1) + i], w[4 * (2 * s1 + 1) + i]); }
+   }
+}
+__device__ __forceinline__ void slab16_to_slabs(double (&w)[16])
+{
+#pragma unroll
+   for (int s1 = 0; s1 < 2; s1++)
+   {
+#pragma unroll
+      for (int i = 0; i < 4; i++) { slab_swap<16>(w[4 * (2 * s1) + i], w[4 * (2 * s1 + 1) + i]); }
+   }
+#pragma unroll
+   for (int b0 = 0; b0 < 2; b0++)
+   {
+#pragma unroll
+      for (int i = 0; i < 4; i++) { slab_swap<32>(w[4 * b0 + i], w[4 * (2 + b0) + i]); }
+   }
+}
+
 // The contract of slab_swap and of the two transposes, checked on the device once per process: lane group s fills
 // block b, entry i with 1000 s + 10 b + i (+ 0.5 to use both register halves); after slab_to_pairs lane group g must
 // hold 1000 sigma + 10 g + i in block sigma, after slab_to_slabs the original again.
@@ -145,10 +178,18 @@ static bool slab_swaps_ok(lgh_ctx *c)
    return good;
 }
 
-template <bool SYM, int WPS, int TRACE, bool WIDE, bool EXACT, bool DYN, bool RANK1>
+// KRON (needs RANK1 and a tensor-product rule: a.M1 != nullptr): the element matrix of compact, separable mass data is a
+// Kronecker product, B^T diag(s_e w (x) w (x) w) B = s_e M1 (x) M1 (x) M1 with the 1-D mass tile M1 = B^T diag(w) B
+// (D x D, assembled once by lgh_create).  The pass then contracts x and y with M1 on the slab (2 x 64 FMAs), transposes
+// 16 instead of 36 values over the lane groups, contracts z (64 FMAs) and transposes back: 192 FMAs + 64 lane swaps
+// where the general form has 1 020 + 144, no quadrature-point values at all, and (d, A d) = sum over the element's
+// nodes of d y.  Same operator in exact arithmetic; rounding differs (tests: tests/test_gpu_k1.py, 2e-12 like every
+// compact-data case).  What a pass then costs is its memory instructions: the kernel becomes bandwidth-bound.
+template <bool SYM, int WPS, int TRACE, bool WIDE, bool EXACT, bool DYN, bool RANK1, bool KRON = false>
 __global__ void __launch_bounds__(256 * WPS, WPS)
 vcg_apply_slab346(const VcgArgs a, const int nset)
 {
+   static_assert(!KRON || RANK1, "the Kronecker form needs compact mass data");
    constexpr int D = 4, Q = 6, NQ = Q * Q * Q, ND = D * D * D, QD = Q * D, HB = SYM ? (QD + 1) / 2 : QD;
    constexpr int ES = 5;                     // elements of a set: 15 items on the 16 lanes of a lane group
    constexpr int NW = 4 * WPS;               // wavefronts of the workgroup (one workgroup per CU), each on its own sets: WPS per SIMD
@@ -222,7 +263,21 @@ vcg_apply_slab346(const VcgArgs a, const int nset)
          m_[4 * dy + 0] = m[0]; m_[4 * dy + 1] = m[1]; m_[4 * dy + 2] = m[2]; m_[4 * dy + 3] = m[3];
       }
    };
-   load_map(s, mo); // in flight while the scalars are read
+   load_map(s, mo);
+   // Everything else the prologue needs from memory goes out WITH the map, ahead of the first wait: the scalars of the
+   // solve and the 1-D table.  (Round 3 read them one after the other behind the gathers - convergence flag, then the
+   // done flags and (r, z), then the table: four dependent round trips of ~1.2 us between a workgroup's arrival and its
+   // first pass, profiles/r4_k1_kron_trace.txt; now two: this batch, then the gathers.)
+   const VcgScalars *const sc0 = a.s;
+   const int sc_all_done = sc0->all_done;
+   int sc_done[kVC];
+   double sc_rz[kVC], sc_rzp[kVC];
+#pragma unroll
+   for (int k = 0; k < kVC; k++) { sc_done[k] = sc0->done[k]; sc_rz[k] = sc0->rz[k]; sc_rzp[k] = sc0->rz_prev[k]; }
+   constexpr int NTAB = KRON ? D * D : HB;
+   double tabv[NTAB];
+#pragma unroll
+   for (int i = 0; i < NTAB; i++) { tabv[i] = KRON ? a.M1[i] : a.B[i]; }
 
    // node vectors: one scalar base + 32-bit byte offsets (vcg_slab_available checks kVC * N * 8 < 2^32).  In the first
    // iteration (beta = 0) the old direction is not defined: r is read in its place and multiplied by zero.
@@ -278,7 +333,7 @@ vcg_apply_slab346(const VcgArgs a, const int nset)
          __builtin_amdgcn_global_load_lds(p + 128 * k, (__attribute__((address_space(3))) void *)(l + 128 * k), 16, 0, 0);
       }
    };
-   if (RANK1)
+   if (RANK1 && !KRON)
    {
 #pragma unroll
       for (int k = 0; k < NDMA; k++)
@@ -291,20 +346,23 @@ vcg_apply_slab346(const VcgArgs a, const int nset)
    load_dq(s, sDa + wid * SBUF);
    load_map(DYN ? max(s1, 0) : s1, mo);
    // (the scalars of the solve are looked at with the first loads of the kernel already in flight)
-   if (a.s->all_done) { __builtin_amdgcn_s_waitcnt(0x0F70); return; } // (nothing in flight into the LDS of a workgroup that is gone)
+   if (sc_all_done) { __builtin_amdgcn_s_waitcnt(0x0F70); return; } // (nothing in flight into the LDS of a workgroup that is gone)
    bool todo[kVC];
    double beta[kVC];
 #pragma unroll
-   for (int k = 0; k < kVC; k++) { todo[k] = a.s->done[k] == 0; }
+   for (int k = 0; k < kVC; k++) { todo[k] = sc_done[k] == 0; }
    if (a.multi && !first && !vcg_pending_update(a.s, a.iter, blockIdx.x == 0 && tid == 0, todo)) { __builtin_amdgcn_s_waitcnt(0x0F70); return; }
 #pragma unroll
-   for (int k = 0; k < kVC; k++) { beta[k] = (first || !todo[k]) ? 0.0 : a.s->rz[k] / a.s->rz_prev[k]; }
+   for (int k = 0; k < kVC; k++) { beta[k] = (first || !todo[k]) ? 0.0 : sc_rz[k] / sc_rzp[k]; }
    const bool mine = (c == 0) ? todo[0] : (c == 1) ? todo[1] : todo[2];
    const double betac = (c == 0) ? beta[0] : (c == 1) ? beta[1] : beta[2];
 
    double Bsr[HB];
 #pragma unroll
-   for (int i = 0; i < HB; i++) { Bsr[i] = uniform_f64(a.B[i]); }
+   for (int i = 0; i < HB; i++) { Bsr[i] = KRON ? 0.0 : uniform_f64(tabv[KRON ? 0 : i]); }
+   double M1[D * D]; // KRON: the 1-D mass tile, M1[i + D j] (symmetric), in scalar registers
+#pragma unroll
+   for (int i = 0; i < D * D; i++) { M1[i] = KRON ? uniform_f64(tabv[KRON ? i : 0]) : 0.0; }
    auto Bs = [&](const int idx) -> double { return (SYM && idx >= HB) ? Bsr[QD - 1 - idx] : Bsr[idx]; };
    // (RANK1: A d = s_e (B^T W B d) - the element factor multiplies the 16 outputs and the partial of (d, A d) at the
    //  end of the pass, not the 54 point values; loaded with the gathers of the pass, two registers)
@@ -338,7 +396,7 @@ vcg_apply_slab346(const VcgArgs a, const int nset)
    // EXACT: (d, A d) in integer accumulators (lgh_vcg.hpp): no ticket, no last workgroup; vcg_update_p_k forms the value
    long long acc[kLimbs] = {0, 0, 0, 0};
    bool acc_bad = false;
-   const int accE = exact_scale((c == 0) ? a.s->rz[0] : (c == 1) ? a.s->rz[1] : a.s->rz[2]);
+   const int accE = exact_scale((c == 0) ? sc_rz[0] : (c == 1) ? sc_rz[1] : sc_rz[2]);
    __builtin_amdgcn_s_waitcnt(0x0F70);
    convert();
    if (DYN) { __syncthreads(); } // s_next is in place (the first draw is a pass away)
@@ -366,7 +424,88 @@ vcg_apply_slab346(const VcgArgs a, const int nset)
       load_map(DYN ? max(s2, 0) : s2, mn);
       LGH_SLAB_STAMP(0); // issue of the loads
       double o[16], dset = 0.0;
-      if (!DYN || s0 >= 0)
+      if (KRON)
+      {
+         if (!DYN || s0 >= 0)
+         {
+            __builtin_amdgcn_sched_barrier(0);
+            // x, then y with the 1-D mass tile on this lane's slab dz = g: w[dx + 4 dy]
+            double w[16];
+#pragma unroll
+            for (int dy = 0; dy < D; dy++)
+            {
+#pragma unroll
+               for (int i = 0; i < D; i++)
+               {
+                  double u = M1[i] * dd[D * dy];
+#pragma unroll
+                  for (int dx = 1; dx < D; dx++) { u = fma(M1[i + D * dx], dd[dx + D * dy], u); }
+                  w[i + D * dy] = u;
+               }
+            }
+            double v[16];
+#pragma unroll
+            for (int i = 0; i < D; i++)
+            {
+#pragma unroll
+               for (int j = 0; j < D; j++)
+               {
+                  double u = M1[j] * w[i];
+#pragma unroll
+                  for (int dy = 1; dy < D; dy++) { u = fma(M1[j + D * dy], w[i + D * dy], u); }
+                  v[i + D * j] = u;
+               }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            load_gather_part(1, true);
+            __builtin_amdgcn_sched_barrier(0);
+            LGH_SLAB_STAMP(1);
+            // slabs -> pairs: v[4 dz + i] = slab dz of the pair (i, dy = g); z with the tile; back
+            slab16_to_pairs(v);
+            __builtin_amdgcn_sched_barrier(0);
+            LGH_SLAB_STAMP(2);
+#pragma unroll
+            for (int i = 0; i < D; i++)
+            {
+               double t[D];
+#pragma unroll
+               for (int k = 0; k < D; k++)
+               {
+                  double u = M1[k] * v[i];
+#pragma unroll
+                  for (int dz = 1; dz < D; dz++) { u = fma(M1[k + D * dz], v[D * dz + i], u); }
+                  t[k] = u;
+               }
+#pragma unroll
+               for (int k = 0; k < D; k++) { v[D * k + i] = t[k]; }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            load_gather_part(2, true);
+            __builtin_amdgcn_sched_barrier(0);
+            LGH_SLAB_STAMP(3);
+            slab16_to_slabs(v);
+            __builtin_amdgcn_sched_barrier(0);
+            load_gather_part(3, true);
+            __builtin_amdgcn_sched_barrier(0);
+            LGH_SLAB_STAMP(4);
+            // (d, A d) of this lane's slab: sum over its 16 nodes (the element factor s_e multiplies it below, with the outputs)
+#pragma unroll
+            for (int j = 0; j < 16; j++)
+            {
+               o[j] = v[j];
+               dset = fma(dd[j], v[j], dset);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            LGH_SLAB_STAMP(5);
+         }
+         else
+         {
+            load_gather_part(1);
+            load_gather_part(2);
+            load_gather_part(3);
+         }
+      }
+      else if (!DYN || s0 >= 0)
       {
       // Phase order is pinned (sched_barrier): with few wavefronts per SIMD the compiler would otherwise hoist every LDS
       // read and half the next phase above the current one and pay for it in register moves.
@@ -704,6 +843,21 @@ bool vcg_slab_available(lgh_ctx *c)
    return c->dim == 3 && c->kid == 0x346 && (size_t)c->N * 8 * kVC < 0xffffffffull && ((size_t)c->NE * c->ND + kYePad) * 8 * (kVC - 1) + 65536 < 0xffffffffull && slab_swaps_ok(c); // (per-lane store offsets: the last component's plane + a set)
 }
 
+template <bool SYM, int WPS, int TR, bool WIDE, bool EX, bool DYN>
+static void slab_launch(lgh_ctx *c, const VcgArgs &a, const int grid, const int nset)
+{
+   if (a.dqs == 0)
+   {
+      // compact mass data; with a tensor-product rule as well (a.M1): the Kronecker form
+      if constexpr (SYM)
+      {
+         if (a.M1) { hipLaunchKernelGGL((vcg_apply_slab346<SYM, WPS, TR, WIDE, EX, DYN, true, true>), dim3(grid), dim3(256 * WPS), 0, c->stream, a, nset); return; }
+      }
+      hipLaunchKernelGGL((vcg_apply_slab346<SYM, WPS, TR, WIDE, EX, DYN, true>), dim3(grid), dim3(256 * WPS), 0, c->stream, a, nset);
+   }
+   else { hipLaunchKernelGGL((vcg_apply_slab346<SYM, WPS, TR, WIDE, EX, DYN, false>), dim3(grid), dim3(256 * WPS), 0, c->stream, a, nset); }
+}
+
 void launch_vcg_slab(lgh_ctx *c, const VcgArgs &a)
 {
    if (c->ncu <= 0) // (per context: contexts of one process may sit on different devices)
@@ -718,8 +872,7 @@ void launch_vcg_slab(lgh_ctx *c, const VcgArgs &a)
    const bool wide = c->slab_wide && a.map_xrows != 0;
    const bool exact = a.limbs != nullptr;
    const bool dyn = exact && c->slab_dyn;
-#define LGH_SLAB_LAUNCH(SYM_, WPS_, TR_, WIDE_, EX_, DYN_) do { if (a.dqs == 0) { hipLaunchKernelGGL((vcg_apply_slab346<SYM_, WPS_, TR_, WIDE_, EX_, DYN_, true>), dim3(grid), dim3(256 * WPS_), 0, c->stream, a, nset); } \
-                                                                  else { hipLaunchKernelGGL((vcg_apply_slab346<SYM_, WPS_, TR_, WIDE_, EX_, DYN_, false>), dim3(grid), dim3(256 * WPS_), 0, c->stream, a, nset); } } while (0)
+#define LGH_SLAB_LAUNCH(SYM_, WPS_, TR_, WIDE_, EX_, DYN_) slab_launch<SYM_, WPS_, TR_, WIDE_, EX_, DYN_>(c, a, grid, nset)
 #define LGH_SLAB_LAUNCH2(SYM_, WPS_, TR_) do { if (wide && dyn) { LGH_SLAB_LAUNCH(SYM_, WPS_, TR_, true, true, true); } else if (wide && exact) { LGH_SLAB_LAUNCH(SYM_, WPS_, TR_, true, true, false); } \
                                                else if (wide) { LGH_SLAB_LAUNCH(SYM_, WPS_, TR_, true, false, false); } \
                                                else if (exact) { LGH_SLAB_LAUNCH(SYM_, WPS_, TR_, false, true, false); } else { LGH_SLAB_LAUNCH(SYM_, WPS_, TR_, false, false, false); } } while (0)

@@ -92,6 +92,19 @@ def test_k1_one_launch_vs_oracle(case, rank1, first, monkeypatch):
     _run_case(prob, monkeypatch, variant, form, rank1, first)
 
 
+@pytest.mark.parametrize("first", [True, False], ids=["first", "later"])
+@pytest.mark.parametrize("case", [c for c in K1_CASES if c[6] == "slab"], ids=[c[0] for c in K1_CASES if c[6] == "slab"])
+def test_k1_slab_through_the_quadrature_points(case, first, monkeypatch):
+    """With compact mass data on a tensor-product rule the slab K1 applies the element matrix as a Kronecker product of
+    1-D mass tiles (no quadrature-point values; the default in the cases above).  LGH_MASS_KRON=0 keeps the
+    contraction through the quadrature points with the compact data: same operator, same tolerance."""
+    from oracle.fem import Problem
+    _, mesh, rs, ok, ot, variant, form = case
+    monkeypatch.setenv("LGH_MASS_KRON", "0")
+    prob = Problem(mesh=mesh, rs=rs, order_v=ok, order_e=ot, problem=1)
+    _run_case(prob, monkeypatch, variant, form, True, first)
+
+
 @pytest.mark.parametrize("rank1", [True, False], ids=["compact", "stored"])
 def test_k1_default_dispatch_at_bench_size(rank1, monkeypatch):
     """Config 2's mesh (32^3 zones, Q3Q2): the kernel bench.py's headline is dominated by, as dispatched by default

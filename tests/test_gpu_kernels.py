@@ -821,6 +821,11 @@ KERNEL_SWITCHES = [
     ((5, 4), {"LGH_MASS_SEP": "0"}, "tol"),
     ((5, 4), {"LGH_MASS_RANK1": "0"}, "tol"),
     ((5, 4), {"LGH_Q_PPT": "1"}, "tol"),
+    # mass operators through the quadrature points instead of the Kronecker form of compact data (slab K1, L2 apply)
+    ((3, 2), {"LGH_MASS_KRON": "0"}, "tol"),
+    ((4, 3), {"LGH_MASS_KRON": "0"}, "tol"),
+    ((5, 4), {"LGH_MASS_KRON": "0"}, "tol"),
+    ((3, 2), {"LGH_MASS_KRON": "0", "LGH_VCG_VARIANT": "4"}, "tol"),
     ((3, 2), {"LGH_Q_FORM": "0"}, "tol"),   # the point form of the quadrature update instead of the row form (lgh_qrows.hpp)
     ((4, 3), {"LGH_Q_FORM": "0"}, "tol"),
     ((3, 2), {"LGH_Q_FORM": "0", "LGH_FUSED_FTV": "0", "LGH_FUSED_F1": "0"}, "tol"),
