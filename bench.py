@@ -180,7 +180,7 @@ KERNEL_NAMES = {0: "vcg_apply_plane (H1 CG K1, 3 velocity components per launch)
                 2: "qpoint_kernel (fused QUpdate + both force products)", 3: "force_mult_3d", 4: "force_mult_t_3d",
                 5: "mass_apply_l2 (L2 CG K1)",
                 6: "halo_sum (pack + grouped ncclSend/Recv + combine)", 7: "ncclAllReduce of device scalars"}
-K1_FORMS = {0: "vcg_apply_3d", 2: "vcg_apply_plane", 3: "vcg_apply_mfma346", 4: "vcg_apply_slab346"}
+K1_FORMS = {0: "vcg_apply_3d", 2: "vcg_apply_plane", 3: "vcg_apply_mfma346", 4: "vcg_apply_slab346", 5: "vcg_apply_kron"}
 
 
 def kernel_names(L, ctx):
@@ -225,7 +225,7 @@ def moved_bytes(sz, L, ctx, k1_name):
     L.lgh_mass_data_form(ctx, ctypes.byref(form))
     h1s, l2s = ctypes.c_int(0), ctypes.c_int(0)
     L.lgh_table_symmetry(ctx, ctypes.byref(h1s), ctypes.byref(l2s))
-    k1_compact = form.value == 1 and k1_name.split(" ")[0] in ("vcg_apply_slab346", "vcg_apply_plane", "vcg_apply_plane_ho")
+    k1_compact = form.value == 1 and k1_name.split(" ")[0] in ("vcg_apply_slab346", "vcg_apply_plane", "vcg_apply_plane_ho", "vcg_apply_kron")
     l2_compact = form.value == 1 and dim == 3 and l2s.value == 1 and os.environ.get("LGH_L2_PLANE", "1") != "0" and D >= 4
     b[0] = 8 * (N * (2 * dim + 1) + NE * dim * ND) + (8 * NE if k1_compact else 8 * NE * NQ)
     b[5] = NE * 8 * ((1 if l2_compact else NQ) + 2 * NL)

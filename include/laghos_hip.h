@@ -266,6 +266,8 @@ int lgh_table_symmetry(lgh_ctx *ctx, int *h1, int *l2);
 /* Which form of the mass-apply kernel K1 the lockstep velocity solve (lgh_solve_velocity) launches for this
  * context: 0 = column form, 2 = plane form, 3 = x contractions on the matrix cores (v_mfma_f64_16x16x4_f64, Q3Q2
  * only), 4 = slab form (sum factorisation in registers, lane-group transposes by v_permlane swaps, Q3Q2 only),
+ * 5 = Kronecker form (compact mass data on a tensor-product rule: the element matrix as s_e M1 (x) M1 (x) M1 with the
+ * 1-D mass tile M1 = B^T diag(w) B; the slab form applies the same where it is dispatched),
  * -1 = no lockstep solve for this kernel id (the scalar CG runs).  Tests use it to make sure a requested
  * form (LGH_VCG_VARIANT) is the one that ran. */
 int lgh_k1_form(lgh_ctx *ctx, int *form);

@@ -791,6 +791,150 @@ vcg_apply_plane_ho(const VcgArgs a)
    }
 }
 
+// ---- K1, Kronecker form, any order (compact mass data on a tensor-product rule; a.M1 = 1-D mass tile B^T diag(w) B):
+// A_e = s_e M1 (x) M1 (x) M1 - three contractions of D on the D^3 dofs of an (element, component) item instead of the
+// six of D x Q and the pass over the quadrature points: 3 D^4 FMAs per item (D = 6: 3 888 against ~21 000), no
+// quadrature-point values; what is left is the traffic: the gathers of r, d_old, 1/diag and the E-vector out.  The
+// Q3Q2 meshes of 20 000 zones and more take the slab form of the same operator (lgh_vcg_slab.hip), everything else
+// this kernel.  One workgroup of 256 threads = NEB consecutive elements x 3 components; a thread owns one row of D
+// values per stage (x rows (item, dz, dy), y rows (item, dz, dx), z rows (item, dy, dx)); (d, A d) = sum over the item's
+// dofs of d y.  Same operator in exact arithmetic as vcg_apply_plane(_ho); rounding differs (tests/test_gpu_k1.py).
+template <int D, int NEB>
+__global__ void __launch_bounds__(256)
+vcg_apply_kron(const VcgArgs a)
+{
+   constexpr int ND = D * D * D, DD = D * D, NT = 256, NI = NEB * kVC;
+   __shared__ double sIn[NI * ND], sT1[NI * ND], sT2[NI * ND];
+   __shared__ double red[48];
+   const int tid = threadIdx.x;
+   const int e0 = xcd_swizzle(blockIdx.x, gridDim.x) * NEB;
+   const int nel = min(NEB, a.NE - e0);
+   constexpr int GPT = (NEB * ND + NT - 1) / NT;
+   int mi[GPT];
+#pragma unroll
+   for (int k = 0; k < GPT; k++)
+   {
+      const int i = tid + k * NT;
+      mi[k] = (i < nel * ND) ? a.map[(size_t)e0 * ND + i] : -1;
+   }
+   if (a.s->all_done) { return; }
+   const bool first = a.s->first != 0;
+   bool todo[kVC];
+   double beta[kVC];
+#pragma unroll
+   for (int k = 0; k < kVC; k++) { todo[k] = a.s->done[k] == 0; }
+   if (a.multi && !first && !vcg_pending_update(a.s, a.iter, blockIdx.x == 0 && tid == 0, todo)) { return; }
+#pragma unroll
+   for (int k = 0; k < kVC; k++) { beta[k] = (first || !todo[k]) ? 0.0 : a.s->rz[k] / a.s->rz_prev[k]; }
+   double M[DD]; // M[i + D j], symmetric, in scalar registers
+#pragma unroll
+   for (int i = 0; i < DD; i++) { M[i] = uniform_f64(a.M1[i]); }
+   // directions d = z + beta d of the three components (K2 stores the same values); item = k2 * NEB + el
+#pragma unroll
+   for (int k = 0; k < GPT; k++)
+   {
+      const int i = tid + k * NT;
+      if (i < nel * ND)
+      {
+         const int el = i / ND, dd = i - el * ND;
+         const int n = mi[k];
+         const double gi = a.dinv[n];
+#pragma unroll
+         for (int k2 = 0; k2 < kVC; k2++)
+         {
+            const double gz = a.r[(size_t)k2 * a.N + n];
+            const double gd = first ? 0.0 : a.d[(size_t)k2 * a.N + n];
+            sIn[(k2 * NEB + el) * ND + dd] = fma(beta[k2], gd, __dmul_rn(gz, gi));
+         }
+      }
+   }
+   __syncthreads();
+   auto live = [&](const int item) -> bool {
+      const int k2 = item / NEB, el = item - k2 * NEB;
+      return el < nel && ((k2 == 0) ? todo[0] : (k2 == 1) ? todo[1] : todo[2]);
+   };
+   auto row = [&](const double (&u)[D], double (&o)[D]) {
+#pragma unroll
+      for (int i = 0; i < D; i++)
+      {
+         double t = M[i] * u[0];
+#pragma unroll
+         for (int j = 1; j < D; j++) { t = fma(M[i + D * j], u[j], t); }
+         o[i] = t;
+      }
+   };
+   // x: rows of D consecutive values
+   for (int r = tid; r < NI * DD; r += NT)
+   {
+      if (!live(r / DD)) { continue; }
+      double u[D], o[D];
+#pragma unroll
+      for (int j = 0; j < D; j++) { u[j] = sIn[r * D + j]; }
+      row(u, o);
+#pragma unroll
+      for (int i = 0; i < D; i++) { sT1[r * D + i] = o[i]; }
+   }
+   __syncthreads();
+   // y: rows (item, dz, dx), stride D
+   for (int r = tid; r < NI * DD; r += NT)
+   {
+      if (!live(r / DD)) { continue; }
+      const int dx = r % D, iz = r / D; // iz = dz + D item
+      const int base = iz * DD + dx;
+      double u[D], o[D];
+#pragma unroll
+      for (int j = 0; j < D; j++) { u[j] = sT1[base + D * j]; }
+      row(u, o);
+#pragma unroll
+      for (int i = 0; i < D; i++) { sT2[base + D * i] = o[i]; }
+   }
+   __syncthreads();
+   // z: rows (item, dy, dx), stride D^2; the element factor; E-vector out and the partials of (d, A d)
+   double dot[kVC] = {0.0, 0.0, 0.0};
+   for (int r = tid; r < NI * DD; r += NT)
+   {
+      const int item = r / DD;
+      if (!live(item)) { continue; }
+      const int yx = r - item * DD;
+      const int k2 = item / NEB, el = item - k2 * NEB;
+      const int base = item * ND + yx;
+      const double se = a.Se[e0 + el];
+      double u[D], o[D];
+#pragma unroll
+      for (int j = 0; j < D; j++) { u[j] = sT2[base + DD * j]; }
+      row(u, o);
+      double *yc = a.YE + (size_t)k2 * a.ye_stride + (size_t)(e0 + el) * ND + yx;
+      double part = 0.0;
+#pragma unroll
+      for (int i = 0; i < D; i++)
+      {
+         const double v = o[i] * se;
+         yc[DD * i] = v;
+         part = fma(sIn[base + DD * i], v, part);
+      }
+      dot[0] += (k2 == 0) ? part : 0.0;
+      dot[1] += (k2 == 1) ? part : 0.0;
+      dot[2] += (k2 == 2) ? part : 0.0;
+   }
+   double bp[kVC];
+   block_sum3(dot[0], dot[1], dot[2], red, bp);
+   double total[kVC];
+   if (grid_sum3_last_block(bp, a.partials, a.stride, a.ticket, red, total))
+   {
+      if (tid == 0)
+      {
+         VcgScalars *s = a.s;
+         for (int k = 0; k < kVC; k++)
+         {
+            if (!todo[k]) { continue; }
+            s->den[k] = total[k];
+            if (total[k] == 0.0 && !a.multi) { s->done[k] = 1; } // breakdown, as upstream
+         }
+         s->first = 0;
+      }
+   }
+}
+
 // base pointer + 32-bit byte offset: one SGPR pair and one VGPR per address
 __device__ __forceinline__ double vcg_ld(const double *base, const unsigned off) { return *(const double *)((const char *)base + off); }
 __device__ __forceinline__ double *vcg_ptr(double *base, const unsigned off) { return (double *)((char *)base + off); }
@@ -1594,6 +1738,11 @@ template <int D, int Q> static void launch_vcg_apply(lgh_ctx *c, const VcgArgs &
    hipLaunchKernelGGL((vcg_apply_3d<D, Q, NEB>), dim3(grid), dim3(Q * Q * NEB), 0, c->stream, a, nbatch);
 }
 
+template <int D, int NEB> static void launch_vcg_kron(lgh_ctx *c, const VcgArgs &a)
+{
+   hipLaunchKernelGGL((vcg_apply_kron<D, NEB>), dim3(ceil_div(c->NE, NEB)), dim3(256), 0, c->stream, a);
+}
+
 // LGH_VCG_VARIANT: 0 = (qx,qy)-column K1, otherwise the plane-per-thread K1
 #define VCG_DISPATCH(D_, Q_)                                                       \
    do {                                                                            \
@@ -1611,6 +1760,13 @@ int vcg_k1_form(lgh_ctx *c)
    // Default at Q3Q2 from kSlabMinElements zones per rank: 40.6 vs 48.5 us per launch at 32^3 zones, 316 vs 383 at 64^3
    // (profiles/README.md); smaller meshes do not fill its one workgroup per CU.
    if (c->kid == 0x346 && c->vcg_variant < 0 && c->NE >= kSlabMinElements && vcg_slab_available(c)) { return 4; }
+   // default everywhere else when the mass data is compact on a tensor-product rule: the Kronecker form (vcg_apply_kron)
+   if ((c->vcg_variant < 0 || c->vcg_variant == 5) && c->M1h && c->w1d)
+   {
+      const double *Dq, *Se;
+      int dqs = 1;
+      if (mass_data(c, &Dq, &dqs, &Se) == LGH_OK && dqs == 0) { return 5; }
+   }
    if (c->vcg_variant == 0) { return 0; }
    if ((c->kid == 0x358 || c->kid == 0x36A) && !c->b_h1_sym) { return 0; }
    return 2;
@@ -1694,7 +1850,7 @@ static int vcg_prepare(lgh_ctx *c, double *B, double *X, double rel_tol, VcgPlan
             LGH_HIP_CHECK(hipGetLastError());
          }
       }
-      if (vcg_k1_form(c) >= 3)
+      if (vcg_k1_form(c) == 3 || vcg_k1_form(c) == 4)
       {
          const size_t nm = (size_t)c->NE * c->ND;
          LGH_HIP_CHECK(hipMalloc((void **)&x->mapb, nm * sizeof(unsigned)));
@@ -1799,6 +1955,18 @@ static void vcg_launch_k1(lgh_ctx *c, const VcgPlan &plan, const VcgArgs &a)
 {
    VcgAux *aux = plan.aux;
    const int k1form = plan.k1form;
+   if (k1form == 5)
+   {
+      switch (c->D1D)
+      {
+         case 2: launch_vcg_kron<2, 64>(c, a); break;
+         case 3: launch_vcg_kron<3, 32>(c, a); break;
+         case 4: launch_vcg_kron<4, 16>(c, a); break;
+         case 5: launch_vcg_kron<5, 8>(c, a); break;
+         default: launch_vcg_kron<6, 4>(c, a); break;
+      }
+      return;
+   }
    switch (c->kid)
    {
       case 0x322: VCG_DISPATCH(2, 2); break;
