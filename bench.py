@@ -227,11 +227,16 @@ def moved_bytes(sz, L, ctx, k1_name):
     L.lgh_table_symmetry(ctx, ctypes.byref(h1s), ctypes.byref(l2s))
     k1_compact = form.value == 1 and k1_name.split(" ")[0] in ("vcg_apply_slab346", "vcg_apply_plane", "vcg_apply_plane_ho", "vcg_apply_kron")
     l2_compact = form.value == 1 and dim == 3 and l2s.value == 1 and os.environ.get("LGH_L2_PLANE", "1") != "0" and D >= 4
+    st = ctypes.c_int(1)
+    L.lgh_qupdate_stores_stress(ctx, ctypes.byref(st))
+    if st.value == 0:  # stress kept in registers: the nine stressJinvT planes are not written
+        b[2] -= NE * 8 * dim * dim * NQ
     b[0] = 8 * (N * (2 * dim + 1) + NE * dim * ND) + (8 * NE if k1_compact else 8 * NE * NQ)
     b[5] = NE * 8 * ((1 if l2_compact else NQ) + 2 * NL)
     notes = {0: "r, d_old (dim components) and 1/diag gathered from node vectors, E-vector out; mass data: %s"
                 % ("compact, one factor per element" if k1_compact else "stored table, NQ per element"),
-             5: "mass data: %s" % ("compact, one factor per element" if l2_compact else "stored table")}
+             5: "mass data: %s" % ("compact, one factor per element" if l2_compact else "stored table"),
+             2: "stressJinvT %s" % ("kept in registers (both force products formed in the kernel; lgh_qupdate_store_stress(ctx, 0))" if st.value == 0 else "written (9 planes)")}
     return b, notes, k1_compact
 
 

@@ -151,6 +151,17 @@ int lgh_qupdate_set_tiny_grad(lgh_ctx *ctx, double tiny_grad);
  * on = 0 switches the fusion off: the products then always come from the ForcePAOperator kernels (per-kernel
  * timing, A/B).  Default on. */
 int lgh_set_fused_forces(lgh_ctx *ctx, int on);
+/* QuadratureData.stressJinvT is the hand-over between UpdateQuadratureData and the two ForcePA products in the
+ * reference (laghos_solver.cpp:1158-1167 -> laghos_assembly.cpp:307-308, :859-872).  With both products formed inside
+ * lgh_qupdate the nine planes are written and never read in a PA run whose SolveEnergy is always given the state's own
+ * velocity (RK1-4, RK6): 43 % of the update's memory traffic.  on = 0: lgh_qupdate keeps the stress in registers and
+ * does not write stressJinvT (3D, force fusion on); every reader then refuses with LGH_ERR_ARG instead of using stale
+ * data - lgh_force_mult, lgh_force_mult_transpose, lgh_solve_velocity for a vector other than one; a SolveEnergy for a
+ * velocity other than the state's (RK2Avg) turns its right-hand side into NaN on the device and the next
+ * lgh_get_dt_est returns LGH_ERR_ARG.  Requesting lgh_qdata_stressJinvT() hands the array to the caller as before.
+ * Default on = 1 (the reference's behaviour); a change takes effect with the next lgh_qupdate. */
+int lgh_qupdate_store_stress(lgh_ctx *ctx, int on);
+int lgh_qupdate_stores_stress(lgh_ctx *ctx, int *on); /* whether the next lgh_qupdate writes stressJinvT (bench.py's byte accounting) */
 /* ResetQuadratureData (laghos_solver.hpp: qdata_is_current = false): the state has changed, the quadrature data -
  * and the force products formed with it - are stale.  The shells call it wherever the reference does. */
 int lgh_reset_quadrature_data(lgh_ctx *ctx);

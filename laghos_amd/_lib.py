@@ -91,6 +91,8 @@ SYMBOLS = {
     "lgh_comm_stats": (_I, [_P, c_int_p, ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_long), c_int_p, c_int_p]),
     "lgh_qupdate_set_tiny_grad": (_I, [_P, _D]),
     "lgh_set_fused_forces": (_I, [_P, _I]),
+    "lgh_qupdate_store_stress": (_I, [_P, _I]),
+    "lgh_qupdate_stores_stress": (_I, [_P, c_int_p]),
     "lgh_reset_quadrature_data": (_I, [_P]),
     "lgh_fused_force_mult": (_I, [_P, _P]),
     "lgh_fused_force_mult_transpose": (_I, [_P, _P]),

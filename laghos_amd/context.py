@@ -263,6 +263,10 @@ class Context:
         check(self.lib.lgh_mass_data_form(self.h, ctypes.byref(f)))
         return "rank1" if f.value == 1 else "stored"
 
+    def qupdate_store_stress(self, on):
+        """0: lgh_qupdate keeps the stress in registers (stressJinvT is not written; its readers refuse)."""
+        check(self.lib.lgh_qupdate_store_stress(self.h, int(bool(on))))
+
     def set_fused_forces(self, on):
         check(self.lib.lgh_set_fused_forces(self.h, 1 if on else 0))
 

@@ -253,6 +253,8 @@ static int create_impl(const lgh_config *cfg, lgh_ctx *c, const int kid)
       // LGH_Q_TINY_GRAD=<value>: default threshold of the QUpdate shortcut; 0: exact zeros only; -1: off
       const char *env = getenv("LGH_Q_TINY_GRAD");
       c->q_tiny_grad = env ? atof(env) : 1e-30;
+      c->stress_store = 1; // (the reference's behaviour: UpdateQuadratureData leaves stressJinvT in memory)
+      c->stress_current = 0;
    }
    c->h0 = 0.0;
    c->device = cfg->device;
@@ -481,7 +483,34 @@ double *lgh_qdata_stressJinvT(lgh_ctx *c)
 {
    // the caller may write through this pointer: F^T v and F.1 of the fused update no longer belong to it
    invalidate_fused(c);
+   c->stress_current = 1; // (whatever the caller puts there is what the force kernels read from now on)
    return c->stressJinvT;
+}
+// The stress of the current quadrature data is in memory (readers of stressJinvT call this first).
+static int stress_on_hand(lgh_ctx *c, const char *who)
+{
+   if (c->stress_current) { return LGH_OK; }
+   set_error("%s needs stressJinvT, which the last lgh_qupdate kept in registers (lgh_qupdate_store_stress(ctx, 0)): "
+             "only F.1 and F^T v of the state's own velocity are on hand; store the stress (..., 1) and update again", who);
+   return LGH_ERR_ARG;
+}
+int lgh_qupdate_stores_stress(lgh_ctx *c, int *on)
+{
+   LGH_CHECK_ARG(c && on);
+   // (what the next lgh_qupdate will do: the planes are only left out when both products come out of the update kernel)
+   *on = (!c->stress_store && c->erhs_q && c->force_e_q && c->v_snap && !c->fused_forces_off && c->dim == 3) ? 0 : 1;
+   return LGH_OK;
+}
+int lgh_qupdate_store_stress(lgh_ctx *c, int on)
+{
+   LGH_CHECK_ARG(c);
+   if ((on != 0) != (c->stress_store != 0))
+   {
+      c->stress_store = on ? 1 : 0;
+      invalidate_fused(c); // the quadrature data has to be updated again before anything reads it
+      c->stress_current = 0;
+   }
+   return LGH_OK;
 }
 int lgh_reset_quadrature_data(lgh_ctx *c)
 {
@@ -553,8 +582,16 @@ int lgh_get_dt_est(lgh_ctx *c, double *v)
 {
    LGH_CHECK_ARG(c && v);
    LGH_HIP_CHECK(hipMemcpyAsync(c->host_pinned + 8, c->dt_est_dev, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+   LGH_HIP_CHECK(hipMemcpyAsync(c->host_pinned + 9, c->dev_flags + 3, sizeof(int), hipMemcpyDeviceToHost, c->stream));
    LGH_HIP_CHECK(hipStreamSynchronize(c->stream));
    *v = c->host_pinned[8];
+   if (*(const int *)(c->host_pinned + 9) != 0)
+   {
+      LGH_HIP_CHECK(hipMemsetAsync(c->dev_flags + 3, 0, sizeof(int), c->stream));
+      set_error("lgh_solve_energy was given a velocity other than the state's while the stress was kept in registers "
+                "(lgh_qupdate_store_stress(ctx, 0)): its right-hand side is NaN");
+      return LGH_ERR_ARG;
+   }
    return LGH_OK;
 }
 
@@ -574,7 +611,9 @@ int lgh_force_mult(lgh_ctx *c, const double *x_l2, double *y_h1)
    LGH_CHECK_ARG(c && x_l2 && y_h1);
    // L2R->Mult is the identity for the lexicographic L2 space (assembly.cpp:559-560)
    kt_begin(c, LGH_KERNEL_FORCE_MULT);
-   int rc = force_mult_E(c, c->stressJinvT, x_l2, c->YE);
+   int rc = stress_on_hand(c, "lgh_force_mult");
+   if (rc) { return rc; }
+   rc = force_mult_E(c, c->stressJinvT, x_l2, c->YE);
    kt_end(c, LGH_KERNEL_FORCE_MULT);
    if (rc) { return rc; }
    rc = h1_transpose_gather(c, c->dim, c->YE, y_h1); // H1R->MultTranspose (:564)
@@ -586,6 +625,8 @@ int lgh_force_mult_transpose(lgh_ctx *c, const double *v_h1, double *y_l2)
 {
    LGH_CHECK_ARG(c && v_h1 && y_l2);
    kt_begin(c, LGH_KERNEL_FORCE_MULT_T);
+   const int rc0 = stress_on_hand(c, "lgh_force_mult_transpose");
+   if (rc0) { return rc0; }
    const int rc = force_mult_t_L(c, c->stressJinvT, v_h1, y_l2);
    kt_end(c, LGH_KERNEL_FORCE_MULT_T);
    return rc;
@@ -688,6 +729,8 @@ int lgh_solve_velocity(lgh_ctx *c, const double *S, double *dS_dt, const double 
       {
          const double *ones = nullptr;
          rc = one_vector(c, one_l2, &ones);
+         if (rc) { return rc; }
+         rc = stress_on_hand(c, "lgh_solve_velocity (F.1 of a vector other than one, or of changed quadrature data)");
          if (rc) { return rc; }
          kt_begin(c, LGH_KERNEL_FORCE_MULT);
          rc = force_mult_E(c, c->stressJinvT, ones, c->YE);
@@ -797,6 +840,13 @@ __global__ void __launch_bounds__(256) copy_unless_k(double *__restrict__ y, con
    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
    if (i < n) { y[i] = x[i]; }
 }
+__global__ void __launch_bounds__(256) poison_if_k(double *y, long n, const int *flag, int *err)
+{
+   if (*flag == 0) { return; }
+   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+   if (i < n) { y[i] = __builtin_nan(""); }
+   if (i == 0) { *err = 1; }
+}
 static int energy_rhs(lgh_ctx *c, const double *v_h1, double *e_rhs)
 {
    if (c->erhs_q && c->fused_ftv_valid)
@@ -805,8 +855,17 @@ static int energy_rhs(lgh_ctx *c, const double *v_h1, double *e_rhs)
       LGH_HIP_CHECK(hipMemsetAsync(flag, 0, sizeof(int), c->stream));
       hipLaunchKernelGGL(vec_differs_k, dim3(ceil_div(c->H1V, 256)), dim3(256), 0, c->stream, v_h1, c->v_snap, (long)c->H1V, flag);
       LGH_HIP_CHECK(hipGetLastError());
-      const int rc = force_mult_t_L(c, c->stressJinvT, v_h1, e_rhs, flag); // (runs only for a different v)
-      if (rc) { return rc; }
+      if (c->stress_current)
+      {
+         const int rc = force_mult_t_L(c, c->stressJinvT, v_h1, e_rhs, flag); // (runs only for a different v)
+         if (rc) { return rc; }
+      }
+      else
+      {
+         // the stress was kept in registers: a velocity other than the state's cannot be served - the right-hand side
+         // becomes NaN on the device (nothing downstream can look right) and the next lgh_get_dt_est reports it
+         hipLaunchKernelGGL(poison_if_k, dim3(ceil_div(c->L2V, 256)), dim3(256), 0, c->stream, e_rhs, (long)c->L2V, flag, c->dev_flags + 3);
+      }
       hipLaunchKernelGGL(copy_unless_k, dim3(ceil_div(c->L2V, 256)), dim3(256), 0, c->stream, e_rhs, c->erhs_q, (long)c->L2V, flag);
       LGH_HIP_CHECK(hipGetLastError());
       return LGH_OK;
@@ -1014,6 +1073,7 @@ int lgh_ktime_end(lgh_ctx *c, int *launches, double *mean_seconds)
 int lgh_set_fused_forces(lgh_ctx *c, int on)
 {
    LGH_CHECK_ARG(c);
+   if (c->fused_forces_off == (on ? 0 : 1)) { return LGH_OK; } // (nothing changes: the products on hand stay)
    c->fused_forces_off = on ? 0 : 1;
    invalidate_fused(c);
    return LGH_OK;

@@ -131,6 +131,8 @@ struct lgh_ctx
    unsigned long qgen;   // counts lgh_qupdate / invalidations (lgh_quadrature_generation)
    int *dev_flags;       // 4 device ints: [0] "v differs from v_snap" of the current lgh_solve_energy
    double *ones_l2;      // L2V ones: the operator's own `one` (laghos_solver.cpp:170-171), allocated on first use
+   int stress_store;            // lgh_qupdate_store_stress: 1 (default) = lgh_qupdate writes the nine stressJinvT planes; 0 = the stress stays in registers
+   int stress_current;          // stressJinvT holds the stress of the current quadrature data (consumers refuse it otherwise)
    int fused_forces_off;        // lgh_set_fused_forces(ctx, 0): the update forms no force products (measurement / A-B)
    // scratch
    double *XE;           // max(L2V, NE*ND*dim)

@@ -158,7 +158,7 @@ __device__ __forceinline__ double qpoint_body(const QArgs &a, const int e, const
       {
          const double sv_ = stressJiT[vd + gd * DIM] * wd;
          sjw[gd + vd * DIM] = sv_;
-         a.stressJinvT[eq + plane * (gd + vd * DIM)] = sv_;
+         if (a.stressJinvT) { a.stressJinvT[eq + plane * (gd + vd * DIM)] = sv_; } // (nullptr: the stress stays in registers, lgh_qupdate_store_stress)
       }
    return dt_cand;
 }

@@ -13,6 +13,10 @@ int qupdate(lgh_ctx *c, const double *S)
    a.v = S + c->H1V;
    a.e = S + 2 * (size_t)c->H1V;
    a.result = c->dt_est_dev;
+   // lgh_qupdate_store_stress(ctx, 0): with both force products formed from registers nobody reads the nine stressJinvT
+   // planes (43 % of this kernel's bytes) - they are not written; every reader checks stress_current and refuses
+   const bool keep = !c->stress_store && a.erhs_q && a.force_e && c->v_snap;
+   if (keep) { a.stressJinvT = nullptr; }
    // 3D up to Q4Q3: the form with row-owned contraction stages (lgh_qrows.hpp); LGH_Q_FORM=0: the point form (A/B, tests)
    const char *fenv = getenv("LGH_Q_FORM");
    const bool rows = qrows_available(c) && !(fenv && fenv[0] == '0');
@@ -20,6 +24,7 @@ int qupdate(lgh_ctx *c, const double *S)
    // F^T v of this state's velocity block is now in c->erhs_q, F.1 in c->force_e_q; lgh_solve_energy compares the
    // velocity it is given with the one the product was formed from
    c->qgen++;
+   c->stress_current = (rc == LGH_OK && !keep) ? 1 : 0;
    c->fused_ftv_valid = (rc == LGH_OK && a.erhs_q && c->v_snap) ? 1 : 0;
    c->fused_f1_valid = (rc == LGH_OK && a.force_e) ? 1 : 0;
    if (c->fused_ftv_valid)

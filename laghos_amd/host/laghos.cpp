@@ -311,6 +311,15 @@ laghos_sim *laghos_sim_create(int argc, const char *const *argv, int nranks, int
          std::fprintf(stderr, "Unknown ODE solver type: %d\n", o.ode_solver_type); // laghos.cpp:527-531
          return nullptr;
    }
+   // RK1-4 / RK6 give every SolveEnergy the velocity block of the state the quadrature data was updated for: F.1 and
+   // F^T v both come out of the update kernel and nobody reads qdata.stressJinvT - it is not written then.  RK2Avg
+   // (laghos_solver.cpp:1464-1480) solves the energy equation for an averaged velocity: the stress stays in memory.
+   // (-store-stress / LGH_STORE_STRESS=1 keep it in memory in any case.)
+   {
+      const char *senv = std::getenv("LGH_STORE_STRESS");
+      const bool keep_in_registers = o.ode_solver_type != 7 && d.dim == 3 && !(senv && senv[0] == '1');
+      if (keep_in_registers) { LGH_VERIFY(lgh_qupdate_store_stress(s->hydro->Context(), 0)); }
+   }
    s->S.FromHost(S0);
    s->S_old.SetSize(s->S.Size());
    s->ode->Init(*s->hydro);

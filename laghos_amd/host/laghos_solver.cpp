@@ -168,9 +168,17 @@ void LagrangianHydroOperator::SolveEnergy(const Vector &S, const Vector &v, Vect
 
 void LagrangianHydroOperator::UpdateQuadratureData(const Vector &S) const
 {
-   if (qdata_is_current) { return; } // :809
+   // (:809) current for the host AND for the library: anything that discards the force products behind the operator's
+   // back - lgh_set_fused_forces, lgh_qupdate_store_stress, a request for the mutable stressJinvT - bumps the
+   // library's generation counter, and the data is then updated again instead of being read stale
+   unsigned long gen = 0;
+   int f1 = 0, ftv = 0;
+   LGH_VERIFY(lgh_quadrature_generation(ctx, &gen, &f1, &ftv));
+   if (qdata_is_current && gen == qdata_gen) { return; }
    qdata_is_current = true;
    qupdate->UpdateQuadratureData(S, *qdata); // :814
+   LGH_VERIFY(lgh_quadrature_generation(ctx, &gen, &f1, &ftv));
+   qdata_gen = gen;
 }
 
 double LagrangianHydroOperator::GetTimeStepEstimate(const Vector &S) const

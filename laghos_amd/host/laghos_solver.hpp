@@ -43,6 +43,7 @@ protected:
    const int cg_max_iter;
    std::unique_ptr<QuadratureData> qdata;
    mutable bool qdata_is_current;
+   mutable unsigned long qdata_gen = 0; // lgh_quadrature_generation() after the operator's last update
    std::unique_ptr<ForcePAOperator> ForcePA;
    std::unique_ptr<MassPAOperator> VMassPA, EMassPA;
    std::unique_ptr<QUpdate> qupdate;

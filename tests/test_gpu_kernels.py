@@ -538,6 +538,59 @@ def test_fused_force_products(cfg, kind):
         o.close()
 
 
+def test_stress_kept_in_registers():
+    """lgh_qupdate_store_stress(ctx, 0): the update forms F.1 and F^T v from the stress in registers and does not write
+    the nine stressJinvT planes.  One right-hand-side evaluation must give the SAME BITS as with the planes written (the
+    products are formed from the same registers either way), the array in memory must stay untouched, every reader of
+    it must refuse loudly, and a SolveEnergy for a velocity other than the state's (what RK2Avg does) must end in NaN
+    plus an error at the next lgh_get_dt_est - never in numbers computed from stale stress."""
+    from laghos_amd._lib import LghError
+    from oracle.fem import Problem
+    prob = Problem(mesh="cube01_hex", rs=1, order_v=3, order_e=2, problem=1)
+    S = deformed_state(prob, seed=71)
+    g = make_gpu(prob)
+    try:
+        ctx = g.ctx
+        Sd = ctx.to_dev(S)
+        dS1, dS2 = ctx.zeros(S.size), ctx.zeros(S.size)
+        g.reset_quadrature_data()
+        g.mult(Sd, dS1)
+        ctx.sync()
+        stress_written = np.array(ctx.stressJinvT, copy=True)
+        assert np.abs(stress_written).max() > 0
+        marker = np.full_like(stress_written, 7.25)
+        ctx.set_stressJinvT(marker)
+        ctx.qupdate_store_stress(0)
+        g.reset_quadrature_data()
+        g.mult(Sd, dS2)
+        ctx.sync()
+        assert np.array_equal(dS1.cpu().numpy(), dS2.cpu().numpy())
+        # (reading the array through the property hands it to the caller - do that last)
+        one = ctx.to_dev(np.ones(prob.L2V))
+        y = ctx.empty(prob.H1V)
+        with pytest.raises(LghError, match="kept in registers"):
+            ctx.force_mult(one, y)
+        with pytest.raises(LghError, match="kept in registers"):
+            ctx.force_mult_transpose(Sd[prob.H1V:2 * prob.H1V], ctx.empty(prob.L2V))
+        # a velocity that is not the state's: NaN right-hand side, error at the next dt read
+        v_other = ctx.to_dev(S[prob.H1V:2 * prob.H1V] * 1.5)
+        e_rhs, dS3 = ctx.empty(prob.L2V), ctx.zeros(S.size)
+        ctx.solve_energy(Sd, v_other, dS3, e_rhs, 1e-8, 50)
+        ctx.sync()
+        assert np.isnan(e_rhs.cpu().numpy()).all()
+        with pytest.raises(LghError, match="velocity other than the state"):
+            ctx.get_dt_est()
+        assert np.array_equal(np.asarray(ctx.stressJinvT), marker), "the planes must not have been written"
+        # back on: the next update writes them again
+        ctx.qupdate_store_stress(1)
+        g.reset_quadrature_data()
+        g.mult(Sd, dS2)
+        ctx.sync()
+        assert np.array_equal(np.asarray(ctx.stressJinvT), stress_written)
+    finally:
+        g.close()
+
+
 def test_fused_products_follow_content_not_addresses():
     """lgh_solve_energy must use the velocity it is GIVEN (ForcePA->MultTranspose(v, e_rhs),
     laghos_solver.cpp:473), whatever lgh_qupdate saw before:
