@@ -191,6 +191,10 @@ def kernel_names(L, ctx):
     names[0] = K1_FORMS.get(f.value, "vcg_apply") + " (H1 CG K1, 3 velocity components per launch)"
     if os.environ.get("LGH_K2P") == "0":
         names[1] = names[1].replace("vcg_update_p_k", "vcg_update_k")
+    q = ctypes.c_int(0)
+    L.lgh_qupdate_form(ctx, ctypes.byref(q))
+    if q.value == 1:
+        names[2] = names[2].replace("qpoint_kernel", "qrows_kernel")
     return names
 
 
@@ -200,8 +204,9 @@ def algorithmic_bytes(sz):
     NQ, ND, NL, NE, N = sz["NQ"], D ** dim, Ld ** dim, sz["NE"], sz["N"]
     return {
         0: NE * 8 * (NQ + dim * 2 * ND),                        # lockstep mass apply: D once + (in + out) per component
-        # K2, per launch: r, d, x read and written, 1/diag, the element contributions (E-vector), their ELL index table
-        1: 8 * N * (dim * 6 + 1) + 8 * dim * NE * ND + 4 * 8 * N,
+        # K2, per launch (mean over a solve): r, d read and written, x read and written every second iteration (5 passes
+        # per component), 1/diag, the element contributions (E-vector), their ELL index table (8 slots), the flag bytes
+        1: 8 * N * (dim * 5 + 1) + 8 * dim * NE * ND + 4 * 8 * N + N,
         2: NE * (8 * (2 * dim * ND + NL + dim * dim * NQ + NQ + dim * dim * NQ) + 8),  # fused QUpdate
         3: NE * 8 * (dim * dim * NQ + NL + dim * ND),           # ForceMult
         4: NE * 8 * (dim * dim * NQ + NL + dim * ND),           # ForceMultTranspose
@@ -337,9 +342,11 @@ def pmc_traffic(workload, kernel):
         hits = [k for k in ks if kernel in k]
         if not hits:
             return None, "no launch of %s in profiles/%s[%s]" % (kernel, PMC_FILE, workload)
-        k = max(hits, key=lambda k: ks[k]["launches"])
-        return ks[k]["bytes_per_launch"], ("profiles/%s[%s] (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, 2*FETCH + WRITE per "
-                                           "launch of %s, kernel sources @%s)" % (PMC_FILE, workload, k, sha))
+        # (several instantiations of one kernel - K2 with and without the update of x - count by their launches)
+        nl = sum(ks[k]["launches"] for k in hits)
+        mean = sum(ks[k]["launches"] * ks[k]["bytes_per_launch"] for k in hits) / nl
+        return mean, ("profiles/%s[%s] (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, 2*FETCH + WRITE per launch, launch-weighted "
+                      "over %s, kernel sources @%s)" % (PMC_FILE, workload, " + ".join(sorted(hits)), sha))
     except Exception as e:
         return None, "unavailable: %r" % (e,)
 

@@ -161,7 +161,10 @@ int lgh_set_fused_forces(lgh_ctx *ctx, int on);
  * lgh_get_dt_est returns LGH_ERR_ARG.  Requesting lgh_qdata_stressJinvT() hands the array to the caller as before.
  * Default on = 1 (the reference's behaviour); a change takes effect with the next lgh_qupdate. */
 int lgh_qupdate_store_stress(lgh_ctx *ctx, int on);
-int lgh_qupdate_stores_stress(lgh_ctx *ctx, int *on); /* whether the next lgh_qupdate writes stressJinvT (bench.py's byte accounting) */
+int lgh_qupdate_stores_stress(lgh_ctx *ctx, int *on);
+/* Kernel lgh_qupdate launches for this context: 1 = qrows_kernel (3D up to Q4Q3: contraction stages with row-owning
+ * threads, lgh_qrows.hpp), 0 = qpoint_kernel (every thread owns one output of every stage; 2D, Q5Q4, LGH_Q_FORM=0). */
+int lgh_qupdate_form(lgh_ctx *ctx, int *form); /* whether the next lgh_qupdate writes stressJinvT (bench.py's byte accounting) */
 /* ResetQuadratureData (laghos_solver.hpp: qdata_is_current = false): the state has changed, the quadrature data -
  * and the force products formed with it - are stale.  The shells call it wherever the reference does. */
 int lgh_reset_quadrature_data(lgh_ctx *ctx);

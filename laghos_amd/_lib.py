@@ -93,6 +93,7 @@ SYMBOLS = {
     "lgh_set_fused_forces": (_I, [_P, _I]),
     "lgh_qupdate_store_stress": (_I, [_P, _I]),
     "lgh_qupdate_stores_stress": (_I, [_P, c_int_p]),
+    "lgh_qupdate_form": (_I, [_P, c_int_p]),
     "lgh_reset_quadrature_data": (_I, [_P]),
     "lgh_fused_force_mult": (_I, [_P, _P]),
     "lgh_fused_force_mult_transpose": (_I, [_P, _P]),

@@ -494,6 +494,12 @@ static int stress_on_hand(lgh_ctx *c, const char *who)
              "only F.1 and F^T v of the state's own velocity are on hand; store the stress (..., 1) and update again", who);
    return LGH_ERR_ARG;
 }
+int lgh_qupdate_form(lgh_ctx *c, int *form)
+{
+   LGH_CHECK_ARG(c && form);
+   *form = qupdate_form(c);
+   return LGH_OK;
+}
 int lgh_qupdate_stores_stress(lgh_ctx *c, int *on)
 {
    LGH_CHECK_ARG(c && on);

@@ -418,6 +418,7 @@ int mass_apply_h1(lgh_ctx *c, const double *x, double *y, bool eliminate);
 int mass_apply_l2(lgh_ctx *c, const double *x, double *y);
 int mass_apply_E(lgh_ctx *c, int space, const double *xE, double *yE);
 int mass_assemble_diag(lgh_ctx *c);
+int qupdate_form(lgh_ctx *c); // 1: row form of the 3D quadrature update (lgh_qrows.hpp), 0: point form
 // the quadrature data of the mass operators as (table, element stride in doubles, per-element factor): value(q, e) = Dq[q + dqs e] * Se[e]
 int mass_data(lgh_ctx *c, const double **Dq, int *dqs, const double **Se);
 int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, int iters[3],

@@ -6,6 +6,7 @@
 namespace lgh
 {
 
+int qupdate_form(lgh_ctx *c);
 int qupdate(lgh_ctx *c, const double *S)
 {
    QArgs a = q_base(c);
@@ -18,8 +19,7 @@ int qupdate(lgh_ctx *c, const double *S)
    const bool keep = !c->stress_store && a.erhs_q && a.force_e && c->v_snap;
    if (keep) { a.stressJinvT = nullptr; }
    // 3D up to Q4Q3: the form with row-owned contraction stages (lgh_qrows.hpp); LGH_Q_FORM=0: the point form (A/B, tests)
-   const char *fenv = getenv("LGH_Q_FORM");
-   const bool rows = qrows_available(c) && !(fenv && fenv[0] == '0');
+   const bool rows = qupdate_form(c) == 1;
    const int rc = rows ? launch_qrows(c, a) : launch_q<QMODE_UPDATE>(c, a);
    // F^T v of this state's velocity block is now in c->erhs_q, F.1 in c->force_e_q; lgh_solve_energy compares the
    // velocity it is given with the one the product was formed from
@@ -32,6 +32,13 @@ int qupdate(lgh_ctx *c, const double *S)
       LGH_HIP_CHECK(hipMemcpyAsync(c->v_snap, S + c->H1V, sizeof(double) * (size_t)c->H1V, hipMemcpyDeviceToDevice, c->stream));
    }
    return rc;
+}
+
+// which form lgh_qupdate launches for this context: 1 = row form (lgh_qrows.hpp), 0 = point form (qpoint_kernel)
+int qupdate_form(lgh_ctx *c)
+{
+   const char *fenv = getenv("LGH_Q_FORM");
+   return (qrows_available(c) && !(fenv && fenv[0] == '0')) ? 1 : 0;
 }
 
 int interp_energy(lgh_ctx *c, int which, const double *vec, double *result)
