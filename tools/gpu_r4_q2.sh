@@ -13,8 +13,8 @@ python - <<'PY' > $O/summary.txt 2>&1
 import json
 for f in ("pipe", "grid0", "grid2", "point"):
     d = json.loads(open('gpurun_out/r4_q2/bench_%s.json' % f).read())
-    q = [v for k, v in d['kernels'].items() if k.startswith('qpoint')][0]
-    tq = [v for k, v in d['legs']['tg']['kernels'].items() if k.startswith('qpoint')][0]
+    q = [v for k, v in d['kernels'].items() if k.startswith(('qpoint', 'qrows'))][0]
+    tq = [v for k, v in d['legs']['tg']['kernels'].items() if k.startswith(('qpoint', 'qrows'))][0]
     print(f, 'c2 ms/step %.3f value %.1f qupdate us %.1f | tg ms/step %.2f value %.1f qupdate us %.1f' % (d['ms_per_step'], d['value'], q['mean_us'], d['legs']['tg']['ms_per_step'], d['legs']['tg']['value'], tq['mean_us']))
 PY
 cat $O/tests.log $O/summary.txt

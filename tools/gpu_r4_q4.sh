@@ -17,9 +17,9 @@ python - <<'PY' > $O/summary.txt 2>&1
 import json, re
 for f in (-1, 0, 3, 5, 7, 10):
     d = json.loads(open('gpurun_out/r4_q4/bench_%d.json' % f).read())
-    q = [v for k, v in d['kernels'].items() if k.startswith('qpoint')][0]
-    tq = [v for k, v in d['legs']['tg']['kernels'].items() if k.startswith('qpoint')][0]
-    dq = [v for k, v in d['legs']['c2dev']['kernels'].items() if k.startswith('qpoint')][0]
+    q = [v for k, v in d['kernels'].items() if k.startswith(('qpoint', 'qrows'))][0]
+    tq = [v for k, v in d['legs']['tg']['kernels'].items() if k.startswith(('qpoint', 'qrows'))][0]
+    dq = [v for k, v in d['legs']['c2dev']['kernels'].items() if k.startswith(('qpoint', 'qrows'))][0]
     fe = re.search(r'FETCH_SIZE\s+med=([0-9.e+]+)', open('gpurun_out/r4_q4/fetch_%d.txt' % f).read())
     print('swz %3d: c2 %.3f ms/step qupdate %.1f us | c2dev qupdate %.1f us | tg %.2f ms/step qupdate %.1f us | FETCH_SIZE %s KB' % (f, d['ms_per_step'], q['mean_us'], dq['mean_us'], d['legs']['tg']['ms_per_step'], tq['mean_us'], fe.group(1) if fe else None))
 PY

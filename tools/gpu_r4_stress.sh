@@ -9,9 +9,9 @@ python - <<'PY' > $O/summary.txt 2>&1
 import json
 for f in (0, 1):
     d = json.loads(open('gpurun_out/r4_stress/bench_store%d.json' % f).read())
-    q = [v for k, v in d['kernels'].items() if k.startswith('qpoint')][0]
-    tg = d['legs']['tg']; tq = [v for k, v in tg['kernels'].items() if k.startswith('qpoint')][0]
-    c3 = d['legs']['c3']; cq = [v for k, v in c3['kernels'].items() if k.startswith('qpoint')][0]
+    q = [v for k, v in d['kernels'].items() if k.startswith(('qpoint', 'qrows'))][0]
+    tg = d['legs']['tg']; tq = [v for k, v in tg['kernels'].items() if k.startswith(('qpoint', 'qrows'))][0]
+    c3 = d['legs']['c3']; cq = [v for k, v in c3['kernels'].items() if k.startswith(('qpoint', 'qrows'))][0]
     print('store %d: c2 %.3f ms/step value %.1f qupdate %.1f us | tg %.2f ms/step value %.1f qupdate %.1f us | c3 %.2f value %.1f qupdate %.1f | e %.12e' % (
         f, d['ms_per_step'], d['value'], q['mean_us'], tg['ms_per_step'], tg['value'], tq['mean_us'], c3['ms_per_step'], c3['value'], cq['mean_us'], d['config']['e_norm']))
 PY
