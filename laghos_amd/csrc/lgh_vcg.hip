@@ -1760,8 +1760,11 @@ int vcg_k1_form(lgh_ctx *c)
    // Default at Q3Q2 from kSlabMinElements zones per rank: 40.6 vs 48.5 us per launch at 32^3 zones, 316 vs 383 at 64^3
    // (profiles/README.md); smaller meshes do not fill its one workgroup per CU.
    if (c->kid == 0x346 && c->vcg_variant < 0 && c->NE >= kSlabMinElements && vcg_slab_available(c)) { return 4; }
-   // default everywhere else when the mass data is compact on a tensor-product rule: the Kronecker form (vcg_apply_kron)
-   if ((c->vcg_variant < 0 || c->vcg_variant == 5) && c->M1h && c->w1d)
+   // default at D1D >= 5 when the mass data is compact on a tensor-product rule: the Kronecker form (vcg_apply_kron;
+   // config 5: 438 against 585 us).  At Q3Q2 the plane form stays the default below the slab threshold (32^3 zones:
+   // plane 49.9, generic Kronecker 55.3 us - its LDS stages and one-node gathers cost more than the FMAs it saves,
+   // profiles/r4_k1_forms.txt); LGH_VCG_VARIANT=5 selects it at any order (tests)
+   if (((c->vcg_variant < 0 && c->D1D >= 5) || c->vcg_variant == 5) && c->M1h && c->w1d)
    {
       const double *Dq, *Se;
       int dqs = 1;

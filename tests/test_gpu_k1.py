@@ -25,6 +25,11 @@ K1_CASES = [
     ("Q3Q2-16-slab", "box01_hex", 0, 3, 2, "4", "slab"),      # ragged last set (sets of 5 elements)
     ("Q3Q2-16-plane", "box01_hex", 0, 3, 2, "2", "plane"),    # ragged last batch (batches of 13)
     ("Q3Q2-512-slab", "cube01_hex", 2, 3, 2, "4", "slab"),    # more sets than wavefronts of one workgroup
+    ("Q3Q2-64-kron", "cube01_hex", 1, 3, 2, "5", "kron"),
+    ("Q3Q2-16-kron", "box01_hex", 0, 3, 2, "5", "kron"),
+    ("Q2Q1-64-kron", "cube01_hex", 1, 2, 1, "5", "kron"),
+    ("Q1Q0-64-kron", "cube01_hex", 1, 1, 0, "5", "kron"),
+    ("Q4Q3-16-kron", "box01_hex", 0, 4, 3, "5", "kron"),
     ("Q2Q1-64-default", "cube01_hex", 1, 2, 1, None, "plane"),
     ("Q2Q1-64-column", "cube01_hex", 1, 2, 1, "0", "column"),
     ("Q1Q0-64-default", "cube01_hex", 1, 1, 0, None, "plane"),
@@ -64,7 +69,12 @@ def _run_case(prob, monkeypatch, variant, form, rank1, first):
     g, o = make_gpu(prob), make_oracle(prob)
     try:
         # (default dispatch with compact mass data on a tensor-product rule: the Kronecker form; the slab form applies it inside)
-        assert g.ctx.k1_form() == ("kron" if (variant is None and rank1 and form == "plane" and os.environ.get("LGH_MASS_KRON") != "0") else form)
+        kron_ok = rank1 and os.environ.get("LGH_MASS_KRON") != "0"
+        if variant == "5":
+            expect = "kron" if kron_ok else "plane"  # (no compact data: nothing to take the Kronecker product of)
+        else:
+            expect = "kron" if (variant is None and kron_ok and form == "plane" and prob.D1D >= 5) else form
+        assert g.ctx.k1_form() == expect
         N = prob.N
         r = seeded(3 * N, 101)
         d_old = seeded(3 * N, 102)
