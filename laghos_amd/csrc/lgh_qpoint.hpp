@@ -63,7 +63,9 @@ __device__ __forceinline__ double smooth_step_01(double x, double eps)
 
 // The point-wise body: QUpdateBody (laghos_solver.cpp:1042-1168).  J and dV are
 // column-major [c + DIM*d] = d u_c / d xi_d.  Returns this point's dt candidate.
-template <int DIM>
+// VISC = false: instantiation without the artificial-viscosity branch (problems that run with visc off: 3D
+// Taylor-Green) - no eigen-decomposition in the code, a register budget of its own (lgh_qrows.hpp)
+template <int DIM, bool VISC = true>
 __device__ __forceinline__ double qpoint_body(const QArgs &a, const int e, const size_t eq,
                                               const double weight, const double *J, const double *dV,
                                               const double e_val, const size_t plane,
@@ -84,7 +86,7 @@ __device__ __forceinline__ double qpoint_body(const QArgs &a, const int e, const
 #pragma unroll
    for (int d = 0; d < DIM; d++) { stress[d * DIM + d] = -P; }
    double visc_coeff = 0.0;
-   if (a.visc)
+   if (VISC && a.visc)
    {
       sm::matmul<DIM>(dV, Jinv, sgrad_v);
       double vorticity_coeff = 1.0;

@@ -76,8 +76,14 @@ template <int N> __device__ __forceinline__ void row_load(const double *__restri
    for (int i = 0; i < N; i++) { v[i] = p[i]; }
 }
 
-template <int D, int Q, int L>
-__global__ void __launch_bounds__(Q *Q *Q)
+// MINW = 4: the same code under a cap of 128 registers (four workgroups per CU at Q3Q2 instead of three), launched for
+// contexts that run WITHOUT artificial viscosity (3D Taylor-Green).  The cap costs the full body 27 spilled registers,
+// and the register allocator places them in and around the viscosity branch - the one part such a context never
+// executes: 64^3 TG 3.42 -> 3.10 ms per call.  With viscosity the same build loses (614 -> 694 us at C2), and an
+// instantiation WITHOUT the branch needs more registers, not fewer (177 uncapped; capped it spills 49 into code that
+// runs: 5.10 ms) - profiles/r4_q_occupancy.txt.  So: one source, two register budgets, chosen by a.visc.
+template <int D, int Q, int L, int MINW>
+__global__ void __launch_bounds__(Q *Q *Q, MINW)
 qrows_kernel(const QArgs a)
 {
    using S = QRows<D, Q, L>;
@@ -363,18 +369,24 @@ static bool qrows_available(const lgh_ctx *c)
    }
    return false;
 }
-static int launch_qrows(lgh_ctx *c, const QArgs &a)
+template <int MINW6> static int launch_qrows_w(lgh_ctx *c, const QArgs &a)
 {
    switch (c->kid)
    {
-      case 0x322: hipLaunchKernelGGL((qrows_kernel<2, 2, 1>), dim3(c->NE), dim3(8), 0, c->stream, a); break;
-      case 0x334: hipLaunchKernelGGL((qrows_kernel<3, 4, 2>), dim3(c->NE), dim3(64), 0, c->stream, a); break;
-      case 0x346: hipLaunchKernelGGL((qrows_kernel<4, 6, 3>), dim3(c->NE), dim3(216), 0, c->stream, a); break;
-      case 0x358: hipLaunchKernelGGL((qrows_kernel<5, 8, 4>), dim3(c->NE), dim3(512), 0, c->stream, a); break;
+      case 0x322: hipLaunchKernelGGL((qrows_kernel<2, 2, 1, 1>), dim3(c->NE), dim3(8), 0, c->stream, a); break;
+      case 0x334: hipLaunchKernelGGL((qrows_kernel<3, 4, 2, 1>), dim3(c->NE), dim3(64), 0, c->stream, a); break;
+      case 0x346: hipLaunchKernelGGL((qrows_kernel<4, 6, 3, MINW6>), dim3(c->NE), dim3(216), 0, c->stream, a); break;
+      case 0x358: hipLaunchKernelGGL((qrows_kernel<5, 8, 4, 1>), dim3(c->NE), dim3(512), 0, c->stream, a); break;
       default: return unknown_kernel(c->kid);
    }
    LGH_HIP_CHECK(hipGetLastError());
    return LGH_OK;
+}
+static int launch_qrows(lgh_ctx *c, const QArgs &a)
+{
+   const char *oenv = getenv("LGH_Q_OCC4"); // A/B: 0 = the three-wavefront build for every context, 1 = the four-wavefront build
+   const bool w4 = oenv ? oenv[0] == '1' : !a.visc;
+   return w4 ? launch_qrows_w<4>(c, a) : launch_qrows_w<1>(c, a);
 }
 
 } // namespace lgh

@@ -879,6 +879,7 @@ KERNEL_SWITCHES = [
     ((4, 3), {"LGH_MASS_KRON": "0"}, "tol"),
     ((5, 4), {"LGH_MASS_KRON": "0"}, "tol"),
     ((3, 2), {"LGH_MASS_KRON": "0", "LGH_VCG_VARIANT": "4"}, "tol"),
+    ((3, 2), {"LGH_Q_OCC4": "1"}, "bits"),  # the 128-register build of the row form (what contexts without viscosity get): same operations
     ((3, 2), {"LGH_Q_FORM": "0"}, "tol"),   # the point form of the quadrature update instead of the row form (lgh_qrows.hpp)
     ((4, 3), {"LGH_Q_FORM": "0"}, "tol"),
     ((3, 2), {"LGH_Q_FORM": "0", "LGH_FUSED_FTV": "0", "LGH_FUSED_F1": "0"}, "tol"),
