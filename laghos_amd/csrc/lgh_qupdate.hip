@@ -19,8 +19,8 @@ int qupdate(lgh_ctx *c, const double *S)
    const bool keep = !c->stress_store && a.erhs_q && a.force_e && c->v_snap;
    if (keep) { a.stressJinvT = nullptr; }
    // 3D up to Q4Q3: the form with row-owned contraction stages (lgh_qrows.hpp); LGH_Q_FORM=0: the point form (A/B, tests)
-   const bool rows = qupdate_form(c) == 1;
-   const int rc = rows ? launch_qrows(c, a) : launch_q<QMODE_UPDATE>(c, a);
+   const int form = qupdate_form(c);
+   const int rc = (form == 1) ? launch_qrows(c, a) : launch_q<QMODE_UPDATE>(c, a);
    // F^T v of this state's velocity block is now in c->erhs_q, F.1 in c->force_e_q; lgh_solve_energy compares the
    // velocity it is given with the one the product was formed from
    c->qgen++;
