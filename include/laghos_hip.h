@@ -158,7 +158,8 @@ int lgh_set_fused_forces(lgh_ctx *ctx, int on);
  * does not write stressJinvT (3D, force fusion on); every reader then refuses with LGH_ERR_ARG instead of using stale
  * data - lgh_force_mult, lgh_force_mult_transpose, lgh_solve_velocity for a vector other than one; a SolveEnergy for a
  * velocity other than the state's (RK2Avg) turns its right-hand side into NaN on the device and the next
- * lgh_get_dt_est returns LGH_ERR_ARG.  Requesting lgh_qdata_stressJinvT() hands the array to the caller as before.
+ * lgh_get_dt_est returns LGH_ERR_ARG.  lgh_qdata_stressJinvT() still returns the array (for inspection), but planes
+ * nobody wrote do not become current by asking for them.
  * Default on = 1 (the reference's behaviour); a change takes effect with the next lgh_qupdate. */
 int lgh_qupdate_store_stress(lgh_ctx *ctx, int on);
 int lgh_qupdate_stores_stress(lgh_ctx *ctx, int *on);

@@ -483,7 +483,10 @@ double *lgh_qdata_stressJinvT(lgh_ctx *c)
 {
    // the caller may write through this pointer: F^T v and F.1 of the fused update no longer belong to it
    invalidate_fused(c);
-   c->stress_current = 1; // (whatever the caller puts there is what the force kernels read from now on)
+   // default mode: whatever the caller puts there is what the force kernels read from now on.  With the stress kept in
+   // registers (explicit opt-in) a request for the pointer does not turn planes nobody wrote into current data: the
+   // readers keep refusing until lgh_qupdate_store_stress(ctx, 1) and an update
+   if (c->stress_store) { c->stress_current = 1; }
    return c->stressJinvT;
 }
 // The stress of the current quadrature data is in memory (readers of stressJinvT call this first).

@@ -240,7 +240,8 @@ static int shm_open_group(const char unique_id[128], int nranks, int rank, std::
       {
          fd = shm_open(g->name.c_str(), O_RDWR, 0600);
          struct stat st;
-         if (fd >= 0 && fstat(fd, &st) == 0 && (size_t)st.st_size >= g->bytes) { break; }
+         // (the size is rank 0's: its LGH_SHM_MB decides, whatever this rank's environment says)
+         if (fd >= 0 && fstat(fd, &st) == 0 && (size_t)st.st_size >= off_msg) { g->bytes = (size_t)st.st_size; break; }
          if (fd >= 0) { close(fd); fd = -1; }
          if (std::chrono::steady_clock::now() - t0 > shm_timeout()) { set_error("shm transport: %s did not appear (rank 0 missing?)", g->name.c_str()); return LGH_ERR_COMM; }
          usleep(2000);

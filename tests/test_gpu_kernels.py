@@ -581,6 +581,9 @@ def test_stress_kept_in_registers():
         with pytest.raises(LghError, match="velocity other than the state"):
             ctx.get_dt_est()
         assert np.array_equal(np.asarray(ctx.stressJinvT), marker), "the planes must not have been written"
+        # looking at the array does not make planes nobody wrote current: the readers still refuse
+        with pytest.raises(LghError, match="kept in registers"):
+            ctx.force_mult(one, y)
         # back on: the next update writes them again
         ctx.qupdate_store_stress(1)
         g.reset_quadrature_data()
