@@ -420,7 +420,7 @@ static int create_impl(const lgh_config *cfg, lgh_ctx *c, const int kid)
    LGH_TRY(dev_alloc_zero(&c->tickets, 4 * (size_t)kTicketSlot));
    LGH_TRY(dev_alloc_zero(&c->cgs, 1));
    LGH_TRY(dev_alloc_zero(&c->scal, 16));
-   LGH_HIP_CHECK(hipHostMalloc((void **)&c->host_pinned, 64 * sizeof(double), hipHostMallocDefault));
+   LGH_HIP_CHECK(hipHostMalloc((void **)&c->host_pinned, 96 * sizeof(double), hipHostMallocDefault));
    LGH_HIP_CHECK(hipEventCreate(&c->timers.ev[0]));
    LGH_HIP_CHECK(hipEventCreate(&c->timers.ev[1]));
    const double inf = std::numeric_limits<double>::infinity();

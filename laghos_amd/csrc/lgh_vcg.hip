@@ -1152,13 +1152,14 @@ __global__ void vcg_init_finish_k(VcgScalars *s)
    }
    s->all_done = all;
 }
-__global__ void vcg_set_tol_k(VcgScalars *s, double rel_tol2, long long *limbs)
+__global__ void vcg_set_tol_k(VcgScalars *s, double rel_tol2, long long *limbs, long long *rzl)
 {
    if (limbs) { for (int i = 0; i < 2 * kLimbWords + 8 * 16; i++) { limbs[i] = 0; } } // accumulators and the set counters behind them
+   if (rzl) { for (int i = 0; i < 3 * kLimbWords; i++) { rzl[i] = 0; } }
    s->rel_tol2 = rel_tol2;
    s->all_done = 0;
    s->first = 1;
-   for (int c = 0; c < kVC; c++) { s->done[c] = 0; s->iters[c] = 0; s->nupd[c] = 0; s->alpha_last[c] = 0.0; }
+   for (int c = 0; c < kVC; c++) { s->done[c] = 0; s->iters[c] = 0; s->nupd[c] = 0; s->alpha_last[c] = 0.0; s->alpha_hist[0][c] = s->alpha_hist[1][c] = 0.0; s->rzh[0][c] = s->rzh[1][c] = 0.0; }
 }
 // Several ranks: the host enqueues the iteration count of the previous solve without looking at the flags,
 // so a few launches may follow convergence.  Their kernels return at once, but the exchanges between them
@@ -1181,6 +1182,21 @@ __global__ void vcg_update_finish_k(VcgScalars *s, int iter)
       all = all && s->done[c];
    }
    s->all_done = all;
+}
+
+// rz_limbs mode: the outcome of the last enqueued iteration `last`, committed for the host (what workgroup 0 of
+// K1(last + 1) would write)
+__global__ void vcg_rz_finish_k(VcgScalars *s, const long long *rzl, const int last)
+{
+   double cur[kVC];
+   bool dn[kVC];
+   for (int k = 0; k < kVC; k++)
+   {
+      const double before = (last > 1) ? s->rzh[(last - 1) & 1][k] : s->rz[k];
+      cur[k] = exact_fold(rzl + (last % 3) * kLimbWords, k, exact_scale(before));
+      dn[k] = s->done[k] != 0 || vcg_rz_converged(last + 1, cur[k], s->r0[k]);
+   }
+   vcg_rz_commit(s, last + 1, cur, dn);
 }
 
 // ---- K2: per node and component: A d = sum of element contributions, ess rows,
@@ -1307,8 +1323,18 @@ vcg_update_p_k(const VcgArgs a)
    const int n0 = a.nstart[w], n1 = a.nstart[w + 1];
    bool todo[kVC];
    double alpha[kVC], alpha_prev[kVC], beta[kVC], den[kVC];
+   // rz_limbs mode (lgh_vcg.hpp): (r, z) of the last two iterations as workgroup 0 of K1 left them
+   double rzc[kVC], rzp[kVC];
+   int rzE[kVC] = {0, 0, 0};
 #pragma unroll
-   for (int k = 0; k < kVC; k++) { den[k] = (a.den_limbs == 1) ? exact_den(a.limbs + (it & 1) * kLimbWords, k, a.s->rz[k]) : a.s->den[k]; }
+   for (int k = 0; k < kVC; k++)
+   {
+      rzc[k] = (a.rzl && it > 1) ? a.s->rzh[(it - 1) & 1][k] : a.s->rz[k];
+      rzp[k] = a.rzl ? a.s->rzh[it & 1][k] : a.s->rz_prev[k]; // (only looked at from the second iteration on)
+      rzE[k] = exact_scale(rzc[k]);
+   }
+#pragma unroll
+   for (int k = 0; k < kVC; k++) { den[k] = (a.den_limbs == 1) ? exact_den(a.limbs + (it & 1) * kLimbWords, k, rzc[k]) : a.s->den[k]; }
    if (a.den_limbs == 1 && blockIdx.x == 0 && tid < kLimbWords) { a.limbs[((it + 1) & 1) * kLimbWords + tid] = 0; } // the set of the next K1
 #pragma unroll
    for (int k = 0; k < kVC; k++)
@@ -1317,9 +1343,18 @@ vcg_update_p_k(const VcgArgs a)
       if (a.den_limbs == 1 && den[k] == 0.0) { todo[k] = false; } // breakdown, as upstream (marked below)
       // (several ranks: breakdown is looked at here, after the sum of (d, A d) over the ranks - vcg_pending_den)
       if (a.multi && todo[k] && vcg_pending_den(a.s, k, blockIdx.x == 0 && tid == 0)) { todo[k] = false; }
-      alpha[k] = todo[k] ? a.s->rz[k] / den[k] : 0.0;
-      alpha_prev[k] = todo[k] ? a.s->alpha_last[k] : 0.0;
-      beta[k] = (first || !todo[k]) ? 0.0 : a.s->rz[k] / a.s->rz_prev[k];
+      alpha[k] = todo[k] ? rzc[k] / den[k] : 0.0;
+      alpha_prev[k] = todo[k] ? (a.rzl ? a.s->alpha_hist[(it - 1) & 1][k] : a.s->alpha_last[k]) : 0.0;
+      beta[k] = (first || !todo[k]) ? 0.0 : rzc[k] / rzp[k];
+   }
+   if (a.rzl && !(todo[0] || todo[1] || todo[2]))
+   {
+      // nothing iterates any more (launches enqueued past convergence): only the bookkeeping of a breakdown is left
+      if (blockIdx.x == 0 && tid == 0)
+      {
+         for (int k = 0; k < kVC; k++) { if (!a.s->done[k] && den[k] == 0.0) { a.s->done[k] = 1; } }
+      }
+      return;
    }
    const bool xload = XU && it > 2;
    const unsigned rowb = 4u * (unsigned)a.N, compb = 8u * (unsigned)a.N;
@@ -1439,6 +1474,60 @@ vcg_update_p_k(const VcgArgs a)
             }
          }
       }
+   }
+   if (a.rzl)
+   {
+      // no last workgroup: the share of (r, z) of this workgroup into set it % 3 (exact limbs, fire-and-forget atomics);
+      // the next kernels fold it.  Workgroup 0 leaves what K2 of the next iteration and the host read.
+      __shared__ long long redi[NT / 64][kVC * kLimbs];
+      __shared__ int redbad[NT / 64];
+      const int lane = tid & 63, wid = tid >> 6;
+      bool bad = false;
+#pragma unroll
+      for (int k = 0; k < kVC; k++)
+      {
+         long long acc[kLimbs] = {0, 0, 0, 0};
+         if (todo[k]) { bad = bad || !exact_add(acc, part[k], rzE[k]); }
+#pragma unroll
+         for (int j = 0; j < kLimbs; j++)
+         {
+            const long long tot = wave_sum_i64(acc[j]);
+            if (lane == 0) { redi[wid][kLimbs * k + j] = tot; }
+         }
+      }
+      const bool anybad = __any(bad);
+      if (lane == 0) { redbad[wid] = anybad ? 1 : 0; }
+      __syncthreads();
+      long long *L = a.rzl + (it % 3) * kLimbWords;
+      if (tid < kVC * kLimbs)
+      {
+         long long sum = 0;
+#pragma unroll
+         for (int w = 0; w < NT / 64; w++) { sum += redi[w][tid]; }
+         if (sum != 0) { (void)__hip_atomic_fetch_add(&L[(blockIdx.x % kLimbShards) * (kVC * kLimbs) + tid], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+      }
+      if (tid == kVC * kLimbs)
+      {
+         int b = 0;
+#pragma unroll
+         for (int w = 0; w < NT / 64; w++) { b |= redbad[w]; }
+         if (b) { (void)__hip_atomic_fetch_or(&L[kLimbShards * kVC * kLimbs], 1LL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+      }
+      if (blockIdx.x == 0 && tid == 0)
+      {
+         VcgScalars *s = a.s;
+         s->first = 0;
+         for (int k = 0; k < kVC; k++)
+         {
+            if (s->done[k]) { continue; }
+            s->den[k] = den[k];
+            if (den[k] == 0.0) { s->done[k] = 1; continue; } // breakdown, as upstream
+            s->alpha_hist[it & 1][k] = alpha[k]; // (K2 of the next iteration: the deferred update of x)
+            s->alpha_last[k] = alpha[k];         // (vcg_xfix_k after the solve)
+            s->nupd[k] = it;
+         }
+      }
+      return;
    }
    double bp[kVC], total[kVC];
    block_sum3(part[0], part[1], part[2], red, bp);
@@ -1662,6 +1751,7 @@ struct VcgAux
    unsigned *mapb = nullptr; // element -> node map as byte offsets into a node vector: vcg_apply_mfma346
    int map_xrows = 0;        // the nodes of every x-row of every element are consecutive (vcg_apply_slab346 then loads rows, not nodes)
    long long *limbs = nullptr; // exact accumulators of (d, A d), 2 parities (lgh_vcg.hpp)
+   long long *rzl = nullptr;   // exact accumulators of (r, z), 3 sets (rz_limbs mode)
    int grid2 = 0;
 };
 void vcg_free(lgh_ctx *c)
@@ -1675,6 +1765,7 @@ void vcg_free(lgh_ctx *c)
    (void)hipFree(x->ellf);
    (void)hipFree(x->mapb);
    (void)hipFree(x->limbs);
+   (void)hipFree(x->rzl);
    delete x;
    c->vcg_aux = nullptr;
 }
@@ -1866,6 +1957,8 @@ static int vcg_prepare(lgh_ctx *c, double *B, double *X, double rel_tol, VcgPlan
          x->map_xrows = (h == 0) ? 1 : 0;
          LGH_HIP_CHECK(hipMalloc((void **)&x->limbs, (2 * kLimbWords + 8 * 16 + 32 * 4096) * sizeof(long long)));
          LGH_HIP_CHECK(hipMemset(x->limbs, 0, (2 * kLimbWords + 8 * 16 + 32 * 4096) * sizeof(long long)));
+         LGH_HIP_CHECK(hipMalloc((void **)&x->rzl, 3 * kLimbWords * sizeof(long long)));
+         LGH_HIP_CHECK(hipMemset(x->rzl, 0, 3 * kLimbWords * sizeof(long long)));
       }
       LGH_HIP_CHECK(hipStreamSynchronize(nullptr)); // the fills run asynchronously on the null stream
    }
@@ -1876,7 +1969,14 @@ static int vcg_prepare(lgh_ctx *c, double *B, double *X, double rel_tol, VcgPlan
    VcgScalars *ds = (VcgScalars *)c->vcg_s;
    // exact accumulators of (d, A d): slab-form K1 with the bounded-grid K2 (LGH_SLAB_EXACT=0: ticketed fold)
    long long *limbs = (c->slab_exact && k2p && k1form == 4) ? aux->limbs : nullptr;
-   hipLaunchKernelGGL(vcg_set_tol_k, dim3(1), dim3(1), 0, c->stream, ds, rel_tol * rel_tol, limbs);
+   // rz_limbs mode: one rank, exact accumulators with the deferred fold (LGH_RZ_LIMBS=0: the ticketed fold of (r, z) in K2)
+   const char *rzenv = getenv("LGH_RZ_LIMBS");
+   long long *rzl = (limbs && !multi && !(rzenv && rzenv[0] == '0')) ? aux->rzl : nullptr;
+   {
+      const char *e0 = getenv("LGH_SLAB_DEFER");
+      if (e0 && e0[0] == '0') { rzl = nullptr; } // (needs the deferred fold of (d, A d) as well)
+   }
+   hipLaunchKernelGGL(vcg_set_tol_k, dim3(1), dim3(1), 0, c->stream, ds, rel_tol * rel_tol, limbs, rzl);
 
    VcgArgs a;
    memset(&a, 0, sizeof(a));
@@ -1911,6 +2011,7 @@ static int vcg_prepare(lgh_ctx *c, double *B, double *X, double rel_tol, VcgPlan
    a.mapb = aux->mapb;
    a.map_xrows = aux->map_xrows;
    a.limbs = limbs;
+   a.rzl = rzl;
    a.queue = limbs ? (unsigned *)(limbs + 2 * kLimbWords) : nullptr;
    {
       const char *e0 = getenv("LGH_SLAB_DEFER"); // A/B: 0 = the last workgroup of K1 folds the accumulators (ticket), K2 reads the result
@@ -2027,7 +2128,7 @@ int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
    }
 
    VcgScalars *hs = (VcgScalars *)(c->host_pinned + 32);
-   static_assert(sizeof(VcgScalars) <= 32 * sizeof(double), "pinned staging too small");
+   static_assert(sizeof(VcgScalars) <= 64 * sizeof(double), "pinned staging too small");
    int it = 0;
    // first chunk = iteration count of the previous velocity solve (see cg_solve)
    int chunk = c->vcg_last > 0 ? c->vcg_last : 8;
@@ -2041,6 +2142,7 @@ int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
       {
          // several ranks: the outcome of the last enqueued update is still pending (vcg_pending_update) - commit it
          if (multi && it > 0) { hipLaunchKernelGGL(vcg_update_finish_k, dim3(1), dim3(1), 0, c->stream, ds, it); }
+         if (a.rzl && it > 0) { hipLaunchKernelGGL(vcg_rz_finish_k, dim3(1), dim3(1), 0, c->stream, ds, a.rzl, it); }
          LGH_HIP_CHECK(hipMemcpyAsync(hs, ds, sizeof(VcgScalars), hipMemcpyDeviceToHost, c->stream));
          LGH_HIP_CHECK(hipStreamSynchronize(c->stream));
          if (hs->all_done || it >= max_iter) { break; }
@@ -2162,6 +2264,17 @@ int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
    return LGH_OK;
 }
 
+__global__ void vcg_test_put_rz_k(long long *set, double v0, double v1, double v2, double s0, double s1, double s2)
+{
+   const double v[kVC] = {v0, v1, v2}, sc[kVC] = {s0, s1, s2};
+   for (int k = 0; k < kVC; k++)
+   {
+      long long acc[kLimbs] = {0, 0, 0, 0};
+      const bool ok = exact_add(acc, v[k], exact_scale(sc[k]));
+      for (int j = 0; j < kLimbs; j++) { set[kLimbs * k + j] = acc[j]; }
+      if (!ok) { set[kLimbShards * kVC * kLimbs] = 1; }
+   }
+}
 // Test hook (lgh_test_vcg_k1): ONE launch of K1, in whichever form vcg_solve dispatches for this context, exactly as
 // the solve would launch it in its first iteration (first != 0: d = r/diag) or in a later one (d = r/diag + beta d_old
 // with beta = rz / rz_prev), on the caller's vectors.  Returns what K1 hands to K2: the element contributions
@@ -2186,7 +2299,18 @@ int vcg_test_k1(lgh_ctx *c, const double *r, const double *d_old, const double r
    memset(&h, 0, sizeof(h));
    for (int k = 0; k < kVC; k++) { h.rz[k] = rz[k]; h.rz_prev[k] = rz_prev[k]; }
    h.first = first ? 1 : 0;
+   if (a.rzl && !first)
+   {
+      // rz_limbs mode: the second iteration takes (r, z) of the first out of set 1 of the exact accumulators and the
+      // one before (which also fixes the scale of that set) out of the scalars
+      for (int k = 0; k < kVC; k++) { h.rzh[0][k] = rz_prev[k]; }
+   }
    LGH_HIP_CHECK(hipMemcpy(ds, &h, sizeof(h), hipMemcpyHostToDevice));
+   if (a.rzl && !first)
+   {
+      hipLaunchKernelGGL(vcg_test_put_rz_k, dim3(1), dim3(1), 0, c->stream, a.rzl + 1 * kLimbWords, rz[0], rz[1], rz[2], rz_prev[0], rz_prev[1], rz_prev[2]);
+      LGH_HIP_CHECK(hipGetLastError());
+   }
    a.iter = first ? 1 : 2;
    a.partials = c->vcg_partials + (size_t)kVC * c->vcg_stride;
    a.ticket = c->vcg_tickets + kTicketSlot;

@@ -18,6 +18,9 @@ struct VcgScalars
    int done[kVC], iters[kVC], first;
    int all_done, pad;
    int nupd[kVC], pad2;    // vcg_update_p_k: iteration of that update (x lags one update behind when it is odd)
+   double alpha_hist[2][kVC]; // rz_limbs mode: alpha of iteration it in [it & 1] - written by workgroup 0 of K2(it) while other
+                              // workgroups of the same launch may still be reading the alpha of it - 1 out of the other row
+   double rzh[2][kVC];        // rz_limbs mode: (r, z) after iteration j in [j & 1], written by workgroup 0 of K1(j + 1)
 };
 
 // Several ranks (see cg_pending_update, lgh_mass.hip): the sums of den and (r, z) over the ranks complete between
@@ -193,6 +196,7 @@ struct VcgArgs
    const unsigned *mapb;  // map as byte offsets into a node vector (8 * node): the matrix-core K1 (lgh_vcg_mfma.hip)
    int map_xrows;         // 1: the D1D nodes of every x-row of every element are consecutive node numbers (checked at set-up)
    unsigned *queue;       // slab-form K1, dynamic schedule: one set counter per XCD range, 128 bytes apart (zero between launches)
+   long long *rzl;        // rz_limbs mode: three sets of kLimbWords words, exact accumulators of (r, z) (see vcg_rz_commit), or nullptr
    long long *limbs;      // exact accumulators of (d, A d): two sets of kLimbWords words (slab-form K1), or nullptr (ticketed fold of workgroup partials)
    int den_limbs;         // 1: K1 only adds into set (iter & 1) of limbs - no ticket, no last workgroup; K2 folds the set itself (exact_den) and clears the other one
    const int *ell;
@@ -307,6 +311,79 @@ __device__ __forceinline__ double exact_den(const long long *__restrict__ set, c
    const long long bad = set[kLimbShards * kVC * kLimbs];
    return bad ? __builtin_nan("") : exact_value(l4, exact_scale(rz));
 }
+// the same with the scale given (the (r, z) sets of the rz_limbs mode use one scale per solve)
+__device__ __forceinline__ double exact_fold(const long long *__restrict__ set, const int k, const int E)
+{
+   long long l4[kLimbs];
+#pragma unroll
+   for (int j = 0; j < kLimbs; j++) { l4[j] = 0; }
+#pragma unroll
+   for (int sh = 0; sh < kLimbShards; sh++)
+   {
+#pragma unroll
+      for (int j = 0; j < kLimbs; j++) { l4[j] += set[sh * (kVC * kLimbs) + kLimbs * k + j]; }
+   }
+   const long long bad = set[kLimbShards * kVC * kLimbs];
+   return bad ? __builtin_nan("") : exact_value(l4, E);
+}
+
+// the same out of a wavefront's registers: lane l holds word l of the set (l <= kLimbShards * kVC * kLimbs: the flag word)
+__device__ __forceinline__ long long lane_word(const long long w, const int l)
+{
+   const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(unsigned long long)w, l);
+   const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)w >> 32), l);
+   return (long long)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ double exact_fold_lanes(const long long w, const int k, const int E)
+{
+   static_assert(kLimbShards * kVC * kLimbs < 64, "one word per lane");
+   long long l4[kLimbs];
+#pragma unroll
+   for (int j = 0; j < kLimbs; j++) { l4[j] = 0; }
+#pragma unroll
+   for (int sh = 0; sh < kLimbShards; sh++)
+   {
+#pragma unroll
+      for (int j = 0; j < kLimbs; j++) { l4[j] += lane_word(w, sh * (kVC * kLimbs) + kLimbs * k + j); }
+   }
+   const long long bad = lane_word(w, kLimbShards * kVC * kLimbs);
+   return bad ? __builtin_nan("") : exact_value(l4, E);
+}
+
+// ---- rz_limbs mode (one rank, slab K1 + bounded-grid K2, exact accumulators): K2 has no last workgroup either.
+// Round 4 measured what the ticketed fold of (r, z) at the end of K2 costs: two dependent atomic round trips and two
+// dependent reads behind the slowest workgroup (profiles/r4_k2_tail.txt).  Now every workgroup of K2(i) adds its
+// share of R_i = (r, z) after iteration i into set i % 3 of `rzl` (exact integer limbs, fire-and-forget atomics; scale
+// exact_scale(R_(i-1)), which both sides know), and K1(i + 1) folds that set: one wavefront per workgroup, the others
+// take the value from LDS - integers, so every workgroup gets the same bits and takes the same decisions:
+//   K1(i) folds set (i-1) % 3 -> R_(i-1); R_(i-2) comes from VcgScalars::rzh[(i-2) & 1]; workgroup 0 writes
+//   rzh[(i-1) & 1] = R_(i-1) and commits what K2(i) and the host read (done, iters, all_done) - values under which the
+//   predicate the other workgroups evaluate stays true; it also clears set i % 3 (last read by K1(i - 2));
+//   K2(i) reads R_(i-1), R_(i-2) and the flags from the scalars (complete: K1(i) has ended) and folds nothing;
+//   convergence of component k after iteration j = R_j <= r0[k];
+//   a one-thread kernel does what K1(last + 1) would do before the host looks (vcg_rz_finish_k).
+__device__ __forceinline__ bool vcg_rz_converged(const int it, const double cur, const double r0)
+{
+   return it > 1 && (cur < 0.0 || cur <= r0); // (as the last workgroup of the ticketed K2 decides)
+}
+// what workgroup 0 of K1(it) leaves for K2(it), the next K1 and the host; cur[k] = R_(it-1)
+__device__ __forceinline__ void vcg_rz_commit(VcgScalars *s, const int it, const double (&cur)[kVC], const bool (&done)[kVC])
+{
+   int all = 1;
+#pragma unroll
+   for (int k = 0; k < kVC; k++)
+   {
+      s->rzh[(it - 1) & 1][k] = cur[k];
+      if (!s->done[k])
+      {
+         __hip_atomic_store(&s->iters[k], it - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+         if (done[k]) { __hip_atomic_store(&s->done[k], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+      }
+      all = all && done[k];
+   }
+   if (all) { __hip_atomic_store(&s->all_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+}
+
 // 64-bit integer sum over the 64 lanes of a full wavefront (DPP, as wave_sum); the total is returned in every lane
 __device__ __forceinline__ long long wave_sum_i64(long long v)
 {

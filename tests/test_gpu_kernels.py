@@ -665,19 +665,22 @@ SLAB_SWITCHES = [
     {"LGH_SLAB_WIDE": "0"},
     {"LGH_SLAB_WPS": "1", "LGH_SLAB_WIDE": "0", "LGH_SLAB_DYN": "0"},
     {"LGH_SLAB_DEFER": "0"},
+    {"LGH_RZ_LIMBS": "0"},
     {"LGH_SLAB_STORE_WAIT": "1"},
     {"LGH_SLAB_YE_WIDE": "1"},
     {"LGH_SLAB_WPS": "2", "LGH_SLAB_WIDE": "0"},
 ]
 
 
-@pytest.mark.parametrize("switches", SLAB_SWITCHES, ids=lambda d: ",".join(f"{k[9:]}={v}" for k, v in d.items()))
+@pytest.mark.parametrize("switches", SLAB_SWITCHES, ids=lambda d: ",".join(f"{k.replace('LGH_SLAB_', '').replace('LGH_', '')}={v}" for k, v in d.items()))
 def test_slab_k1_switches(switches, monkeypatch):
     """Every A/B switch of the slab-form K1 (lgh_vcg_slab.hip) selects a different instantiation: one or two wavefronts
     per SIMD, row loads or node gathers, exact integer accumulation of (d, A d) or the ticketed fold, sets drawn from
     the workgroup's queue or assigned statically.  128 zones (26 sets: a ragged last set),
     distorted state, CG to 1e-14: the velocity part of dS/dt agrees with the oracle to the operator tolerance, and -
-    the sum being exact - the two schedules with exact accumulation give the same bits."""
+    the sums being exact - all schedules with exact accumulation give the same bits.  (r, z) is kept in exact
+    accumulators as well unless LGH_RZ_LIMBS=0 or the deferred fold of (d, A d) is off: those two fold (r, z) with the
+    ticketed reduction of K2, round it differently, and agree bit for bit with each other."""
     from oracle.fem import Problem
     prob = Problem(mesh="box01_hex", rs=1, order_v=3, order_e=2, problem=1)
     S = deformed_state(prob, seed=39)
@@ -707,7 +710,7 @@ def test_slab_k1_switches(switches, monkeypatch):
         g.close()
     assert rel_err(dS[H1V:2 * H1V], dS_o[H1V:2 * H1V]) < 1e-10
     if "LGH_SLAB_EXACT" not in switches:
-        key = "slab_exact_bits"
+        key = "slab_ticket_rz_bits" if ("LGH_SLAB_DEFER" in switches or "LGH_RZ_LIMBS" in switches) else "slab_exact_bits"
         ref = test_slab_k1_switches.__dict__.setdefault(key, dS[H1V:2 * H1V].copy())
         assert np.array_equal(ref, dS[H1V:2 * H1V]), "exact accumulation: the result must not depend on the schedule"
 
@@ -882,6 +885,7 @@ KERNEL_SWITCHES = [
     ((4, 3), {"LGH_MASS_KRON": "0"}, "tol"),
     ((5, 4), {"LGH_MASS_KRON": "0"}, "tol"),
     ((3, 2), {"LGH_MASS_KRON": "0", "LGH_VCG_VARIANT": "4"}, "tol"),
+    ((3, 2), {"LGH_RZ_LIMBS": "0", "LGH_VCG_VARIANT": "4"}, "tol"),  # (r, z) by the ticketed reduction of K2 instead of exact accumulators
     ((3, 2), {"LGH_Q_OCC4": "1"}, "bits"),  # the 128-register build of the row form (what contexts without viscosity get): same operations
     ((3, 2), {"LGH_Q_FORM": "0"}, "tol"),   # the point form of the quadrature update instead of the row form (lgh_qrows.hpp)
     ((4, 3), {"LGH_Q_FORM": "0"}, "tol"),
