@@ -453,7 +453,7 @@ vcg_apply_slab346(const VcgArgs a, const int nset)
 #define LGH_SLAB_STAMP(K_) do { if (TRACE == 2) { const unsigned long long c_now = clock64(); c_ph[K_] += c_now - c_prev; c_prev = c_now; } } while (0)
    auto body = [&](const double *__restrict__ sDcur, double *__restrict__ sDnxt) __attribute__((always_inline)) {
       const int e = ES * max(s0, 0) + el;
-      const bool act = (n < 15) && (e < a.NE) && mine && (!DYN || s0 >= 0);
+      const bool act = (n < 15) && (e < a.NE) && mine;
       const double actf = act ? 1.0 : 0.0;
       const double *sDp = sDcur + el * NQ + 9 * g; // this lane's nine (qx, qy) pairs: sDp[i + 36 qz]
       // next set: gathers and quadrature data now, the map of the one after
@@ -469,9 +469,12 @@ vcg_apply_slab346(const VcgArgs a, const int nset)
       load_map(DYN ? max(s2, 0) : s2, mn);
       LGH_SLAB_STAMP(0); // issue of the loads
       double o[16], dset = 0.0;
+      // (The body only runs with a set to contract: s0 >= 0 - the sets of a wavefront are a run of valid ones followed by
+      //  empty slots, see more().  Round 4: a `s0 < 0` path that only issued the loads was dead code, but the compiler
+      //  merged its pending loads into the wait counters of the live path and drained the gathers just issued - vmcnt(0) -
+      //  in front of the first contraction of every pass, profiles/r4_k1_spurious_waits.txt.)
       if (KRON)
       {
-         if (!DYN || s0 >= 0)
          {
             __builtin_amdgcn_sched_barrier(0);
             // x, then y with the 1-D mass tile on this lane's slab dz = g: w[dx + 4 dy]
@@ -543,14 +546,8 @@ vcg_apply_slab346(const VcgArgs a, const int nset)
             __builtin_amdgcn_sched_barrier(0);
             LGH_SLAB_STAMP(5);
          }
-         else
-         {
-            load_gather_part(1);
-            load_gather_part(2);
-            load_gather_part(3);
-         }
       }
-      else if (!DYN || s0 >= 0)
+      else
       {
       // Phase order is pinned (sched_barrier): with few wavefronts per SIMD the compiler would otherwise hoist every LDS
       // read and half the next phase above the current one and pay for it in register moves.
@@ -663,12 +660,6 @@ vcg_apply_slab346(const VcgArgs a, const int nset)
       // the loads of the next set are complete by now (wave 0 counts what is left of their latency): its direction;
       // the stores of this set go out behind them, so that no wait ever covers a store that has just been issued
       LGH_SLAB_STAMP(5); // backward y, x
-      } // (s0)
-      else
-      {
-         load_gather_part(1);
-         load_gather_part(2);
-         load_gather_part(3);
       }
       if (TRACE == 2)
       {
@@ -677,13 +668,12 @@ vcg_apply_slab346(const VcgArgs a, const int nset)
          c_wait += clock64() - c0;
       }
       __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): gathers, LDS-DMA and map of the next set (and the ticket)
-      if (!DYN || s1 >= 0) { convert(); }
+      convert(); // (an empty slot s1 < 0 has re-read set 0: finite values nobody uses)
 #pragma unroll
       for (int j = 0; j < 16; j += (WIDE ? 4 : 1)) { mo[j] = mn[j]; }
       __builtin_amdgcn_sched_barrier(0);
       LGH_SLAB_STAMP(6); // wait + direction of the next set
       // the slab of the E-vector: 16 contiguous doubles per lane, stored as whole lines by groups of eight lanes (above)
-      if (!DYN || s0 >= 0)
       {
          double *tl = RANK1 ? (sDb + wid * SBUF) : const_cast<double *>(sDcur); // (not RANK1: the data of this set has been used)
          v2d *wp = (v2d *)(tl + lane * TP);
@@ -738,7 +728,8 @@ vcg_apply_slab346(const VcgArgs a, const int nset)
          s2 += W;
       }
    };
-   auto more = [&]() -> bool { return DYN ? (s0 >= 0 || s1 >= 0 || s2 >= 0) : (s0 >= 0); };
+   // (DYN: the initial slots and the draws are monotone - once a slot is empty all later ones are - so s0 < 0 ends the loop)
+   auto more = [&]() -> bool { return s0 >= 0; };
    double *bcur = sDa + wid * SBUF, *bnxt = RANK1 ? bcur : sDb + wid * SBUF; // (RANK1: the weights stay in sDa, sDb is the exchange buffer of the stores)
    int n_pass = 0;
    while (more())
