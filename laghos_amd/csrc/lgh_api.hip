@@ -368,7 +368,7 @@ static int create_impl(const lgh_config *cfg, lgh_ctx *c, const int kid)
       env = getenv("LGH_SLAB_EXACT");
       c->slab_exact = (env && env[0] == '0') ? 0 : 1;
       env = getenv("LGH_SLAB_DYN");
-      c->slab_dyn = (env && env[0] == '0') ? 0 : 1;
+      c->slab_dyn = (env && env[0] == '0') ? 0 : (env && env[0] == '1') ? 1 : -1; // -1: by passes per wavefront (launch_vcg_slab)
    }
    for (int k = 0; k < 3; k++)
    {

@@ -907,7 +907,10 @@ void launch_vcg_slab(lgh_ctx *c, const VcgArgs &a)
    const int grid = std::min(ceil_div(nset, 4 * wps), ncu); // one workgroup of 4 wps wavefronts per CU
    const bool wide = c->slab_wide && a.map_xrows != 0;
    const bool exact = a.limbs != nullptr;
-   const bool dyn = exact && c->slab_dyn;
+   // Sets drawn from the workgroup's queue even out the wavefronts of a workgroup, which pays while a wavefront has few
+   // passes (32^3: 6.4 each, 30.6 against 31.6 us); with many, the static interleaved schedule - the whole grid sweeps
+   // through the mesh together - is ahead (64^3: 51 passes each, 210.8 against 222 us, profiles/r4_k1_forms.txt).
+   const bool dyn = exact && (c->slab_dyn < 0 ? nset <= 16 * grid * 4 * wps : c->slab_dyn != 0);
 #define LGH_SLAB_LAUNCH(SYM_, WPS_, TR_, WIDE_, EX_, DYN_) slab_launch<SYM_, WPS_, TR_, WIDE_, EX_, DYN_>(c, a, grid, nset)
 #define LGH_SLAB_LAUNCH2(SYM_, WPS_, TR_) do { if (wide && dyn) { LGH_SLAB_LAUNCH(SYM_, WPS_, TR_, true, true, true); } else if (wide && exact) { LGH_SLAB_LAUNCH(SYM_, WPS_, TR_, true, true, false); } \
                                                else if (wide) { LGH_SLAB_LAUNCH(SYM_, WPS_, TR_, true, false, false); } \
