@@ -1479,39 +1479,33 @@ vcg_update_p_k(const VcgArgs a)
    {
       // no last workgroup: the share of (r, z) of this workgroup into set it % 3 (exact limbs, fire-and-forget atomics);
       // the next kernels fold it.  Workgroup 0 leaves what K2 of the next iteration and the host read.
-      __shared__ long long redi[NT / 64][kVC * kLimbs];
-      __shared__ int redbad[NT / 64];
+      // (the workgroup's share as ONE double per component - a fixed tree: wave sums, then the eight wavefronts in
+      //  order - split into limbs by one thread per component: exactness is only needed ACROSS workgroups, whose
+      //  atomics arrive in any order.  Round 4, first version: every thread split its own partial and the limbs went
+      //  through twelve 64-bit wave sums - 0.5 us more per launch, profiles/r4_k2_tail.txt.)
       const int lane = tid & 63, wid = tid >> 6;
-      bool bad = false;
-#pragma unroll
-      for (int k = 0; k < kVC; k++)
-      {
-         long long acc[kLimbs] = {0, 0, 0, 0};
-         if (todo[k]) { bad = bad || !exact_add(acc, part[k], rzE[k]); }
-#pragma unroll
-         for (int j = 0; j < kLimbs; j++)
-         {
-            const long long tot = wave_sum_i64(acc[j]);
-            if (lane == 0) { redi[wid][kLimbs * k + j] = tot; }
-         }
-      }
-      const bool anybad = __any(bad);
-      if (lane == 0) { redbad[wid] = anybad ? 1 : 0; }
+      const double w0 = wave_sum(part[0], lane, 64), w1 = wave_sum(part[1], lane, 64), w2 = wave_sum(part[2], lane, 64);
+      if (lane == 0) { red[3 * wid + 0] = w0; red[3 * wid + 1] = w1; red[3 * wid + 2] = w2; }
       __syncthreads();
       long long *L = a.rzl + (it % 3) * kLimbWords;
-      if (tid < kVC * kLimbs)
+      if (tid < kVC)
       {
-         long long sum = 0;
+         double t = 0.0;
 #pragma unroll
-         for (int w = 0; w < NT / 64; w++) { sum += redi[w][tid]; }
-         if (sum != 0) { (void)__hip_atomic_fetch_add(&L[(blockIdx.x % kLimbShards) * (kVC * kLimbs) + tid], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-      }
-      if (tid == kVC * kLimbs)
-      {
-         int b = 0;
+         for (int w = 0; w < NT / 64; w++) { t += red[3 * w + tid]; }
+         const bool live = (tid == 0) ? todo[0] : (tid == 1) ? todo[1] : todo[2];
+         const int E = (tid == 0) ? rzE[0] : (tid == 1) ? rzE[1] : rzE[2];
+         long long acc[kLimbs] = {0, 0, 0, 0};
+         const bool bad = live && !exact_add(acc, t, E);
+         if (live && !bad)
+         {
 #pragma unroll
-         for (int w = 0; w < NT / 64; w++) { b |= redbad[w]; }
-         if (b) { (void)__hip_atomic_fetch_or(&L[kLimbShards * kVC * kLimbs], 1LL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            for (int j = 0; j < kLimbs; j++)
+            {
+               if (acc[j] != 0) { (void)__hip_atomic_fetch_add(&L[(blockIdx.x % kLimbShards) * (kVC * kLimbs) + kLimbs * tid + j], acc[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            }
+         }
+         if (bad) { (void)__hip_atomic_fetch_or(&L[kLimbShards * kVC * kLimbs], 1LL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
       }
       if (blockIdx.x == 0 && tid == 0)
       {
