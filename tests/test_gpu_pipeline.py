@@ -200,6 +200,29 @@ def test_full_size_sedov_steps(full_size):
     assert abs(e0 - 0.125) < 1e-12  # E0/2^dim (laghos.cpp:603-604)
 
 
+def test_64_cubed_schedules_agree(monkeypatch):
+    """64^3 zones of Q3Q2 Sedov (the `c3` leg of the bench; HBM-resident, 8x configs[1]): beyond 16 passes per wavefront
+    the slab K1 takes the static interleaved schedule instead of the workgroup queues (launch_vcg_slab).  Both
+    accumulate (d, A d) in exact integers and K2's (r, z) likewise, so a step through either must give the same bits -
+    and the queued one is what the 32^3 runs pin to the oracle.  One RK4 step plus the step the driver always adds;
+    energy conservation as in test_full_size_sedov_steps."""
+    from laghos_amd import hydro
+    from oracle.fem import Problem
+    prob = Problem(mesh="cube01_hex", rs=5, order_v=3, order_e=2, problem=1)
+    res = {}
+    for dyn in ("auto", "1", "0"):
+        if dyn == "auto":
+            monkeypatch.delenv("LGH_SLAB_DYN", raising=False)
+        else:
+            monkeypatch.setenv("LGH_SLAB_DYN", dyn)
+        res[dyn] = hydro.run(prob, max_steps=1, timers=False)
+    a, q, st = res["auto"], res["1"], res["0"]
+    assert a["steps"] == q["steps"] == st["steps"] >= 1
+    assert np.array_equal(a["S"], st["S"]), "64^3 dispatches the static schedule"
+    assert np.array_equal(q["S"], st["S"]), "exact accumulation: the schedule must not change a bit"
+    assert a["dt"] == q["dt"] and a["e_norm"] == q["e_norm"] and np.isfinite(a["e_norm"])
+
+
 def test_config2_full_size_vs_oracle():
     """BASELINE configs[1] at FULL size against the oracle, not only through size-independent properties: 3 RK4 steps
     of the 32^3 Q3Q2 Sedov problem from t = 0 on both sides (12 stages: QUpdate, both force products, three H1 PCG
