@@ -342,6 +342,18 @@ int lgh_mass_apply_E(lgh_ctx *ctx, int space, const double *x_E, double *y_E);
  * work vectors only. */
 int lgh_test_vcg_k1(lgh_ctx *ctx, const double *r, const double *d_old, const double rz[3], const double rz_prev[3],
                     int first, double *y_E, double den[3]);
+/* ONE launch of the node kernel K2 of the lockstep velocity solve (the kernel with the largest share of the step: the
+ * E -> L sum of K1's element contributions, essential rows, r -= alpha A d, d = r_old/diag + beta d, the deferred update
+ * of x, (r, r/diag)) exactly as the one-rank solve launches it in iteration it >= 1: y_E = 3 planes of NE*D1D^3
+ * (device) as lgh_test_vcg_k1 returns them; r, d, x: H1 vectors of 3 components (device), updated in place - d in: the
+ * direction of iteration it-1 (ignored for it = 1), d out: that of iteration it; den[c] = (d_c, A d_c) of this
+ * iteration, rz[c] / rz_prev[c] = (r, z) after iterations it-1 / it-2, alpha_prev[c] = alpha of iteration it-1 (host
+ * doubles).  rz_out[c] = (r, z) of the new residual.  *deferred_x = 1: the bounded-grid kernel ran - x is updated
+ * only in even iterations, with the terms of iterations it and it-1 (it = 2: x := both terms, the old content is not
+ * read); 0: the round-1 kernel (LGH_K2P=0), x += alpha d every iteration.  Single rank; synchronous. */
+int lgh_test_vcg_k2(lgh_ctx *ctx, int it, const double *y_E, double *r, double *d, double *x, const double den[3],
+                    const double rz[3], const double rz_prev[3], const double alpha_prev[3], double rz_out[3],
+                    int *deferred_x);
 /* halo pieces without the RCCL transport (tests emulate the exchange between
  * several contexts on one GPU): rank bookkeeping, pack into / combine from caller
  * buffers of 3*total doubles laid out as the send / receive buffers are. */

@@ -257,6 +257,15 @@ class Context:
                                        int(bool(first)), _ptr(y), _dbl(den)))
         return y.view(3, -1), den
 
+    def test_vcg_k2(self, it, y_E, r, d, x, den, rz, rz_prev, alpha_prev):
+        """One launch of the lockstep solve's K2 (lgh_test_vcg_k2); r, d, x are updated in place.
+        Returns ((r, z) of the new residual [3], deferred_x)."""
+        den, rz, rzp, al, out = _np_f64(den), _np_f64(rz), _np_f64(rz_prev), _np_f64(alpha_prev), np.zeros(3)
+        form = ctypes.c_int(-1)
+        check(self.lib.lgh_test_vcg_k2(self.h, int(it), _ptr(y_E), _ptr(r), _ptr(d), _ptr(x), _dbl(den), _dbl(rz), _dbl(rzp),
+                                       _dbl(al), _dbl(out), ctypes.byref(form)))
+        return out, bool(form.value)
+
     def mass_data_form(self):
         """'rank1' when the mass kernels read D[q, e] = W[q] s_e (one double per element), 'stored' otherwise."""
         f = ctypes.c_int(-1)

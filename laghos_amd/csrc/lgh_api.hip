@@ -1123,6 +1123,12 @@ int lgh_test_vcg_k1(lgh_ctx *c, const double *r, const double *d_old, const doub
    LGH_CHECK_ARG(c && r && (first || d_old) && rz && rz_prev && y_E && den);
    return vcg_test_k1(c, r, d_old, rz, rz_prev, first, y_E, den);
 }
+int lgh_test_vcg_k2(lgh_ctx *c, int it, const double *y_E, double *r, double *d, double *x, const double den[3], const double rz[3],
+                    const double rz_prev[3], const double alpha_prev[3], double rz_out[3], int *deferred_x)
+{
+   LGH_CHECK_ARG(c && it >= 1 && y_E && r && d && x && den && rz && rz_prev && alpha_prev && rz_out && deferred_x);
+   return vcg_test_k2(c, it, y_E, r, d, x, den, rz, rz_prev, alpha_prev, rz_out, deferred_x);
+}
 int lgh_force_mult_E(lgh_ctx *c, const double *sJit, const double *x_E, double *y_E)
 {
    LGH_CHECK_ARG(c && sJit && x_E && y_E);

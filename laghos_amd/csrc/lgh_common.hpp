@@ -433,6 +433,8 @@ constexpr int kYePad = 16; // doubles behind every Y_E plane of the CG; the firs
 bool vcg_available(const lgh_ctx *c);
 int vcg_test_k1(lgh_ctx *c, const double *r, const double *d_old, const double rz[3], const double rz_prev[3], int first,
                 double *YE_out, double den_out[3]); // one launch of K1 (test hook)
+int vcg_test_k2(lgh_ctx *c, int it, const double *YE_in, double *r, double *d, double *x, const double den[3], const double rz[3],
+                const double rz_prev[3], const double alpha_prev[3], double rz_out[3], int *deferred_x); // one launch of K2 (test hook)
 int vcg_k1_form(lgh_ctx *c); // 0 column, 2 plane, 3 matrix cores, 4 slab, -1 none
 // multi-rank: flags / list of the nodes shared with other ranks (nullptr / 0 without neighbours)
 void comm_shared_nodes(const lgh_ctx *c, const uint8_t **hmask, const int **sh_node, int *n_shared);

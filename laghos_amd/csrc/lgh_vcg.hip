@@ -2086,6 +2086,20 @@ static void vcg_launch_k1(lgh_ctx *c, const VcgPlan &plan, const VcgArgs &a)
    }
 }
 
+// one launch of K2 as the one-rank solve issues it in iteration `it` (a.iter, a.partials, a.ticket set by the caller):
+// the bounded-grid kernel (x updated every second iteration) or the round-1 kernel (LGH_K2P=0, unusual valence)
+static void vcg_launch_k2p(lgh_ctx *c, const VcgPlan &plan, const VcgArgs &a, const int it)
+{
+   kt_begin(c, LGH_KERNEL_CG_UPDATE_H1);
+   const char *uenv = getenv("LGH_K2_U"); // A/B: nodes per thread and pass (2: 182 VGPRs, one workgroup per CU resident)
+   const int u2 = (uenv && uenv[0] == '2') ? 1 : 0;
+#define LGH_K2P_LAUNCH(XU_, U_) hipLaunchKernelGGL((vcg_update_p_k<XU_, U_>), dim3(plan.aux->grid2), dim3(512), 0, c->stream, a)
+   if (it & 1) { if (u2) { LGH_K2P_LAUNCH(false, 2); } else { LGH_K2P_LAUNCH(false, 1); } }
+   else { if (u2) { LGH_K2P_LAUNCH(true, 2); } else { LGH_K2P_LAUNCH(true, 1); } }
+#undef LGH_K2P_LAUNCH
+   kt_end(c, LGH_KERNEL_CG_UPDATE_H1);
+}
+
 int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, int iters[3], const double *force_E)
 {
    if (!vcg_supported(c)) { return LGH_ERR_UNSUPPORTED; }
@@ -2156,16 +2170,7 @@ int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
          LGH_HIP_CHECK(hipGetLastError());
          a.partials = c->vcg_partials;
          a.ticket = c->vcg_tickets;
-         auto launch_k2p = [&]() {
-            kt_begin(c, LGH_KERNEL_CG_UPDATE_H1);
-            const char *uenv = getenv("LGH_K2_U"); // A/B: nodes per thread and pass (2: 182 VGPRs, one workgroup per CU resident)
-            const int u2 = (uenv && uenv[0] == '2') ? 1 : 0;
-#define LGH_K2P_LAUNCH(XU_, U_) hipLaunchKernelGGL((vcg_update_p_k<XU_, U_>), dim3(aux->grid2), dim3(512), 0, c->stream, a)
-            if (it & 1) { if (u2) { LGH_K2P_LAUNCH(false, 2); } else { LGH_K2P_LAUNCH(false, 1); } }
-            else { if (u2) { LGH_K2P_LAUNCH(true, 2); } else { LGH_K2P_LAUNCH(true, 1); } }
-#undef LGH_K2P_LAUNCH
-            kt_end(c, LGH_KERNEL_CG_UPDATE_H1);
-         };
+         auto launch_k2p = [&]() { vcg_launch_k2p(c, plan, a, it); };
          if (k2p && !multi) { launch_k2p(); }
          else if (!multi && c->t_deg <= 8)
          {
@@ -2320,6 +2325,65 @@ int vcg_test_k1(lgh_ctx *c, const double *r, const double *d_old, const double r
       den_out[k] = h.den[k];
       LGH_HIP_CHECK(hipMemcpy(YE_out + (size_t)k * nE, a.YE + (size_t)k * a.ye_stride, nE * sizeof(double), hipMemcpyDeviceToDevice));
    }
+   return LGH_OK;
+}
+
+// Test hook (lgh_test_vcg_k2): ONE launch of K2 - the node kernel of the lockstep solve, the largest kernel of the
+// step - as the one-rank solve issues it in iteration `it` (1: first, beta = 0; even: the launch that also updates x
+// with the terms of two iterations; odd > 1: x untouched), on the caller's vectors: the E-vector K1 would have
+// written (kVC planes of NE * ND), r, the old direction d and x (kVC * N each, updated in place), the scalars K1 and
+// the iteration before leave: (d, A d), (r, z) after iterations it-1 and it-2, alpha of iteration it-1.  Returns
+// (r, z) of the new residual as the solve would see it (ticketed fold, or the exact accumulators folded as the next
+// K1 does).  One rank only.
+int vcg_test_k2(lgh_ctx *c, int it, const double *YE_in, double *r, double *d, double *x, const double den[3],
+                const double rz[3], const double rz_prev[3], const double alpha_prev[3], double rz_out[3], int *deferred_x)
+{
+   if (!vcg_supported(c)) { set_error("lgh_test_vcg_k2: no lockstep solve for kernel 0x%x", c->kid); return LGH_ERR_UNSUPPORTED; }
+   if (c->multi != 0 || it < 1) { set_error("lgh_test_vcg_k2: single rank, it >= 1"); return LGH_ERR_ARG; }
+   VcgPlan plan;
+   int rc = vcg_prepare(c, nullptr, x, 0.0, plan);
+   if (rc) { return rc; }
+   VcgArgs &a = plan.a;
+   const size_t N = (size_t)c->N, nE = (size_t)c->NE * c->ND;
+   VcgScalars *ds = (VcgScalars *)c->vcg_s;
+   LGH_HIP_CHECK(hipMemcpyAsync(a.r, r, kVC * N * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+   LGH_HIP_CHECK(hipMemcpyAsync(a.d, d, kVC * N * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+   for (int k = 0; k < kVC; k++)
+   {
+      LGH_HIP_CHECK(hipMemcpyAsync(a.YE + (size_t)k * a.ye_stride, YE_in + (size_t)k * nE, nE * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+   }
+   LGH_HIP_CHECK(hipStreamSynchronize(c->stream)); // (vcg_set_tol_k has cleared the accumulators)
+   VcgScalars h;
+   memset(&h, 0, sizeof(h));
+   for (int k = 0; k < kVC; k++)
+   {
+      h.rz[k] = rz[k];
+      h.rz_prev[k] = rz_prev[k];
+      h.den[k] = den[k];
+      h.alpha_last[k] = alpha_prev[k];
+      h.rzh[(it - 1) & 1][k] = rz[k];
+      h.rzh[it & 1][k] = rz_prev[k];
+      h.alpha_hist[(it - 1) & 1][k] = alpha_prev[k];
+      h.nupd[k] = it - 1;
+   }
+   h.first = (it == 1) ? 1 : 0;
+   LGH_HIP_CHECK(hipMemcpy(ds, &h, sizeof(h), hipMemcpyHostToDevice));
+   a.den_limbs = 0; // (d, A d) comes from the scalars here - the accumulators K1 fills are its own test's subject
+   *deferred_x = plan.k2p ? 1 : 0;
+   a.iter = it;
+   a.partials = c->vcg_partials;
+   a.ticket = c->vcg_tickets;
+   if (plan.k2p) { vcg_launch_k2p(c, plan, a, it); }
+   else if (c->t_deg <= 8) { hipLaunchKernelGGL((vcg_update_k<true, 8>), dim3(ceil_div((long)N, 256)), dim3(256), 0, c->stream, a); }
+   else { set_error("lgh_test_vcg_k2: unusual valence (the unfused gather runs in the solve)"); return LGH_ERR_UNSUPPORTED; }
+   LGH_HIP_CHECK(hipGetLastError());
+   if (a.rzl && plan.k2p) { hipLaunchKernelGGL(vcg_rz_finish_k, dim3(1), dim3(1), 0, c->stream, ds, a.rzl, it); }
+   LGH_HIP_CHECK(hipGetLastError());
+   LGH_HIP_CHECK(hipStreamSynchronize(c->stream));
+   LGH_HIP_CHECK(hipMemcpy(&h, ds, sizeof(h), hipMemcpyDeviceToHost));
+   for (int k = 0; k < kVC; k++) { rz_out[k] = (a.rzl && plan.k2p) ? h.rzh[it & 1][k] : h.rz[k]; }
+   LGH_HIP_CHECK(hipMemcpy(r, a.r, kVC * N * sizeof(double), hipMemcpyDeviceToDevice));
+   LGH_HIP_CHECK(hipMemcpy(d, a.d, kVC * N * sizeof(double), hipMemcpyDeviceToDevice));
    return LGH_OK;
 }
 
