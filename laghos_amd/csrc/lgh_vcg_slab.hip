@@ -200,7 +200,6 @@ vcg_apply_slab346(const VcgArgs a, const int nset)
    // it, it waits for ALL outstanding loads (the gathers of the next set) before the first LDS read of an iteration
    __shared__ double sDa[NW * SBUF], sDb[NW * SBUF];
    __shared__ double red[48];
-   __shared__ double rz_sh[kVC]; // rz_limbs mode: (r, z) after the last iteration, folded by wavefront 0
 
    const int tid = threadIdx.x, lane = tid & 63;
    const unsigned long long t_enter = TRACE ? wall_clock64() : 0ull; // debug: the workgroup is on its CU
@@ -276,15 +275,15 @@ vcg_apply_slab346(const VcgArgs a, const int nset)
 #pragma unroll
    for (int k = 0; k < kVC; k++) { sc_done[k] = sc0->done[k]; sc_rz[k] = sc0->rz[k]; sc_rzp[k] = sc0->rz_prev[k]; sc_r0[k] = sc0->r0[k]; }
    // rz_limbs mode (lgh_vcg.hpp): (r, z) of the iteration before the last comes from the scalars (first iteration: both
-   // are the initial one), the last one out of the exact accumulators K2 added into - wavefront 0 folds them (below)
+   // are the initial one), the last one out of the exact accumulators K2 added into - folded below
    if (a.rzl && a.iter > 1)
    {
 #pragma unroll
       for (int k = 0; k < kVC; k++) { sc_rzp[k] = sc0->rzh[a.iter & 1][k]; } // (= [(iter - 2) & 1])
    }
-   // (the words of that set: one per lane of wavefront 0, one load instruction in this batch - not a round trip of its own later)
+   // (the words of that set: one per lane, one load instruction in this batch - not a round trip of its own later)
    long long rz_word = 0;
-   if (a.rzl && a.iter > 1 && wid == 0 && lane <= kLimbShards * kVC * kLimbs) { rz_word = a.rzl[((a.iter - 1) % 3) * kLimbWords + lane]; }
+   if (a.rzl && a.iter > 1 && lane <= kLimbShards * kVC * kLimbs) { rz_word = a.rzl[((a.iter - 1) % 3) * kLimbWords + lane]; }
    constexpr int NTAB = KRON ? D * D : HB;
    double tabv[NTAB];
 #pragma unroll
@@ -364,23 +363,15 @@ vcg_apply_slab346(const VcgArgs a, const int nset)
    for (int k = 0; k < kVC; k++) { todo[k] = sc_done[k] == 0; }
    if (a.rzl)
    {
-      // (r, z) after the last iteration: one wavefront folds the set K2 added into (the scale is that of the value
-      // before), the others take it from LDS while their gathers are in flight.  Every workgroup decides alike (integers);
-      // workgroup 0 commits what K2 and the host read and clears the set K2 of this iteration adds into.
+      // (r, z) after the last iteration: every wavefront folds the set K2 added into out of its own registers (the scale
+      // is that of the value before; one vector load in the prologue batch, v_readlane, integer adds - four wavefronts
+      // per CU: the scalar unit has the room, and no wavefront depends on another one's view of the flags).  Every
+      // wavefront of every workgroup decides alike (integers); workgroup 0 commits what K2 and the host read and clears
+      // the set K2 of this iteration adds into.
       if (a.iter > 1)
       {
-         if (wid == 0)
-         {
 #pragma unroll
-            for (int k = 0; k < kVC; k++)
-            {
-               const double v = exact_fold_lanes(rz_word, k, exact_scale(sc_rzp[k]));
-               if (lane == 0) { rz_sh[k] = v; }
-            }
-         }
-         __syncthreads();
-#pragma unroll
-         for (int k = 0; k < kVC; k++) { sc_rz[k] = rz_sh[k]; }
+         for (int k = 0; k < kVC; k++) { sc_rz[k] = exact_fold_lanes(rz_word, k, exact_scale(sc_rzp[k])); }
       }
       bool dn[kVC];
 #pragma unroll
