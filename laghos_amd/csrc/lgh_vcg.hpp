@@ -354,8 +354,9 @@ __device__ __forceinline__ double exact_fold_lanes(const long long w, const int 
 // Round 4 measured what the ticketed fold of (r, z) at the end of K2 costs: two dependent atomic round trips and two
 // dependent reads behind the slowest workgroup (profiles/r4_k2_tail.txt).  Now every workgroup of K2(i) adds its
 // share of R_i = (r, z) after iteration i into set i % 3 of `rzl` (exact integer limbs, fire-and-forget atomics; scale
-// exact_scale(R_(i-1)), which both sides know), and K1(i + 1) folds that set: one wavefront per workgroup, the others
-// take the value from LDS - integers, so every workgroup gets the same bits and takes the same decisions:
+// exact_scale(R_(i-1)), which both sides know), and K1(i + 1) folds that set: every wavefront out of its own registers
+// (one vector load in its prologue batch, v_readlane; four wavefronts per CU) - integers, so every wavefront of every
+// workgroup gets the same bits and takes the same decisions, whatever it sees of the flags workgroup 0 is committing:
 //   K1(i) folds set (i-1) % 3 -> R_(i-1); R_(i-2) comes from VcgScalars::rzh[(i-2) & 1]; workgroup 0 writes
 //   rzh[(i-1) & 1] = R_(i-1) and commits what K2(i) and the host read (done, iters, all_done) - values under which the
 //   predicate the other workgroups evaluate stays true; it also clears set i % 3 (last read by K1(i - 2));
