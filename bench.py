@@ -504,12 +504,16 @@ def main():
     torch.cuda.set_device(local_rank)
     nccl_id = None
     dist = None
-    ddev = "cpu" if shm else "cuda"  # (gloo carries the rendezvous data of the shm transport: RCCL refuses two ranks on one GPU)
     if world > 1:
+        # torch.distributed only carries the rendezvous (the 128-byte communicator id) and the host barriers around the
+        # timed region, over gloo on either transport: the one RCCL instance of the process is the library's own (torch's
+        # nccl backend would load a second copy of RCCL beside the one lgh_comm.hip opens, for a broadcast of 128 bytes),
+        # and it is the path the one-GPU box can execute (tests/test_gpu_multiproc.py).  The ranks' GPU work is fenced by
+        # sim.sync() + torch.cuda.synchronize() on both sides of every barrier.
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo" if shm else "nccl", rank=rank, world_size=world)
-        buf = torch.zeros(128, dtype=torch.uint8, device=ddev)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        buf = torch.zeros(128, dtype=torch.uint8)
         if rank == 0:
             cid = ctypes.create_string_buffer(128)
             _lib.check(_lib.load().lgh_comm_unique_id_shm(cid) if shm else _lib.load().lgh_comm_unique_id(cid))
@@ -577,7 +581,7 @@ def main():
     barrier()
     wall = time.perf_counter() - t0
     if dist is not None:
-        w = torch.tensor([wall], dtype=torch.float64, device=ddev)
+        w = torch.tensor([wall], dtype=torch.float64)
         dist.all_reduce(w, op=dist.ReduceOp.MAX)
         wall = float(w.item())
     rk_steps = sim.rk_steps - rk0
