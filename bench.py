@@ -512,6 +512,7 @@ def main():
         # sim.sync() + torch.cuda.synchronize() on both sides of every barrier.
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")  # one node: no dependence on the host name resolving
         dist.init_process_group("gloo", rank=rank, world_size=world)
         buf = torch.zeros(128, dtype=torch.uint8)
         if rank == 0:
