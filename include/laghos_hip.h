@@ -286,6 +286,11 @@ int lgh_table_symmetry(lgh_ctx *ctx, int *h1, int *l2);
  * -1 = no lockstep solve for this kernel id (the scalar CG runs).  Tests use it to make sure a requested
  * form (LGH_VCG_VARIANT) is the one that ran. */
 int lgh_k1_form(lgh_ctx *ctx, int *form);
+/* Which kernel MassPAOperator::Mult on the L2 space (the energy CG, laghos_solver.cpp:480-488) launches for this context:
+ * 2 = Kronecker form s_e M1l (x) M1l (x) M1l (compact mass data on a tensor-product rule, L1D <= 5), 1 = plane form,
+ * 0 = column form; *compact = 1 when that kernel reads one factor per element instead of the NQ-entry table
+ * (bench.py's byte accounting follows the kernel that runs, not the kernel id). */
+int lgh_l2_mass_form(lgh_ctx *ctx, int *form, int *compact);
 
 /* ---- multi-GPU: element blocks per rank, shared H1 nodes summed
  * over RCCL, dot products / dt all-reduced.  unique_id is the 128-byte

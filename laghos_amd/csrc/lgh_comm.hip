@@ -735,6 +735,13 @@ int lgh_comm_set_neighbors(lgh_ctx *c, int n_nbr, const int *nbr_rank, const int
    // into the collective below: a rank that fails must not leave its peers blocked in the all-reduce.
    const int rc_local = [&]() -> int {
    LGH_CHECK_ARG(n_nbr == 0 || (nbr_rank && nbr_count && nbr_nodes));
+   if (n_nbr == 0 && c->nranks > 1)
+   {
+      // every exchange is a rendezvous of all ranks (process-wide barriers on the loopback transports): a rank of a
+      // connected partition always has a neighbour, and one without would return from halo_sum before the others arrive
+      set_error("lgh_comm_set_neighbors: rank %d of %d has no neighbour (disconnected partition)", c->rank, c->nranks);
+      return LGH_ERR_ARG;
+   }
    for (int k = 0; k < n_nbr; k++)
    {
       LGH_CHECK_ARG(nbr_count[k] >= 0 && (nbr_count[k] == 0 || nbr_nodes[k]));

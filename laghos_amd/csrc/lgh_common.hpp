@@ -129,7 +129,9 @@ struct lgh_ctx
    double *force_e_q;    // NE*ND*dim: F.1 as E-vector (3D)
    int fused_ftv_valid, fused_f1_valid;
    unsigned long qgen;   // counts lgh_qupdate / invalidations (lgh_quadrature_generation)
-   int *dev_flags;       // 4 device ints: [0] "v differs from v_snap" of the current lgh_solve_energy
+   int *dev_flags;       // 8 device ints, one owner each: [0] / [2] "v differs from v_snap" of the current lgh_solve_energy (main /
+                         // second stream), [1] "x differs from ones" of lgh_force_mult, [3] "mass table is not W[q]*s_e" (mass_data),
+                         // [4] "an energy right-hand side was poisoned" (poison_if_k; read and cleared by lgh_get_dt_est)
    double *ones_l2;      // L2V ones: the operator's own `one` (laghos_solver.cpp:170-171), allocated on first use
    int stress_store;            // lgh_qupdate_store_stress: 1 (default) = lgh_qupdate writes the nine stressJinvT planes; 0 = the stress stays in registers
    int stress_current;          // stressJinvT holds the stress of the current quadrature data (consumers refuse it otherwise)
@@ -421,6 +423,7 @@ int mass_assemble_diag(lgh_ctx *c);
 int qupdate_form(lgh_ctx *c); // 1: row form of the 3D quadrature update (lgh_qrows.hpp), 0: point form
 // the quadrature data of the mass operators as (table, element stride in doubles, per-element factor): value(q, e) = Dq[q + dqs e] * Se[e]
 int mass_data(lgh_ctx *c, const double **Dq, int *dqs, const double **Se);
+int l2_mass_form(lgh_ctx *c, int *form, int *compact); // kernel of the L2 mass apply: 2 Kronecker, 1 plane, 0 column (lgh_l2_mass_form)
 int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, int iters[3],
               const double *force_E = nullptr);
 bool vcg_fused_init_ok(const lgh_ctx *c);

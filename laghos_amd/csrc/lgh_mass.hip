@@ -732,11 +732,41 @@ mass_apply_l2_kron(const MassArgs a)
 
 template <int Q> constexpr int neb_for() { return (256 / (Q * Q)) > 0 ? (256 / (Q * Q)) : 1; }
 
+// Which kernel the L2 mass apply (modes 0 / 3: the energy CG) launches, decided in ONE place for the dispatch below
+// and for lgh_l2_mass_form(): 2 = mass_apply_l2_kron (needs compact data on a tensor-product rule), 1 = the plane form,
+// 0 = the column form.  `compact`: whether the kernel reads one factor per element instead of the NQ-entry table.
+static int l2_mass_kernel(lgh_ctx *c, int *form, int *compact)
+{
+   const int id = (c->dim << 8) | (c->L1D << 4) | c->Q1D;
+   const double *Dq, *Se;
+   int dqs = 1;
+   *form = 0;
+   *compact = 0;
+   const bool kron_ok = c->dim == 3 && c->M1l && c->w1d && c->L1D <= 5;
+   const char *penv = getenv("LGH_L2_PLANE"); // A/B: 0 = column form
+   const bool plane_ok = c->b_l2_sym && (id == 0x336 || id == 0x348 || id == 0x35A) && !(penv && penv[0] == '0');
+   if (kron_ok || plane_ok)
+   {
+      const int rc = mass_data(c, &Dq, &dqs, &Se);
+      if (rc) { return rc; }
+   }
+   if (kron_ok && dqs == 0) { *form = 2; *compact = 1; }
+   else if (plane_ok) { *form = 1; *compact = (dqs == 0); }
+   return LGH_OK;
+}
+int l2_mass_form(lgh_ctx *c, int *form, int *compact) { return l2_mass_kernel(c, form, compact); }
+
 template <int MODE> static int launch_mass(lgh_ctx *c, int space, const MassArgs &a0)
 {
    const MassArgs &a = a0;
    const int n1d = (space == LGH_SPACE_H1) ? c->D1D : c->L1D;
    const int id = (c->dim << 8) | (n1d << 4) | c->Q1D;
+   int l2form = 0, l2compact = 0;
+   if ((MODE == 0 || MODE == 3) && space == LGH_SPACE_L2)
+   {
+      const int rc_f = l2_mass_kernel(c, &l2form, &l2compact);
+      if (rc_f) { return rc_f; }
+   }
 #define LGH_MASS_CASE(DIMK, D_, Q_)                                                           \
    {                                                                                          \
       constexpr int NEB_ = neb_for<Q_>();                                                     \
@@ -744,13 +774,12 @@ template <int MODE> static int launch_mass(lgh_ctx *c, int space, const MassArgs
                          dim3(Q_ * Q_ * NEB_), 0, c->stream, a);                              \
    }                                                                                          \
    break
-   if ((MODE == 0 || MODE == 3) && space == LGH_SPACE_L2 && c->dim == 3 && c->M1l && c->w1d && c->L1D <= 5)
+   if (l2form == 2)
    {
       // compact mass data on a tensor-product rule: the Kronecker form (LGH_MASS_KRON=0: no tiles, see lgh_create)
       MassArgs a = a0;
       const int rc_md = mass_data(c, &a.Dq, &a.dqs, &a.Se);
       if (rc_md) { return rc_md; }
-      if (a.dqs == 0)
       {
          constexpr int M = (MODE == 3 ? 3 : 0);
          a.M1 = c->M1l;
@@ -768,11 +797,9 @@ template <int MODE> static int launch_mass(lgh_ctx *c, int space, const MassArgs
          return LGH_OK;
       }
    }
-   if ((MODE == 0 || MODE == 3) && space == LGH_SPACE_L2 && c->b_l2_sym && (id == 0x336 || id == 0x348 || id == 0x35A))
+   if (l2form == 1)
    {
-      const char *penv = getenv("LGH_L2_PLANE"); // A/B: 0 = column form
       constexpr int M = (MODE == 3 ? 3 : 0);
-      if (!(penv && penv[0] == '0'))
       {
          MassArgs a = a0; // (the plane form takes the mass data in its compact form where it has one)
          const int rc_md = mass_data(c, &a.Dq, &a.dqs, &a.Se);

@@ -52,6 +52,7 @@ struct Options
    int nranks = 1, rank = 0;
    const char *nccl_id = nullptr;
    bool quiet = false;
+   bool store_stress = false;      // -store-stress: qdata.stressJinvT written by every update (the reference's behaviour)
 };
 
 bool ParseArgs(int argc, const char *const *argv, Options &o, std::string &err)
@@ -93,6 +94,8 @@ bool ParseArgs(int argc, const char *const *argv, Options &o, std::string &err)
       if (a == "-no-fom" || a == "--no-fom") { o.fom = false; continue; }
       if (a == "-q" || a == "--quiet") { o.quiet = true; continue; }
       if (a == "-print" || a == "--print") { o.gfprint = true; continue; }
+      if (a == "-store-stress" || a == "--store-stress") { o.store_stress = true; continue; }
+      if (a == "-no-store-stress" || a == "--no-store-stress") { o.store_stress = false; continue; }
       if (a == "-k" || a == "--outputfilename") { if (!(v = need(i))) { return false; } o.basename = v; continue; }
       if (a == "-d" || a == "--device") { if (!need(i)) { return false; } continue; } // always the HIP path
       if (a == "-no-vis" || a == "--no-visualization" || a == "-no-visit" || a == "-no-print") { continue; }
@@ -317,7 +320,7 @@ laghos_sim *laghos_sim_create(int argc, const char *const *argv, int nranks, int
    // (-store-stress / LGH_STORE_STRESS=1 keep it in memory in any case.)
    {
       const char *senv = std::getenv("LGH_STORE_STRESS");
-      const bool keep_in_registers = o.ode_solver_type != 7 && d.dim == 3 && !(senv && senv[0] == '1');
+      const bool keep_in_registers = o.ode_solver_type != 7 && d.dim == 3 && !o.store_stress && !(senv && senv[0] == '1');
       if (keep_in_registers) { LGH_VERIFY(lgh_qupdate_store_stress(s->hydro->Context(), 0)); }
    }
    s->S.FromHost(S0);

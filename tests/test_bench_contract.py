@@ -13,8 +13,28 @@ def _line(name):
     return json.loads(lines[0])
 
 
-def test_bench_line_has_the_contract_fields():
-    d = _line("r4_bench.json")
+def _bench():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    return bench
+
+
+def _walk(o, path=""):
+    if isinstance(o, dict):
+        for k, v in o.items():
+            yield from _walk(v, path + "/" + str(k))
+    elif isinstance(o, list):
+        for i, v in enumerate(o):
+            yield from _walk(v, path + "/%d" % i)
+    else:
+        yield path, o
+
+
+def _check_line(d, text):
+    """what the driver needs from the ONE stdout line (round-4 verdict: a 23.8 KB line left BENCH_r04.parsed null)"""
+    assert len(text) <= 8192, "the driver keeps 8 KB of stdout: the contract line has to fit (%d bytes)" % len(text)
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "parity"):
         assert key in d, key
@@ -33,56 +53,64 @@ def test_bench_line_has_the_contract_fields():
     wall = d["ms_per_step"] * 1e-3 * d["steps"]
     assert abs(d["value"] - 1e-6 * dofs * c["rk_stages_executed"] / wall) < 1e-6 * d["value"]
     r = d["roofline"]
-    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "sec8d_frac", "other_kernels"):
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "other_kernels", "mean_launch_us", "bytes_per_launch"):
         assert key in r, key
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
-    assert abs(r["achieved"] - r["bytes_per_launch"] / (r["mean_launch_us"] * 1e-6) / 1e9) < 1e-6 * r["achieved"]
-    assert abs(r["frac_of_achievable"] - r["achieved"] / r["achievable"]) < 1e-12
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-5
+    assert abs(r["achieved"] - r["bytes_per_launch"] / (r["mean_launch_us"] * 1e-6) / 1e9) < 1e-4 * r["achieved"]
     assert "traffic_source" in r  # a counter figure is only reported for the build it was measured on
     # the roofline kernel is the one with the largest share of the sampled RK step
     share = r["time_share_us_per_rk_step"]
-    assert r["kernel"].split(" ")[0] == max(share, key=share.get)
-    # Honest bytes (round-3 advisor): `achieved` counts what the kernel form that ran has to MOVE; no figure may exceed
-    # what the memory system delivered - for the roofline kernel and for every kernel beside it the counter traffic
-    # covers the moved bytes - and nothing runs above the HBM peak
-    assert r["traffic"] is not None and r["bytes_per_launch"] <= r["traffic"] <= 1.5 * r["bytes_per_launch"]
+    assert r["kernel"] == max(share, key=share.get)
     assert 0 < r["frac"] < 1
     for name, o in r["other_kernels"].items():
         assert 0 < o["frac"] < 1, name
-        assert o["traffic"] is not None and o["bytes_per_launch"] <= o["traffic"], name
-    for name, k in d["kernels"].items():
-        assert k["GBs"] < r["peak"], name
-    # K1 beside it: what it moves is less than SURVEY 8(d)'s figure (compact mass data: no quadrature table)
-    k1 = r["other_kernels"]["vcg_apply_slab346"]
-    assert k1["bytes_per_launch"] < k1["sec8d_bytes_per_launch"] and k1["frac"] < k1["sec8d_frac"]
-    # north_star quotes its target on the Force+Mass operator apply: F.1 + F^T v + the mass applies of the H1 CG, in both accountings
+    # Honest bytes: where counter traffic is quoted (only for the build it was collected on) it covers the moved bytes
+    if r["traffic"] is not None:
+        assert r["bytes_per_launch"] <= r["traffic"] <= 1.5 * r["bytes_per_launch"]
+        for name, o in r["other_kernels"].items():
+            assert o["traffic"] is None or o["bytes_per_launch"] <= o["traffic"], name
+    # north_star quotes its target on the Force+Mass operator apply: F.1 + F^T v + the mass applies of the H1 CG
     for key in ("force_mass_aggregate", "force_mass_cg_aggregate"):
         a = r[key]
-        assert abs(a["frac"] - a["achieved"] / r["peak"]) < 1e-12
-        assert abs(a["achieved"] - 1e-9 * a["bytes_per_rk_step"] / a["seconds_per_rk_step"]) < 1e-6 * a["achieved"]
-        assert a["bytes_per_rk_step"] <= a["sec8d_bytes_per_rk_step"] and a["frac"] <= a["sec8d_frac"] < 1
-    assert r["force_mass_aggregate"]["kernels"] == ["force_mult_3d", "force_mult_t_3d", "vcg_apply_slab346"]
+        assert abs(a["frac"] - a["achieved"] / r["peak"]) < 1e-5 and 0 < a["frac"] < 1
+        assert abs(a["achieved"] - 1e-9 * a["bytes_per_rk_step"] / a["seconds_per_rk_step"]) < 1e-4 * a["achieved"]
+    # No figure anywhere in the line above the HBM peak: no GB/s entry, no fraction > 1 (round-4 verdict, weak #3:
+    # SURVEY 8(d)'s bytes of the reference's kernel forms priced at this implementation's times gave 1.42 of peak)
+    for path, v in _walk(d):
+        leaf = path.rsplit("/", 1)[-1]
+        assert not leaf.startswith("sec8d"), path
+        if isinstance(v, (int, float)) and not isinstance(v, bool):
+            if leaf in ("frac", "force_mass_frac") or leaf.endswith("_frac"):
+                assert 0 <= v < 1, (path, v)
+            if leaf in ("achieved", "GBs"):
+                assert v < 8000.0, (path, v)
     # parity block: the bench's own problem against the oracle, printed with the number it belongs to
     assert d["parity"]["pass"] is True and d["parity"]["e_norm_rel_diff"] <= 1e-9 and d["parity"]["rk4_steps"] == 3
-    # the other single-GPU configs of BASELINE.json as extra legs: 64^3 Sedov (HBM-resident) and 64^3 Taylor-Green
-    for leg in ("c3", "tg"):
+    # the other single-GPU configs of BASELINE.json as extra legs: value, ms_per_step, roofline kernel and fraction only
+    for leg in ("c3", "tg", "c5", "c2dev", "c2stored", "c2multi"):
         g = d["legs"][leg]
-        assert g["elements"] == 262144 and g["value"] > 0 and 0 < g["force_mass_aggregate"]["frac"] < 1
-        assert all(k["GBs"] < r["peak"] for k in g["kernels"].values())
-        assert g["roofline"]["traffic"] is None or g["roofline"]["bytes_per_launch"] <= g["roofline"]["traffic"]
-    assert "Taylor-Green" in d["legs"]["tg"]["workload"] and "-rs 5" in d["legs"]["c3"]["workload"]
-    # config 5 (Q5Q4) on one GPU, the developed-flow view of C2, the general-mesh path (stored mass table) and the
-    # N-rank code path on one rank
-    assert d["legs"]["c5"]["elements"] == 65536 and d["legs"]["c5"]["value"] > 0
-    assert d["legs"]["c2dev"]["value"] > 0
-    assert "stored" in d["legs"]["c2stored"]["workload"] and 0 < d["legs"]["c2stored"]["value"] <= 1.02 * d["value"]
-    m = d["legs"]["c2multi"]
-    assert m["comm"]["ranks"] == 1 and m["comm"]["allreduce"]["per_rk_step"] > 0 and abs(m["ms_per_step_minus_single_rank_path"]) < 1.0
+        assert g["value"] > 0 and g["ms_per_step"] > 0 and 0 < g["frac"] < 1 and g["kernel"], leg
+        assert set(g) <= {"value", "ms_per_step", "kernel", "frac", "force_mass_frac", "ms_per_step_minus_single_rank_path"}, leg
+    assert 0 < d["legs"]["c2stored"]["value"] <= 1.02 * d["value"]
+    assert abs(d["legs"]["c2multi"]["ms_per_step_minus_single_rank_path"]) < 1.0
     b = d["cpu_baseline"]
     for key in ("value", "unit", "cores", "kind", "sample", "cpu_model"):
         assert key in b, key
     assert b["kind"] in ("port", "reference") and b["unit"] == d["unit"] and b["cores"] >= 1
+
+
+def test_compact_line_of_a_full_record_fits_the_driver():
+    """bench.compact_line() is a pure function of the full record: applied to round 4's 23.8 KB record it must give a line
+    the driver can keep (<= 8 KB) that still holds the whole contract."""
+    bench = _bench()
+    with open(os.path.join(ROOT, "profiles", "r4_bench.json")) as f:
+        full = json.loads([l for l in f.read().splitlines() if l.startswith("{")][0])
+    line = bench.compact_line(full, "gpurun_out/bench_detail.json")
+    text = json.dumps(line, separators=(",", ":"))
+    assert len(text) < 4096
+    _check_line(json.loads(text), text)
+    assert line["value"] == full["value"] and line["ms_per_step"] == full["ms_per_step"]  # what the driver's clock is held against: unrounded
 
 
 def test_profiled_run_agrees_with_the_plain_run():
@@ -96,10 +124,7 @@ def test_profiled_run_agrees_with_the_plain_run():
 def test_weak_scaling_layout_of_the_bench():
     """N ranks keep 32^3 elements each in a block grid whose ranks are all neighbours of each other
     up to N = 8 (the partitions for which the CG sums ride on the halo exchange)."""
-    import importlib.util
-    spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
-    bench = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(bench)
+    bench = _bench()
     assert [tuple(bench.block_grid(n)) for n in (1, 2, 4, 8)] == [(1, 1, 1), (2, 1, 1), (2, 2, 1), (2, 2, 2)]
     for n in (1, 2, 3, 4, 6, 8):
         px, py, pz = bench.block_grid(n)

@@ -820,6 +820,39 @@ def test_mass_data_forms(variant, monkeypatch):
     assert rel_err(dS_t[H1V:], dS_c[H1V:]) < 1e-10
 
 
+def test_stored_mass_table_does_not_trip_the_dt_estimate():
+    """Round-4 advisor: the 'mass table is not compact' flag and the 'energy right-hand side poisoned' flag shared one
+    device word, so on a context whose mass data is genuinely not W[q]*s_e (a graded mesh, a density that varies inside
+    a zone) the first lgh_get_dt_est after a mass apply failed with the poisoned-velocity error.  Each flag has its own
+    word now: a rewritten, truly non-compact table -> mass apply -> a whole Mult -> the dt estimate must come back."""
+    from oracle.fem import Problem
+    prob = Problem(mesh="box01_hex", rs=1, order_v=3, order_e=2, problem=1)
+    S = deformed_state(prob, seed=61)
+    factor = 1.0 + 0.25 * np.abs(seeded(prob.NE * prob.NQ, 62))
+    import torch
+    g = make_gpu(prob)
+    try:
+        g.ctx.massD = g.ctx.massD * factor
+        assert g.ctx.mass_data_form() == "stored"
+        xv, yv = g.ctx.to_dev(seeded(prob.N, 63)), g.ctx.empty(prob.N)
+        torch.cuda.synchronize()
+        g.ctx.mass_set_ess(-1)
+        g.ctx.mass_mult(0, xv, yv)
+        g.ctx.set_dt_est(0.125)
+        assert g.ctx.get_dt_est() == 0.125          # (raised "velocity other than the state's" before the fix)
+        Sd, dS = g.ctx.to_dev(S), g.ctx.zeros(S.size)
+        g.reset_quadrature_data()
+        g.reset_time_step_estimate()
+        g.mult(Sd, dS)
+        dt = g.get_time_step_estimate(Sd)
+        assert np.isfinite(dt) and dt > 0
+        g.ctx.mass_data_changed()                    # the check runs again (and must not erase or fake a poison report)
+        g.ctx.mass_mult(0, xv, yv)
+        assert g.ctx.get_dt_est() == dt
+    finally:
+        g.close()
+
+
 @pytest.mark.parametrize("variant", ["2", "4"], ids=["plane", "slab"])
 def test_mass_data_changed_keeps_operator_and_diagonal_consistent(variant, monkeypatch):
     """A caller that keeps the lgh_mass_D() pointer and rewrites the table AFTER a mass apply has run (round-3 advisor:
