@@ -558,6 +558,10 @@ def compact_line(full, detail_path=None):
     for k in ("value", "ms_per_step"):
         if k in full:
             line[k] = full[k]
+    # ... and the verification values of the run (|e|, t, dt: what the reference prints to compare runs by) keep every bit
+    for k in ("e_norm", "t", "dt"):
+        if k in full.get("config", {}):
+            line["config"][k] = full["config"][k]
     return line
 
 

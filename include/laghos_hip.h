@@ -347,6 +347,12 @@ int lgh_mass_apply_E(lgh_ctx *ctx, int space, const double *x_E, double *y_E);
  * work vectors only. */
 int lgh_test_vcg_k1(lgh_ctx *ctx, const double *r, const double *d_old, const double rz[3], const double rz_prev[3],
                     int first, double *y_E, double den[3]);
+/* The slab form of K1 stores a set of five x-neighbouring zones with the shared x-faces already summed (merged E-vector
+ * layout, round 5: what K2 reads shrinks by a fifth and comes in whole cache lines).  lgh_test_vcg_k1 then reports such a
+ * sum in the LEFT zone's entry (dx = 3) and 0.0 in the right zone's (dx = 0); mask[e * D1D^3 + d] (host, NE * D1D^3
+ * bytes) = 1 marks those right-hand entries, *n_merged counts them (0 with every other form of K1 or LGH_SLAB_MERGE=0).
+ * lgh_test_vcg_k2 takes the element-local E-vector either way (it forms the sums K1 would have stored). */
+int lgh_test_vcg_merged_faces(lgh_ctx *ctx, unsigned char *mask, long *n_merged);
 /* ONE launch of the node kernel K2 of the lockstep velocity solve (the kernel with the largest share of the step: the
  * E -> L sum of K1's element contributions, essential rows, r -= alpha A d, d = r_old/diag + beta d, the deferred update
  * of x, (r, r/diag)) exactly as the one-rank solve launches it in iteration it >= 1: y_E = 3 planes of NE*D1D^3

@@ -112,6 +112,7 @@ SYMBOLS = {
     "lgh_force_mult_transpose_E": (_I, [_P, _P, _P, _P]),
     "lgh_mass_apply_E": (_I, [_P, _I, _P, _P]),
     "lgh_test_vcg_k1": (_I, [_P, _P, _P, c_dbl_p, c_dbl_p, _I, _P, c_dbl_p]),
+    "lgh_test_vcg_merged_faces": (_I, [_P, _P, ctypes.POINTER(ctypes.c_long)]),
     "lgh_test_vcg_k2": (_I, [_P, _I, _P, _P, _P, _P, c_dbl_p, c_dbl_p, c_dbl_p, c_dbl_p, c_dbl_p, ctypes.POINTER(ctypes.c_int)]),
     "lgh_test_set_rank": (_I, [_P, _I, _I]),
     "lgh_test_halo_pack": (_I, [_P, _P, _I, _P]),

@@ -257,6 +257,14 @@ class Context:
                                        int(bool(first)), _ptr(y), _dbl(den)))
         return y.view(3, -1), den
 
+    def test_vcg_merged_faces(self):
+        """uint8 mask [NE*ND] of the E-vector entries K1 has already summed into their left x-neighbour's (slab K1, merged
+        layout; all zero otherwise) and their number (lgh_test_vcg_merged_faces)."""
+        mask = np.zeros(self.NE * self.ND, dtype=np.uint8)
+        n = ctypes.c_long(0)
+        check(self.lib.lgh_test_vcg_merged_faces(self.h, mask.ctypes.data_as(ctypes.c_void_p), ctypes.byref(n)))
+        return mask, n.value
+
     def test_vcg_k2(self, it, y_E, r, d, x, den, rz, rz_prev, alpha_prev):
         """One launch of the lockstep solve's K2 (lgh_test_vcg_k2); r, d, x are updated in place.
         Returns ((r, z) of the new residual [3], deferred_x)."""

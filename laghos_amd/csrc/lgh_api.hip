@@ -1128,6 +1128,11 @@ int lgh_test_vcg_k1(lgh_ctx *c, const double *r, const double *d_old, const doub
    LGH_CHECK_ARG(c && r && (first || d_old) && rz && rz_prev && y_E && den);
    return vcg_test_k1(c, r, d_old, rz, rz_prev, first, y_E, den);
 }
+int lgh_test_vcg_merged_faces(lgh_ctx *c, unsigned char *mask, long *n_merged)
+{
+   LGH_CHECK_ARG(c && mask && n_merged);
+   return vcg_test_merged_faces(c, mask, n_merged);
+}
 int lgh_test_vcg_k2(lgh_ctx *c, int it, const double *y_E, double *r, double *d, double *x, const double den[3], const double rz[3],
                     const double rz_prev[3], const double alpha_prev[3], double rz_out[3], int *deferred_x)
 {

@@ -299,6 +299,12 @@ struct Comm
    int *d_base = nullptr, *d_cnt = nullptr; // device, per neighbour: block base, node count
    int *rank_src = nullptr;                 // device, per rank: neighbour index or -1 (self)
    int bufsize = 0;                         // doubles in sendbuf / recvbuf
+   // exchange_words: the peers' accumulator words (n_nbr blocks of wordcap words), and where this rank's own words are
+   // (the in-process transport copies device to device out of the peer's accumulators)
+   long long *wordbuf = nullptr;
+   int wordcap = 0;
+   const long long *word_src = nullptr;
+   std::vector<long long> wstage;
 };
 constexpr int kHaloSlack = 4; // doubles of room behind every neighbour's block (<= 3 scalars used)
 
@@ -488,6 +494,72 @@ void comm_shared_nodes(const lgh_ctx *c, const uint8_t **hmask, const int **sh_n
    *n_shared = (cm && cm->hmask) ? cm->n_shared : 0;
 }
 
+int comm_word_peers(lgh_ctx *c, int nwords, const long long **peers, int *n_peers)
+{
+   Comm *cm = c->comm;
+   *peers = nullptr;
+   *n_peers = 0;
+   if (!cm || cm->n_nbr == 0) { return LGH_OK; } // (a communicator of size 1: nobody to hear from)
+   if (!cm->allpairs) { set_error("comm_word_peers: all-pairs partitions only"); return LGH_ERR_ARG; }
+   if (cm->wordcap < nwords)
+   {
+      if (cm->wordbuf) { (void)hipFree(cm->wordbuf); cm->wordbuf = nullptr; }
+      LGH_HIP_CHECK(hipMalloc((void **)&cm->wordbuf, (size_t)cm->n_nbr * nwords * sizeof(long long)));
+      LGH_HIP_CHECK(hipMemset(cm->wordbuf, 0, (size_t)cm->n_nbr * nwords * sizeof(long long)));
+      cm->wordcap = nwords;
+   }
+   *peers = cm->wordbuf;
+   *n_peers = cm->n_nbr;
+   return LGH_OK;
+}
+
+int exchange_words(lgh_ctx *c, const long long *src, int nwords)
+{
+   Comm *cm = c->comm;
+   if (!cm || cm->n_nbr == 0) { return LGH_OK; }
+   if (!cm->allpairs || !cm->wordbuf || cm->wordcap != nwords || c->on_stream2) { set_error("exchange_words: all-pairs partition, main channel, peer buffer of %d words", nwords); return LGH_ERR_ARG; }
+   KtScope sample(c, LGH_KERNEL_ALLREDUCE); // (counted with the small sums it replaces)
+   const size_t bytes = (size_t)nwords * sizeof(long long);
+   if (cm->local)
+   {
+      LocalGroup *g = cm->local.get();
+      cm->word_src = src;
+      LGH_HIP_CHECK(hipStreamSynchronize(c->stream)); // my words are complete
+      if (!g->barrier()) { set_error("local communicator: barrier timed out (words)"); return LGH_ERR_COMM; }
+      for (int k = 0; k < cm->n_nbr; k++)
+      {
+         const Comm *pc = g->ctx[cm->nbr_rank[k]]->comm;
+         if (!pc->word_src) { set_error("local communicator: rank %d exchanges no words", cm->nbr_rank[k]); return LGH_ERR_COMM; }
+         LGH_HIP_CHECK(hipMemcpyAsync(cm->wordbuf + (size_t)k * nwords, pc->word_src, bytes, hipMemcpyDeviceToDevice, c->stream));
+      }
+      LGH_HIP_CHECK(hipStreamSynchronize(c->stream));
+      if (!g->barrier()) { set_error("local communicator: barrier timed out (words)"); return LGH_ERR_COMM; } // peers may go on adding
+      return LGH_OK;
+   }
+   if (cm->shm)
+   {
+      ShmGroup *g = cm->shm.get();
+      if (bytes > g->hdr()->cap) { set_error("shm transport: %zu bytes of words, room for %zu", bytes, g->hdr()->cap); return LGH_ERR_COMM; }
+      LGH_HIP_CHECK(hipStreamSynchronize(c->stream));
+      LGH_HIP_CHECK(hipMemcpy(g->msg(c->rank, 0), src, bytes, hipMemcpyDeviceToHost));
+      if (!g->barrier()) { set_error("shm transport: barrier timed out (words): a rank is missing or the ranks do not call the same exchanges"); return LGH_ERR_COMM; }
+      cm->wstage.resize((size_t)cm->n_nbr * nwords);
+      for (int k = 0; k < cm->n_nbr; k++) { memcpy(cm->wstage.data() + (size_t)k * nwords, g->msg(cm->nbr_rank[k], 0), bytes); }
+      LGH_HIP_CHECK(hipMemcpy(cm->wordbuf, cm->wstage.data(), (size_t)cm->n_nbr * bytes, hipMemcpyHostToDevice));
+      if (!g->barrier()) { set_error("shm transport: barrier timed out (words)"); return LGH_ERR_COMM; } // peers may reuse their message area
+      return LGH_OK;
+   }
+   LGH_NCCL_CHECK(g_nccl.GroupStart());
+   for (int k = 0; k < cm->n_nbr; k++)
+   {
+      // (send / recv move bytes: the words travel under the 8-byte type the halo messages already use)
+      LGH_NCCL_CHECK(g_nccl.Send(src, (size_t)nwords, ncclFloat64, cm->nbr_rank[k], cm->comm, c->stream));
+      LGH_NCCL_CHECK(g_nccl.Recv(cm->wordbuf + (size_t)k * nwords, (size_t)nwords, ncclFloat64, cm->nbr_rank[k], cm->comm, c->stream));
+   }
+   LGH_NCCL_CHECK(g_nccl.GroupEnd());
+   return LGH_OK;
+}
+
 int allreduce_dev(lgh_ctx *c, double *dev, int count, int op, bool packed)
 {
    Comm *cm = c->comm;
@@ -584,7 +656,7 @@ void lgh_comm_free(lgh_ctx *c)
    if (cm->comm2 && g_nccl.CommDestroy) { g_nccl.CommDestroy(cm->comm2); }
    if (cm->comm && g_nccl.CommDestroy) { g_nccl.CommDestroy(cm->comm); }
    void *ptrs[] = {cm->nodes, cm->sendbuf, cm->recvbuf, cm->sendbuf2, cm->recvbuf2, cm->sh_node, cm->sh_off, cm->sh_src, cm->pos, cm->cnt, cm->hmask,
-                   cm->d_base, cm->d_cnt, cm->rank_src};
+                   cm->d_base, cm->d_cnt, cm->rank_src, cm->wordbuf};
    for (void *p : ptrs) { if (p) { (void)hipFree(p); } }
    delete cm;
    c->comm = nullptr;

@@ -428,8 +428,9 @@ int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
               const double *force_E = nullptr);
 bool vcg_fused_init_ok(const lgh_ctx *c);
 // tables of the node kernel K2 (lgh_vcg.hip)
-int partition_nodes_by_cost(lgh_ctx *c, int W, int **out);
-int make_ellz(lgh_ctx *c, unsigned **out);
+int partition_nodes_by_cost(lgh_ctx *c, int W, int **out, const std::vector<int> *valence = nullptr);
+int make_ellz(lgh_ctx *c, unsigned **out, const int *ell = nullptr, int deg = 0);
+int vcg_test_merged_faces(lgh_ctx *c, unsigned char *mask, long *n_merged); // lgh_test_vcg_merged_faces
 int make_essbits(lgh_ctx *c, uint8_t **out);
 void vcg_free(lgh_ctx *c);
 constexpr int kYePad = 16; // doubles behind every Y_E plane of the CG; the first one (slot NE*ND) stays 0.0
@@ -473,6 +474,12 @@ struct HaloPackTables
 bool comm_pack_tables(const lgh_ctx *c, HaloPackTables *t); // false: no neighbours / no tables
 bool halo_can_piggyback(const lgh_ctx *c);
 bool comm_second_channel(const lgh_ctx *c); // reductions may run on the context's second stream as well
+// Exact all-reduce of integer accumulator words (lgh_vcg.hpp: the (r, z) of the lockstep solve) in ONE message round and
+// without a kernel: every rank sends its `nwords` 64-bit words to every peer straight out of the accumulators and
+// receives theirs into its peer buffer (comm_word_peers: block k = neighbour k); whoever folds the sum adds own and
+// peer words - integers, so every rank gets the same bits whatever the arrival order.  All-pairs partitions only.
+int exchange_words(lgh_ctx *c, const long long *src, int nwords);
+int comm_word_peers(lgh_ctx *c, int nwords, const long long **peers, int *n_peers); // (allocates the peer buffer on first use)
 int allreduce_dev(lgh_ctx *c, double *dev, int count, int op, bool packed = false); // packed: as halo_sum (sums that travel as one exchange with every peer only)
 
 // bracket one launch of kernel `id` with an event pair when sampling is on

@@ -1186,14 +1186,23 @@ __global__ void vcg_update_finish_k(VcgScalars *s, int iter)
 
 // rz_limbs mode: the outcome of the last enqueued iteration `last`, committed for the host (what workgroup 0 of
 // K1(last + 1) would write)
-__global__ void vcg_rz_finish_k(VcgScalars *s, const long long *rzl, const int last)
+__global__ void vcg_rz_finish_k(VcgScalars *s, const long long *rzl, const int last, const long long *peers, const int n_peers)
 {
+   // several ranks: own words + the peers' (exchange_words) = the sum over the ranks; folded into a scratch set - the
+   // flag word rides along (any rank's overflow turns the sum into NaN on every rank)
+   long long set[kLimbWords]; // (a copy: K1(last + 1), if the host enqueues it after its look, folds own + peers itself)
+   for (int i = 0; i <= kLimbShards * kVC * kLimbs; i++)
+   {
+      long long w = rzl[(last % 3) * kLimbWords + i];
+      for (int p = 0; p < n_peers; p++) { w += peers[p * kLimbWords + i]; }
+      set[i] = w;
+   }
    double cur[kVC];
    bool dn[kVC];
    for (int k = 0; k < kVC; k++)
    {
       const double before = (last > 1) ? s->rzh[(last - 1) & 1][k] : s->rz[k];
-      cur[k] = exact_fold(rzl + (last % 3) * kLimbWords, k, exact_scale(before));
+      cur[k] = exact_fold(set, k, exact_scale(before));
       dn[k] = s->done[k] != 0 || vcg_rz_converged(last + 1, cur[k], s->r0[k]);
    }
    vcg_rz_commit(s, last + 1, cur, dn);
@@ -1605,7 +1614,12 @@ vcg_gather_k(const VcgArgs a)
 __device__ __forceinline__ void vcg_fold_den(const VcgArgs &a)
 {
    const int tid = threadIdx.x, it = a.iter;
-   if (tid < kVC && !a.s->done[tid]) { __hip_atomic_store(&a.s->den[tid], exact_den(a.limbs + (it & 1) * kLimbWords, tid, a.s->rz[tid]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+   // (the scale of the accumulators is that of (r, z) before this iteration: in rz_limbs mode K1 of this iteration left it in rzh)
+   if (tid < kVC && !a.s->done[tid])
+   {
+      const double ref = (a.rzl && it > 1) ? a.s->rzh[(it - 1) & 1][tid] : a.s->rz[tid];
+      __hip_atomic_store(&a.s->den[tid], exact_den(a.limbs + (it & 1) * kLimbWords, tid, ref), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+   }
    if (tid < kLimbWords) { a.limbs[((it + 1) & 1) * kLimbWords + tid] = 0; }
    if (tid == 0) { a.s->first = 0; }
 }
@@ -1683,11 +1697,16 @@ vcg_ellz_k(const int *__restrict__ ell, unsigned *__restrict__ ellz, const size_
 // (measured: t = 4.2..5.3 ns + 1.7..1.8 ns * valence per node and workgroup, the traces of the persistent-solve experiment, profiles/r2_pcg_trace_*.txt); with equal
 // node counts the workgroups whose range covers element-boundary planes take 40 % longer and every barrier
 // waits for them.  Ranges of equal cost instead, boundaries rounded to 16 nodes (128 B).
-int partition_nodes_by_cost(lgh_ctx *c, const int W, int **out)
+int partition_nodes_by_cost(lgh_ctx *c, const int W, int **out, const std::vector<int> *valence)
 {
    const int N = c->N;
    std::vector<int> off((size_t)N + 1);
-   LGH_HIP_CHECK(hipMemcpy(off.data(), c->t_off, off.size() * sizeof(int), hipMemcpyDeviceToHost));
+   if (valence) // (the merged layout of the slab K1: contributions per node as THAT layout has them)
+   {
+      off[0] = 0;
+      for (int n = 0; n < N; n++) { off[(size_t)n + 1] = off[n] + (*valence)[n]; }
+   }
+   else { LGH_HIP_CHECK(hipMemcpy(off.data(), c->t_off, off.size() * sizeof(int), hipMemcpyDeviceToHost)); }
    const char *wenv = getenv("LGH_K2_NODE_WEIGHT"); // fixed part in units of half a contribution; <0: equal counts
    const long fixed = wenv ? atol(wenv) : 5;
    std::vector<long> cum((size_t)N + 1, 0);
@@ -1710,13 +1729,71 @@ int partition_nodes_by_cost(lgh_ctx *c, const int W, int **out)
 }
 // ELL transpose of the restriction as byte offsets into a Y_E plane of NE*ND + pad doubles whose slot NE*ND is
 // zero: absent contributions point there, so the gather needs no predicate
-int make_ellz(lgh_ctx *c, unsigned **out)
+int make_ellz(lgh_ctx *c, unsigned **out, const int *ell, const int deg)
 {
    const size_t ell_n = (size_t)8 * c->N;
    LGH_HIP_CHECK(hipMalloc((void **)out, ell_n * sizeof(unsigned)));
-   hipLaunchKernelGGL(vcg_ellz_k, dim3((unsigned)((ell_n + 255) / 256)), dim3(256), 0, nullptr, c->t_ell, *out,
-                      (size_t)c->t_deg * c->N, ell_n, c->NE * c->ND);
+   hipLaunchKernelGGL(vcg_ellz_k, dim3((unsigned)((ell_n + 255) / 256)), dim3(256), 0, nullptr, ell ? ell : c->t_ell, *out,
+                      (size_t)(ell ? deg : c->t_deg) * c->N, ell_n, c->NE * c->ND);
    LGH_HIP_CHECK(hipGetLastError());
+   return LGH_OK;
+}
+
+// ---- merged E-vector layout of the slab-form K1 (round 5) ---------------------------------------------------------
+// K1 hands K2 the element contributions A_e d_e; in the element-local layout [e][dz][dy][dx] every node of an x-face
+// between two zones travels twice (64 values per zone for 27 nodes) and a wavefront of K2 - consecutive nodes of an
+// x-line - uses one y-row (32 bytes) of every 128-byte line it touches.  The slab K1 works on sets of five consecutive
+// zones; where those are x-neighbours ("x-chain": zone i + 1's dx = 0 nodes ARE zone i's dx = 3 nodes, read off the
+// element -> node map, nothing about the mesh is assumed) the set is stored as 16 rows (dz, dy) of the set's 16 x-nodes
+// with the four shared faces summed by K1: 256 instead of 320 doubles per component, every row one cache line.  Sets
+// that are not chains (a row of zones ends inside them; the short last set; any unstructured numbering) keep the
+// element-local layout.  The plane of a component is the concatenation of the sets' slices; everything K2 and the
+// several-rank gathers know about the layout is the ELL table built here.
+//   pos[e * ND + d]: where the entry lives in a plane;  sec[...] = 1: the right-hand member of a merged pair
+//   settab[s]: (offset of the set's slice / 64) | chain << 31
+struct SlabLayout
+{
+   std::vector<unsigned> settab;
+   std::vector<int> pos;
+   std::vector<uint8_t> sec;
+   size_t n_merged = 0;
+};
+static int slab_merge_layout(lgh_ctx *c, SlabLayout &L)
+{
+   constexpr int ES = 5, D = 4, ND = 64;
+   if (c->D1D != D || c->dim != 3) { set_error("slab_merge_layout: Q3 only"); return LGH_ERR_UNSUPPORTED; }
+   const int NE = c->NE, nset = ceil_div(NE, ES);
+   std::vector<int> map((size_t)NE * ND);
+   LGH_HIP_CHECK(hipMemcpy(map.data(), c->h1map, map.size() * sizeof(int), hipMemcpyDeviceToHost));
+   L.settab.assign((size_t)nset, 0u);
+   L.pos.assign((size_t)NE * ND, 0);
+   L.sec.assign((size_t)NE * ND, 0);
+   L.n_merged = 0;
+   size_t off = 0; // doubles
+   for (int s = 0; s < nset; s++)
+   {
+      const int e0 = ES * s, nel = std::min(ES, NE - e0);
+      bool chain = (nel == ES);
+      for (int i = 0; chain && i + 1 < ES; i++)
+      {
+         const int *ma = &map[(size_t)(e0 + i) * ND], *mb = &map[(size_t)(e0 + i + 1) * ND];
+         for (int k = 0; chain && k < D * D; k++) { chain = (ma[D * k + (D - 1)] == mb[D * k]); }
+      }
+      if (off % 64 != 0 || off / 64 > 0x7fffffffull) { set_error("slab_merge_layout: plane offset out of range"); return LGH_ERR_UNSUPPORTED; }
+      L.settab[s] = (unsigned)(off / 64) | (chain ? 0x80000000u : 0u);
+      for (int i = 0; i < nel; i++)
+      {
+         for (int d = 0; d < ND; d++)
+         {
+            const size_t idx = (size_t)(e0 + i) * ND + d;
+            if (!chain) { L.pos[idx] = (int)(off + (size_t)i * ND + d); continue; }
+            const int dx = d % D, row = d / D; // row = dy + 4 dz
+            L.pos[idx] = (int)(off + (size_t)row * 16 + 3 * i + dx);
+            if (i > 0 && dx == 0) { L.sec[idx] = 1; L.n_merged++; }
+         }
+      }
+      off += chain ? 256 : (size_t)nel * ND;
+   }
    return LGH_OK;
 }
 // bit k of entry n: node n is essential for component k
@@ -1747,11 +1824,21 @@ struct VcgAux
    long long *limbs = nullptr; // exact accumulators of (d, A d), 2 parities (lgh_vcg.hpp)
    long long *rzl = nullptr;   // exact accumulators of (r, z), 3 sets (rz_limbs mode)
    int grid2 = 0;
+   // merged E-vector layout of the slab K1 (slab_merge_layout): its set table and the tables of K2 for that layout
+   unsigned *settab = nullptr;
+   int *ellm = nullptr;
+   int degm = 0;
+   unsigned *ellzm = nullptr;
+   int *nstartm = nullptr;
 };
 void vcg_free(lgh_ctx *c)
 {
    VcgAux *x = (VcgAux *)c->vcg_aux;
    if (!x) { return; }
+   (void)hipFree(x->settab);
+   (void)hipFree(x->ellm);
+   (void)hipFree(x->ellzm);
+   (void)hipFree(x->nstartm);
    (void)hipFree(x->ye);
    (void)hipFree(x->ellz);
    (void)hipFree(x->essbits);
@@ -1882,6 +1969,41 @@ struct VcgPlan
    int k1form;
    bool k2p;
 };
+// the tables of K2 (and of the several-rank gathers) for the merged layout: the ELL transpose with every merged pair as
+// ONE entry, its byte-offset form, node ranges balanced by the contributions that are left
+static int vcg_build_merged_tables(lgh_ctx *c, VcgAux *x)
+{
+   SlabLayout L;
+   int rc = slab_merge_layout(c, L);
+   if (rc) { return rc; }
+   const size_t N = (size_t)c->N;
+   const int deg = c->t_deg;
+   std::vector<int> ell((size_t)deg * N), ellm((size_t)8 * N, -1), val(N, 0);
+   LGH_HIP_CHECK(hipMemcpy(ell.data(), c->t_ell, ell.size() * sizeof(int), hipMemcpyDeviceToHost));
+   int degm = 0;
+   for (size_t n = 0; n < N; n++)
+   {
+      int cnt = 0;
+      for (int j = 0; j < deg; j++)
+      {
+         const int p = ell[(size_t)j * N + n];
+         if (p < 0 || L.sec[p]) { continue; } // (the right-hand member of a merged pair: summed into its partner's entry by K1)
+         ellm[(size_t)cnt * N + n] = L.pos[p];
+         cnt++;
+      }
+      val[n] = cnt;
+      degm = std::max(degm, cnt);
+   }
+   x->degm = degm;
+   LGH_HIP_CHECK(hipMalloc((void **)&x->settab, L.settab.size() * sizeof(unsigned)));
+   LGH_HIP_CHECK(hipMemcpy(x->settab, L.settab.data(), L.settab.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+   LGH_HIP_CHECK(hipMalloc((void **)&x->ellm, ellm.size() * sizeof(int)));
+   LGH_HIP_CHECK(hipMemcpy(x->ellm, ellm.data(), ellm.size() * sizeof(int), hipMemcpyHostToDevice));
+   rc = make_ellz(c, &x->ellzm, x->ellm, 8);
+   if (rc) { return rc; }
+   return partition_nodes_by_cost(c, x->grid2, &x->nstartm, &val);
+}
+
 static int vcg_prepare(lgh_ctx *c, double *B, double *X, double rel_tol, VcgPlan &plan)
 {
    const bool multi = c->multi != 0;
@@ -1923,11 +2045,11 @@ static int vcg_prepare(lgh_ctx *c, double *B, double *X, double rel_tol, VcgPlan
          if (genv && atoi(genv) > 0) { x->grid2 = atoi(genv) * ncu; }
          else { x->grid2 = (int)std::max<long>(4L * ncu, (((long)c->N + 1023) / 1024 + 7) & ~7L); }
          x->grid2 = std::min<long>(x->grid2, (long)c->vcg_stride - (long)kShards); // (one partial per workgroup in a reduction slot)
-         rc = make_ellz(c, &x->ellz);
+         rc = make_ellz(c, &x->ellz, nullptr, 0);
          if (rc) { return rc; }
          rc = make_essbits(c, &x->essbits);
          if (rc) { return rc; }
-         rc = partition_nodes_by_cost(c, x->grid2, &x->nstart);
+         rc = partition_nodes_by_cost(c, x->grid2, &x->nstart, nullptr);
          if (rc) { return rc; }
          if ((size_t)kVC * (c->NE + 1) * c->ND * 8 < 0xffffffffull)
          {
@@ -1954,6 +2076,14 @@ static int vcg_prepare(lgh_ctx *c, double *B, double *X, double rel_tol, VcgPlan
          LGH_HIP_CHECK(hipMalloc((void **)&x->rzl, 3 * kLimbWords * sizeof(long long)));
          LGH_HIP_CHECK(hipMemset(x->rzl, 0, 3 * kLimbWords * sizeof(long long)));
       }
+      {
+         const char *menv = getenv("LGH_SLAB_MERGE"); // A/B: 0 = element-local E-vector for every set (the layout of rounds 3 and 4)
+         if (vcg_k1_form(c) == 4 && x->ellz && !(menv && menv[0] == '0'))
+         {
+            rc = vcg_build_merged_tables(c, x);
+            if (rc) { return rc; }
+         }
+      }
       LGH_HIP_CHECK(hipStreamSynchronize(nullptr)); // the fills run asynchronously on the null stream
    }
    VcgAux *aux = (VcgAux *)c->vcg_aux;
@@ -1965,7 +2095,9 @@ static int vcg_prepare(lgh_ctx *c, double *B, double *X, double rel_tol, VcgPlan
    long long *limbs = (c->slab_exact && k2p && k1form == 4) ? aux->limbs : nullptr;
    // rz_limbs mode: one rank, exact accumulators with the deferred fold (LGH_RZ_LIMBS=0: the ticketed fold of (r, z) in K2)
    const char *rzenv = getenv("LGH_RZ_LIMBS");
-   long long *rzl = (limbs && !multi && !(rzenv && rzenv[0] == '0')) ? aux->rzl : nullptr;
+   // (several ranks, round 5: all-pairs partitions, where the words of every rank reach every other in one exchange)
+   // (a communicator of size 1 - LGH_FORCE_MULTI - has nobody to exchange with: the words are complete as they are)
+   long long *rzl = (limbs && (!multi || ((halo_can_piggyback(c) || c->nranks == 1) && c->t_deg <= 8)) && !(rzenv && rzenv[0] == '0')) ? aux->rzl : nullptr;
    {
       const char *e0 = getenv("LGH_SLAB_DEFER");
       if (e0 && e0[0] == '0') { rzl = nullptr; } // (needs the deferred fold of (d, A d) as well)
@@ -2004,8 +2136,22 @@ static int vcg_prepare(lgh_ctx *c, double *B, double *X, double rel_tol, VcgPlan
    a.nstart = aux->nstart;
    a.mapb = aux->mapb;
    a.map_xrows = aux->map_xrows;
+   if (k1form == 4 && aux->settab)
+   {
+      // merged E-vector layout: K1 stores by the set table, everybody who reads Y_E goes through the tables of that layout
+      a.settab = aux->settab;
+      a.ell = aux->ellm;
+      a.deg = aux->degm;
+      a.ellz = aux->ellzm;
+      a.nstart = aux->nstartm;
+   }
    a.limbs = limbs;
    a.rzl = rzl;
+   if (rzl && multi)
+   {
+      rc = comm_word_peers(c, kLimbWords, &a.rzl_peers, &a.n_rz_peers);
+      if (rc) { return rc; }
+   }
    a.queue = limbs ? (unsigned *)(limbs + 2 * kLimbWords) : nullptr;
    {
       const char *e0 = getenv("LGH_SLAB_DEFER"); // A/B: 0 = the last workgroup of K1 folds the accumulators (ticket), K2 reads the result
@@ -2038,7 +2184,7 @@ static int vcg_prepare(lgh_ctx *c, double *B, double *X, double rel_tol, VcgPlan
       {
          a.pack_halo = 1;
          a.nx_den = halo_can_piggyback(c) ? kVC : 0;
-         a.pack_rz = halo_can_piggyback(c) ? 1 : 0;
+         a.pack_rz = (halo_can_piggyback(c) && !rzl) ? 1 : 0; // (rz_limbs mode: (r, z) travels as accumulator words, exchange_words)
       }
    }
    plan.a = a;
@@ -2149,8 +2295,8 @@ int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
       if (!first_look || max_iter <= 0)
       {
          // several ranks: the outcome of the last enqueued update is still pending (vcg_pending_update) - commit it
-         if (multi && it > 0) { hipLaunchKernelGGL(vcg_update_finish_k, dim3(1), dim3(1), 0, c->stream, ds, it); }
-         if (a.rzl && it > 0) { hipLaunchKernelGGL(vcg_rz_finish_k, dim3(1), dim3(1), 0, c->stream, ds, a.rzl, it); }
+         if (multi && !a.rzl && it > 0) { hipLaunchKernelGGL(vcg_update_finish_k, dim3(1), dim3(1), 0, c->stream, ds, it); }
+         if (a.rzl && it > 0) { hipLaunchKernelGGL(vcg_rz_finish_k, dim3(1), dim3(1), 0, c->stream, ds, a.rzl, it, a.rzl_peers, a.n_rz_peers); }
          LGH_HIP_CHECK(hipMemcpyAsync(hs, ds, sizeof(VcgScalars), hipMemcpyDeviceToHost, c->stream));
          LGH_HIP_CHECK(hipStreamSynchronize(c->stream));
          if (hs->all_done || it >= max_iter) { break; }
@@ -2218,7 +2364,14 @@ int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
             if (mixed && k2p) { launch_k2p(); }
             else if (mixed) { hipLaunchKernelGGL((vcg_update_k<true, 8>), dim3(nb), dim3(256), 0, c->stream, a); }
             else { hipLaunchKernelGGL((vcg_update_k<false, 0>), dim3(nb), dim3(256), 0, c->stream, a); }
-            if (multi)
+            if (multi && a.rzl)
+            {
+               // exact all-reduce of (r, z): the accumulator words K2 just added into go to every peer as they are - no fold,
+               // no pack, no combine kernel; the next K1 (or vcg_rz_finish_k) adds own and peers' words before it folds
+               rc = exchange_words(c, a.rzl + (it % 3) * kLimbWords, kLimbWords);
+               if (rc) { return rc; }
+            }
+            else if (multi)
             {
                rc = allreduce_dev(c, ds->rz, kVC, 0, a.pack_rz != 0 && mixed && k2p); // convergence is looked at by the next K1 (vcg_pending_update)
                if (rc) { return rc; }
@@ -2274,6 +2427,63 @@ __global__ void vcg_test_put_rz_k(long long *set, double v0, double v1, double v
       if (!ok) { set[kLimbShards * kVC * kLimbs] = 1; }
    }
 }
+// Test hooks and the merged layout: the hooks speak the element-local E-vector ([e][d] per component) on both sides.
+// Out of K1: every entry from its place in the plane; the right-hand member of a merged pair reads 0.0 and the sum K1
+// formed is reported in the left-hand zone's entry (lgh_test_vcg_merged_faces tells the caller which entries those are).
+// Into K2: a merged place receives the sum of its two entries (what K1 would have stored there).
+__global__ void __launch_bounds__(256)
+vcg_unpack_merged_k(const double *__restrict__ plane, const int *__restrict__ pos, const uint8_t *__restrict__ sec, double *__restrict__ out, const size_t n)
+{
+   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+   if (i < n) { out[i] = sec[i] ? 0.0 : plane[pos[i]]; }
+}
+__global__ void __launch_bounds__(256)
+vcg_pack_merged_k(const double *__restrict__ in, const int *__restrict__ pos, const uint8_t *__restrict__ sec, const int ND, double *__restrict__ plane, const size_t n)
+{
+   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+   if (i >= n || sec[i]) { return; }
+   double v = in[i];
+   const size_t j = i + (size_t)ND - 3; // same (dy, dz), dx = 0 of the next zone - the partner of a dx = 3 entry of a chain
+   if ((i % 4) == 3 && j < n && sec[j] && pos[j] == pos[i]) { v += in[j]; }
+   plane[pos[i]] = v;
+}
+struct MergedDev
+{
+   int *pos = nullptr;
+   uint8_t *sec = nullptr;
+   ~MergedDev() { (void)hipFree(pos); (void)hipFree(sec); }
+};
+static int merged_to_device(lgh_ctx *c, MergedDev &m)
+{
+   SlabLayout L;
+   const int rc = slab_merge_layout(c, L);
+   if (rc) { return rc; }
+   LGH_HIP_CHECK(hipMalloc((void **)&m.pos, L.pos.size() * sizeof(int)));
+   LGH_HIP_CHECK(hipMalloc((void **)&m.sec, L.sec.size()));
+   LGH_HIP_CHECK(hipMemcpy(m.pos, L.pos.data(), L.pos.size() * sizeof(int), hipMemcpyHostToDevice));
+   LGH_HIP_CHECK(hipMemcpy(m.sec, L.sec.data(), L.sec.size(), hipMemcpyHostToDevice));
+   return LGH_OK;
+}
+// lgh_test_vcg_merged_faces: mask[e * ND + d] = 1 where K1 of this context has already summed the entry into its left
+// neighbour's (all zero when the layout is element-local: every other form of K1, LGH_SLAB_MERGE=0)
+int vcg_test_merged_faces(lgh_ctx *c, unsigned char *mask, long *n_merged)
+{
+   const size_t nE = (size_t)c->NE * c->ND;
+   memset(mask, 0, nE);
+   *n_merged = 0;
+   if (!vcg_supported(c)) { return LGH_OK; }
+   VcgPlan plan;
+   const int rc = vcg_prepare(c, nullptr, nullptr, 0.0, plan);
+   if (rc) { return rc; }
+   if (!plan.a.settab) { return LGH_OK; }
+   SlabLayout L;
+   const int rc2 = slab_merge_layout(c, L);
+   if (rc2) { return rc2; }
+   memcpy(mask, L.sec.data(), nE);
+   *n_merged = (long)L.n_merged;
+   return LGH_OK;
+}
+
 // Test hook (lgh_test_vcg_k1): ONE launch of K1, in whichever form vcg_solve dispatches for this context, exactly as
 // the solve would launch it in its first iteration (first != 0: d = r/diag) or in a later one (d = r/diag + beta d_old
 // with beta = rz / rz_prev), on the caller's vectors.  Returns what K1 hands to K2: the element contributions
@@ -2320,11 +2530,19 @@ int vcg_test_k1(lgh_ctx *c, const double *r, const double *d_old, const double r
    LGH_HIP_CHECK(hipGetLastError());
    LGH_HIP_CHECK(hipStreamSynchronize(c->stream));
    LGH_HIP_CHECK(hipMemcpy(&h, ds, sizeof(h), hipMemcpyDeviceToHost));
+   MergedDev md;
+   if (a.settab) { rc = merged_to_device(c, md); if (rc) { return rc; } }
    for (int k = 0; k < kVC; k++)
    {
       den_out[k] = h.den[k];
-      LGH_HIP_CHECK(hipMemcpy(YE_out + (size_t)k * nE, a.YE + (size_t)k * a.ye_stride, nE * sizeof(double), hipMemcpyDeviceToDevice));
+      if (a.settab)
+      {
+         hipLaunchKernelGGL(vcg_unpack_merged_k, dim3((unsigned)((nE + 255) / 256)), dim3(256), 0, c->stream, a.YE + (size_t)k * a.ye_stride, md.pos, md.sec, YE_out + (size_t)k * nE, nE);
+         LGH_HIP_CHECK(hipGetLastError());
+      }
+      else { LGH_HIP_CHECK(hipMemcpy(YE_out + (size_t)k * nE, a.YE + (size_t)k * a.ye_stride, nE * sizeof(double), hipMemcpyDeviceToDevice)); }
    }
+   LGH_HIP_CHECK(hipStreamSynchronize(c->stream));
    return LGH_OK;
 }
 
@@ -2348,9 +2566,16 @@ int vcg_test_k2(lgh_ctx *c, int it, const double *YE_in, double *r, double *d, d
    VcgScalars *ds = (VcgScalars *)c->vcg_s;
    LGH_HIP_CHECK(hipMemcpyAsync(a.r, r, kVC * N * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
    LGH_HIP_CHECK(hipMemcpyAsync(a.d, d, kVC * N * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+   MergedDev md;
+   if (a.settab) { rc = merged_to_device(c, md); if (rc) { return rc; } }
    for (int k = 0; k < kVC; k++)
    {
-      LGH_HIP_CHECK(hipMemcpyAsync(a.YE + (size_t)k * a.ye_stride, YE_in + (size_t)k * nE, nE * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+      if (a.settab)
+      {
+         hipLaunchKernelGGL(vcg_pack_merged_k, dim3((unsigned)((nE + 255) / 256)), dim3(256), 0, c->stream, YE_in + (size_t)k * nE, md.pos, md.sec, c->ND, a.YE + (size_t)k * a.ye_stride, nE);
+         LGH_HIP_CHECK(hipGetLastError());
+      }
+      else { LGH_HIP_CHECK(hipMemcpyAsync(a.YE + (size_t)k * a.ye_stride, YE_in + (size_t)k * nE, nE * sizeof(double), hipMemcpyDeviceToDevice, c->stream)); }
    }
    LGH_HIP_CHECK(hipStreamSynchronize(c->stream)); // (vcg_set_tol_k has cleared the accumulators)
    VcgScalars h;
@@ -2377,7 +2602,7 @@ int vcg_test_k2(lgh_ctx *c, int it, const double *YE_in, double *r, double *d, d
    else if (c->t_deg <= 8) { hipLaunchKernelGGL((vcg_update_k<true, 8>), dim3(ceil_div((long)N, 256)), dim3(256), 0, c->stream, a); }
    else { set_error("lgh_test_vcg_k2: unusual valence (the unfused gather runs in the solve)"); return LGH_ERR_UNSUPPORTED; }
    LGH_HIP_CHECK(hipGetLastError());
-   if (a.rzl && plan.k2p) { hipLaunchKernelGGL(vcg_rz_finish_k, dim3(1), dim3(1), 0, c->stream, ds, a.rzl, it); }
+   if (a.rzl && plan.k2p) { hipLaunchKernelGGL(vcg_rz_finish_k, dim3(1), dim3(1), 0, c->stream, ds, a.rzl, it, (const long long *)nullptr, 0); }
    LGH_HIP_CHECK(hipGetLastError());
    LGH_HIP_CHECK(hipStreamSynchronize(c->stream));
    LGH_HIP_CHECK(hipMemcpy(&h, ds, sizeof(h), hipMemcpyDeviceToHost));

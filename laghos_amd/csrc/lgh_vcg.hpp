@@ -197,6 +197,8 @@ struct VcgArgs
    int map_xrows;         // 1: the D1D nodes of every x-row of every element are consecutive node numbers (checked at set-up)
    unsigned *queue;       // slab-form K1, dynamic schedule: one set counter per XCD range, 128 bytes apart (zero between launches)
    long long *rzl;        // rz_limbs mode: three sets of kLimbWords words, exact accumulators of (r, z) (see vcg_rz_commit), or nullptr
+   const long long *rzl_peers; // several ranks, rz_limbs mode: the other ranks' words of the set K2 just added into (n_rz_peers blocks of
+   int n_rz_peers;             // kLimbWords, exchange_words) - whoever folds a set adds them to the own words: an exact all-reduce
    long long *limbs;      // exact accumulators of (d, A d): two sets of kLimbWords words (slab-form K1), or nullptr (ticketed fold of workgroup partials)
    int den_limbs;         // 1: K1 only adds into set (iter & 1) of limbs - no ticket, no last workgroup; K2 folds the set itself (exact_den) and clears the other one
    const int *ell;
@@ -227,6 +229,11 @@ struct VcgArgs
    int k2_skip;               // vcg_update_p_k: skip ELL slots no node of the wavefront uses (LGH_K2_SKIP=0: fetch all 8)
    int store_wait;        // slab-form K1 (A/B, LGH_SLAB_STORE_WAIT): every wavefront waits for the stores of a pass before it starts the next one
    int ye_wide;           // slab-form K1: the three planes of Y_E exceed 4 GB - per-set 64-bit store base instead of 32-bit offsets from Y_E
+   // slab-form K1, merged E-vector layout (round 5; LGH_SLAB_MERGE=0: nullptr): one word per set of five zones - bits 0..30 the
+   // set's slice of a Y_E plane in units of 64 doubles, bit 31 set when the five zones are x-neighbours ("x-chain": zone i + 1's
+   // dx = 0 nodes are zone i's dx = 3 nodes, checked on the map) and the set is stored as 16 rows (dz, dy) of 16 x-nodes with the
+   // shared x-faces already summed (256 doubles) instead of 5 x 64 element-local values; ell / ellz / nstart then describe THAT layout
+   const unsigned *settab;
    // several ranks: kernels that fill the send buffer themselves (one launch less per exchange)
    HaloPackTables hp;
    const int *sh_off;     // (= hp.sh_off: CSR of the unique shared nodes over the entries of the neighbour lists)

@@ -35,6 +35,15 @@ typedef v2d v2d_a8 __attribute__((aligned(8))); // 16-byte loads at 8-byte align
 
 __device__ __forceinline__ double slab_ld(const double *base, const unsigned off) { return *(const double *)((const char *)base + off); }
 
+// lane i of every row of 16 lanes receives the value of lane i - K of the same row (DPP row_shr:K, the direction the wave
+// reductions of lgh_common.hpp use; a lane whose source lies outside the row receives 0.0)
+template <int K> __device__ __forceinline__ double dpp_row_shr(const double v)
+{
+   const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x110 + K, 0xF, 0xF, true);
+   const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x110 + K, 0xF, 0xF, true);
+   return __hiloint2double(hi, lo);
+}
+
 // After the call (H = 32 or 16, "side" = bit 5 or bit 4 of the lane number): a = the a or b of the side-0 lane of the
 // pair, b = that of the side-1 lane - each lane keeps the register that carries its side's number and receives the
 // same register of its partner:  side 0: (a, b) = (own a, partner's a);  side 1: (a, b) = (partner's b, own b).
@@ -264,6 +273,9 @@ vcg_apply_slab346(const VcgArgs a, const int nset)
       }
    };
    load_map(s, mo);
+   // merged E-vector layout (a.settab, lgh_vcg.hpp): word of the set being contracted - its slice of a Y_E plane in units
+   // of 64 doubles, bit 31: the set is an x-chain whose rows are stored merged; the word of the next set is read a pass ahead
+   unsigned tw_cur = a.settab ? a.settab[min(s, nset - 1)] : 0u;
    // Everything else the prologue needs from memory goes out WITH the map, ahead of the first wait: the scalars of the
    // solve and the 1-D table.  (Round 3 read them one after the other behind the gathers - convergence flag, then the
    // done flags and (r, z), then the table: four dependent round trips of ~1.2 us between a workgroup's arrival and its
@@ -283,7 +295,13 @@ vcg_apply_slab346(const VcgArgs a, const int nset)
    }
    // (the words of that set: one per lane, one load instruction in this batch - not a round trip of its own later)
    long long rz_word = 0;
-   if (a.rzl && a.iter > 1 && lane <= kLimbShards * kVC * kLimbs) { rz_word = a.rzl[((a.iter - 1) % 3) * kLimbWords + lane]; }
+   if (a.rzl && a.iter > 1 && lane <= kLimbShards * kVC * kLimbs)
+   {
+      rz_word = a.rzl[((a.iter - 1) % 3) * kLimbWords + lane];
+      // several ranks: the words of the other ranks, as the exchange after K2 left them - own + peers' is the sum over
+      // the ranks, the same integers on every rank (the flag word adds up to "some rank's sum is bad")
+      for (int p = 0; p < a.n_rz_peers; p++) { rz_word += a.rzl_peers[p * kLimbWords + lane]; }
+   }
    constexpr int NTAB = KRON ? D * D : HB;
    double tabv[NTAB];
 #pragma unroll
@@ -382,12 +400,22 @@ vcg_apply_slab346(const VcgArgs a, const int nset)
       }
       if (blockIdx.x == 0)
       {
-         if (tid == 0) { vcg_rz_commit(a.s, a.iter, sc_rz, dn); }
+         if (tid == 0)
+         {
+            vcg_rz_commit(a.s, a.iter, sc_rz, dn);
+            // several ranks: the exchanges of launches enqueued past a component's convergence go on summing its (d, A d)
+            // over the ranks - they must sum zeros (see vcg_update_finish_k)
+            if (a.multi)
+            {
+#pragma unroll
+               for (int k = 0; k < kVC; k++) { if (dn[k]) { __hip_atomic_store(&a.s->den[k], 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } }
+            }
+         }
          if (tid < kLimbWords) { a.rzl[(a.iter % 3) * kLimbWords + tid] = 0; }
       }
       if (!(todo[0] || todo[1] || todo[2])) { __builtin_amdgcn_s_waitcnt(0x0F70); return; }
    }
-   if (a.multi && !first && !vcg_pending_update(a.s, a.iter, blockIdx.x == 0 && tid == 0, todo)) { __builtin_amdgcn_s_waitcnt(0x0F70); return; }
+   if (a.multi && !a.rzl && !first && !vcg_pending_update(a.s, a.iter, blockIdx.x == 0 && tid == 0, todo)) { __builtin_amdgcn_s_waitcnt(0x0F70); return; }
 #pragma unroll
    for (int k = 0; k < kVC; k++) { beta[k] = (first || !todo[k]) ? 0.0 : sc_rz[k] / sc_rzp[k]; }
    const bool mine = (c == 0) ? todo[0] : (c == 1) ? todo[1] : todo[2];
@@ -458,6 +486,8 @@ vcg_apply_slab346(const VcgArgs a, const int nset)
       load_gather_part(0);
       load_dq(DYN ? max(s1, 0) : s1, sDnxt);
       load_map(DYN ? max(s2, 0) : s2, mn);
+      unsigned tw_nxt = 0u;
+      if (a.settab) { tw_nxt = a.settab[__builtin_amdgcn_readfirstlane(min(max(s1, 0), nset - 1))]; } // (wave-uniform: a scalar load, a pass ahead of its use)
       LGH_SLAB_STAMP(0); // issue of the loads
       double o[16], dset = 0.0;
       // (The body only runs with a set to contract: s0 >= 0 - the sets of a wavefront are a run of valid ones followed by
@@ -664,19 +694,83 @@ vcg_apply_slab346(const VcgArgs a, const int nset)
       for (int j = 0; j < 16; j += (WIDE ? 4 : 1)) { mo[j] = mn[j]; }
       __builtin_amdgcn_sched_barrier(0);
       LGH_SLAB_STAMP(6); // wait + direction of the next set
-      // the slab of the E-vector: 16 contiguous doubles per lane, stored as whole lines by groups of eight lanes (above)
+      // the slab of the E-vector: 16 contiguous doubles per lane, stored as whole lines by groups of eight lanes (above);
+      // an x-chain set of the merged layout: 48 rows of 16 x-nodes, the shared x-faces summed here (below)
       {
          double *tl = RANK1 ? (sDb + wid * SBUF) : const_cast<double *>(sDcur); // (not RANK1: the data of this set has been used)
-         v2d *wp = (v2d *)(tl + lane * TP);
-#pragma unroll
-         for (int j = 0; j < 8; j++) { wp[j] = v2d{o[2 * j] * se, o[2 * j + 1] * se}; }
-         __builtin_amdgcn_wave_barrier(); // (one wavefront: its LDS instructions execute in order; this only pins the compiler)
          const int s0c = max(s0, 0);
          const int nel = min(ES, a.NE - ES * s0c); // elements of this set (the last one may be short)
          // one scalar base + 32-bit byte offsets while the three planes of Y_E fit 4 GB (every mesh up to 140^3 zones);
          // beyond that (a.ye_wide) the set's offset goes into the base and only the per-lane part has to fit
-         const unsigned set_off = 8u * (unsigned)ND * (unsigned)(ES * s0c);
-         char *const set_base = (char *)a.YE + (size_t)8 * ND * ES * (size_t)s0c;
+         const bool tabled = a.settab != nullptr;
+         const bool chain = tabled && (tw_cur >> 31) != 0u;
+         const unsigned set_off = tabled ? (tw_cur & 0x7fffffffu) * 512u : 8u * (unsigned)ND * (unsigned)(ES * s0c);
+         char *const set_base = (char *)a.YE + (tabled ? (size_t)(tw_cur & 0x7fffffffu) * 512 : (size_t)8 * ND * ES * (size_t)s0c);
+         if (chain)
+         {
+            // Merged rows (round 5).  The five zones of this set are x-neighbours (checked on the map at set-up): zone el
+            // and zone el + 1 share the 16 nodes of an x-face, and the two contributions to such a node are added HERE -
+            // a lane shift by three items (DPP row_shr:3: item n - 3 is the same component of the zone to the left) - instead
+            // of travelling to K2 as two values behind two table entries.  A component's slice of the set is then 16 rows
+            // (dz, dy) of 16 x-nodes: 256 instead of 320 doubles, every row one 128-byte line, and the node kernel's
+            // wavefronts - consecutive nodes of an x-line - read whole lines of it.  The rows are assembled in the
+            // wavefront's LDS buffer (lane (g, el, c) owns x = 3 el .. 3 el + 2 of the rows (c, dz = g, dy), zone 4 also
+            // x = 15) and leave as six instructions of 1 KB: eight complete lines each.
+            constexpr int RB = 66; // doubles per (component, dz) block of four rows in the exchange buffer (64 + 2: blocks start on different banks)
+            static_assert(12 * RB <= SBUF, "the rows of a set fit the wavefront's exchange buffer");
+            double os[16];
+#pragma unroll
+            for (int j = 0; j < 16; j++) { os[j] = o[j] * se; }
+#pragma unroll
+            for (int dy = 0; dy < 4; dy++)
+            {
+               // x = 3 el is this zone's dx = 0 AND the left zone's dx = 3: the owner of the place (this lane) takes the sum
+               const double t = dpp_row_shr<3>(os[4 * dy + 3]); // (dx = 3 column of the zone to the left: three items down)
+               os[4 * dy] += (el > 0) ? t : 0.0;
+            }
+            if (n < 15)
+            {
+               double *rw = tl + (4 * c + g) * RB + 3 * el;
+#pragma unroll
+               for (int dy = 0; dy < 4; dy++)
+               {
+                  rw[16 * dy + 0] = os[4 * dy + 0];
+                  rw[16 * dy + 1] = os[4 * dy + 1];
+                  rw[16 * dy + 2] = os[4 * dy + 2];
+                  if (el == ES - 1) { rw[16 * dy + 3] = os[4 * dy + 3]; }
+               }
+            }
+            __builtin_amdgcn_wave_barrier(); // (one wavefront: its LDS instructions execute in order; this only pins the compiler)
+            // piece q = 64 k + lane of the 384 16-byte pieces: row q >> 3 = 4 (block) + dy, piece q & 7 of the row
+            const v2d *rp = (const v2d *)(tl + (lane >> 5) * RB + 16 * ((lane >> 3) & 3) + 2 * (lane & 7));
+            double vlo[6], vhi[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++)
+            {
+               const v2d val = rp[k * RB]; // (8 rows = 2 blocks further per instruction: 2 RB doubles = RB pieces)
+               vlo[k] = val[0];
+               vhi[k] = val[1];
+            }
+#pragma unroll
+            for (int k = 0; k < 6; k++) { asm volatile("" : "+v"(vlo[k]), "+v"(vhi[k])); }
+#pragma unroll
+            for (int k = 0; k < 6; k++)
+            {
+               const bool live = (k < 2) ? todo[0] : (k < 4) ? todo[1] : todo[2];
+               if (live)
+               {
+                  const unsigned off = 16u * (unsigned)lane + 1024u * (unsigned)(k & 1) + 8u * (unsigned)(k >> 1) * (unsigned)a.ye_stride;
+                  if (a.ye_wide) { *(v2d *)(set_base + off) = v2d{vlo[k], vhi[k]}; }
+                  else { *(v2d *)((char *)a.YE + (off + set_off)) = v2d{vlo[k], vhi[k]}; }
+               }
+            }
+         }
+         else
+         {
+         v2d *wp = (v2d *)(tl + lane * TP);
+#pragma unroll
+         for (int j = 0; j < 8; j++) { wp[j] = v2d{o[2 * j] * se, o[2 * j + 1] * se}; }
+         __builtin_amdgcn_wave_barrier(); // (one wavefront: its LDS instructions execute in order; this only pins the compiler)
          const v2d *rp = (const v2d *)(tl + (lane & ~7) * TP) + (lane & 7);
          // (all eight reads first, pinned: inside the predicated blocks each of them would be followed by a wait for
          //  the LDS - eight round trips in a row, a seventh of the pass)
@@ -699,6 +793,8 @@ vcg_apply_slab346(const VcgArgs a, const int nset)
                else { *(v2d *)((char *)a.YE + (st_off[k] + set_off)) = v2d{vlo[k], vhi[k]}; }
             }
          }
+         }
+         tw_cur = tw_nxt;
       }
       if (a.store_wait) { __builtin_amdgcn_s_waitcnt(0x0F70); }
       LGH_SLAB_STAMP(7); // stores

@@ -246,6 +246,18 @@ class Hydro:
                            self.cg_max_iter if max_iter is None else max_iter)
         return x, it
 
+    def cg_state(self, space=0):
+        """(r, d, [nom, den, alpha, betanom]) of the recurrence as the last cg() call left it: the residual, the direction
+        of the last iteration performed, and that iteration's scalars (lgo_cg_vec / lgo_cg_scalars)."""
+        n = self.p.N if space == 0 else self.p.L2V
+        self.L.lgo_cg_vec.restype = ctypes.POINTER(ctypes.c_double)
+        self.L.lgo_cg_vec.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        r = np.ctypeslib.as_array(self.L.lgo_cg_vec(self.h, 0), shape=(n,)).copy()
+        d = np.ctypeslib.as_array(self.L.lgo_cg_vec(self.h, 2), shape=(n,)).copy()
+        sc = np.zeros(4)
+        self.L.lgo_cg_scalars(self.h, _dp(sc))
+        return r, d, sc
+
     def internal_energy(self, S):
         e = np.ascontiguousarray(S[2 * self.p.H1V:])
         return self.L.lgo_internal_energy(self.h, _dp(e))

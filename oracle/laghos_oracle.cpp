@@ -897,6 +897,7 @@ struct Ctx
    // scratch
    std::vector<double> XE, YE, q_dx, q_dv, q_e, q_dt, e_vec;
    std::vector<double> cg_r, cg_z, cg_d;
+   double cg_last[4] = {0, 0, 0, 0}; // lgo_cg: nom, den, alpha, betanom of the last iteration performed (lgo_cg_scalars)
    // timers (laghos_solver.hpp:39-56)
    double t_force, t_cgH1, t_cgL2, t_qdata;
    long H1iter, L2iter, quad_tstep;
@@ -1372,6 +1373,7 @@ int lgo_cg(void *h, int space, const double *b, double *x, double rel_tol, int m
       for (int i = 1; true;)
       {
          const double alpha = nom / den;
+         c->cg_last[0] = nom; c->cg_last[1] = den; c->cg_last[2] = alpha;
 #pragma omp parallel for schedule(static)
          for (int k = 0; k < n; k++)
          {
@@ -1386,6 +1388,7 @@ int lgo_cg(void *h, int space, const double *b, double *x, double rel_tol, int m
             betanom = dot(r, z);
          }
          else { betanom = dot(r, r); }
+         c->cg_last[3] = betanom;
          if (betanom < 0.0) { final_iter = i; break; }
          if (betanom <= r0) { final_iter = i; break; }
          if (++i > max_iter) { break; }
@@ -1410,6 +1413,20 @@ done:
    if (space == 0) { c->t_cgH1 += now() - t0; c->H1iter += final_iter; }
    else { c->t_cgL2 += now() - t0; c->L2iter += (final_iter == 0) ? 1 : final_iter; } // laghos_solver.cpp:486
    return final_iter;
+}
+
+// The recurrence as the last lgo_cg call left it (tests/test_gpu_k2.py holds ONE launch of the HIP path's node kernel
+// against one iteration of THIS loop): which = 0: r, 1: z (space 0: r / diag; space 1: the last A d), 2: d - the
+// direction of the last iteration performed; out[4] = (r, z) before that iteration, (d, A d), alpha, (r, z) after it.
+const double *lgo_cg_vec(void *h, int which)
+{
+   Ctx *c = (Ctx *)h;
+   return which == 0 ? c->cg_r.data() : which == 1 ? c->cg_z.data() : c->cg_d.data();
+}
+void lgo_cg_scalars(void *h, double out[4])
+{
+   Ctx *c = (Ctx *)h;
+   for (int k = 0; k < 4; k++) { out[k] = c->cg_last[k]; }
 }
 
 // LagrangianHydroOperator::Mult (laghos_solver.cpp:308-327) with

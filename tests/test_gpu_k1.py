@@ -86,6 +86,19 @@ def _run_case(prob, monkeypatch, variant, form, rank1, first):
         yE, den = g.ctx.test_vcg_k1(g.ctx.to_dev(r), None if first else g.ctx.to_dev(d_old), rz, rz_prev, first)
         assert g.ctx.mass_data_form() == ("rank1" if rank1 else "stored")
         yE = yE.cpu().numpy()
+        # Merged E-vector layout of the slab K1 (round 5): where the zones of a set are x-neighbours the two contributions to
+        # a node of a shared x-face leave K1 as ONE value - reported in the left zone's dx = 3 entry, 0.0 in the right zone's
+        # dx = 0 entry (lgh_test_vcg_merged_faces marks those).  The oracle's element contributions are summed the same way.
+        mask, n_merged = g.ctx.test_vcg_merged_faces()
+        merged = os.environ.get("LGH_SLAB_MERGE") != "0" and expect == "slab"
+        assert merged or n_merged == 0  # (whether a mesh HAS x-chains of five zones depends on its rows: the callers below say where it must)
+        if n_merged:
+            idx = np.nonzero(mask)[0]
+            assert np.all(idx % prob.D1D == 0) and np.all(idx >= prob.ND)  # dx = 0 entries of a zone with a left neighbour
+            yE_o = yE_o.copy()
+            for c in range(3):
+                yE_o[c, idx - prob.ND + (prob.D1D - 1)] += yE_o[c, idx]    # (same dy, dz; dx = 3 of the zone before)
+                yE_o[c, idx] = 0.0
     finally:
         g.close()
         o.close()
@@ -93,6 +106,7 @@ def _run_case(prob, monkeypatch, variant, form, rank1, first):
     for c in range(3):
         assert rel_err(yE[c], yE_o[c]) < tol, (c, "E-vector")
         assert abs(den[c] - den_o[c]) <= tol * abs(den_o[c]), (c, "den", den[c], den_o[c])
+    return n_merged
 
 
 @pytest.mark.parametrize("first", [True, False], ids=["first", "later"])
@@ -102,7 +116,9 @@ def test_k1_one_launch_vs_oracle(case, rank1, first, monkeypatch):
     from oracle.fem import Problem
     _, mesh, rs, ok, ot, variant, form = case
     prob = Problem(mesh=mesh, rs=rs, order_v=ok, order_e=ot, problem=1)
-    _run_case(prob, monkeypatch, variant, form, rank1, first)
+    n_merged = _run_case(prob, monkeypatch, variant, form, rank1, first)
+    if case[0] == "Q3Q2-512-slab":  # rows of 8 zones: every other set of five is an x-chain (4 faces x 16 nodes merged in each)
+        assert n_merged == 51 * 64
 
 
 @pytest.mark.parametrize("first", [True, False], ids=["first", "later"])
@@ -124,4 +140,41 @@ def test_k1_default_dispatch_at_bench_size(rank1, monkeypatch):
     (slab form from 20 000 zones), one launch against the oracle's mass apply on all 32 768 elements."""
     from oracle.fem import Problem
     prob = Problem(mesh="cube01_hex", rs=4, order_v=3, order_e=2, problem=1)
-    _run_case(prob, monkeypatch, None, "slab", rank1, False)
+    n_merged = _run_case(prob, monkeypatch, None, "slab", rank1, False)
+    assert n_merged > 4000 * 64  # (rows of 32 zones: five or six of every 6.4 sets are x-chains)
+
+
+def test_k1_static_schedule_at_64_cubed(monkeypatch):
+    """64^3 zones (configs 3 / 4 on one GPU): the slab K1 runs its STATIC interleaved schedule there (51 passes per
+    wavefront; the workgroup queues only up to 16) and its merged E-vector has whole x-chains and sets that straddle
+    rows of zones.  An oracle context of that size holds ~10 GB of quadrature data the comparison does not need, so this
+    case is a size-independent property instead: one launch of the slab form and one of the plane form - the form the
+    cases above hold to the oracle at every size the oracle is cheap at - on the same vectors must hand K2 the same
+    assembled A d (E -> L sum through the element -> node map) and the same (d, A d), to the 2e-12 of the compact mass
+    data.  Entries K1 has merged are reported once (lgh_test_vcg_merged_faces): the assembled sum does not care."""
+    from oracle.fem import Problem
+    prob = Problem(mesh="cube01_hex", rs=5, order_v=3, order_e=2, problem=1)
+    N, NE, ND = prob.N, prob.NE, prob.ND
+    hmap = np.asarray(prob.h1map).reshape(-1)
+    r, d_old = seeded(3 * N, 111), seeded(3 * N, 112)
+    out = {}
+    for variant, form in (("4", "slab"), ("2", "plane")):
+        monkeypatch.setenv("LGH_VCG_VARIANT", variant)
+        g = make_gpu(prob)
+        try:
+            assert g.ctx.k1_form() == form
+            dinv = 1.0 / np.asarray(g.ctx.mass_diag)
+            rz = np.array([float(np.dot(r[c * N:(c + 1) * N] ** 2, dinv)) for c in range(3)])
+            yE, den = g.ctx.test_vcg_k1(g.ctx.to_dev(r), g.ctx.to_dev(d_old), rz, rz * np.array([1.7, 0.6, 1.1]), False)
+            yE = yE.cpu().numpy()
+            _, n_merged = g.ctx.test_vcg_merged_faces()
+            assert (n_merged > 0) == (form == "slab")
+            Ad = np.zeros((3, N))
+            for c in range(3):
+                Ad[c] = np.bincount(hmap, weights=yE[c], minlength=N)
+            out[form] = (Ad, den)
+        finally:
+            g.close()
+    for c in range(3):
+        assert rel_err(out["slab"][0][c], out["plane"][0][c]) < 2e-12, c
+        assert abs(out["slab"][1][c] - out["plane"][1][c]) <= 2e-12 * abs(out["plane"][1][c]), c

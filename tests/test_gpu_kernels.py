@@ -715,6 +715,49 @@ def test_slab_k1_switches(switches, monkeypatch):
         assert np.array_equal(ref, dS[H1V:2 * H1V]), "exact accumulation: the result must not depend on the schedule"
 
 
+def test_slab_merged_evector_vs_element_local(monkeypatch):
+    """Round 5: where the five zones of a slab set are x-neighbours K1 sums the shared x-faces itself and stores 16 rows
+    of 16 x-nodes per component (merged E-vector layout, lgh_vcg.hip::slab_merge_layout); LGH_SLAB_MERGE=0 keeps the
+    element-local layout of rounds 3 and 4.  512 zones in rows of 8 (chains, sets that straddle two rows, a ragged last
+    set), distorted state, CG to 1e-14: both layouts give the oracle's dv/dt to the operator tolerance and agree with
+    each other to round-off (the order of the per-node sums differs); within a layout the schedule (workgroup queues or
+    static sets) does not move a bit."""
+    from oracle.fem import Problem
+    prob = Problem(mesh="cube01_hex", rs=2, order_v=3, order_e=2, problem=1)
+    S = deformed_state(prob, seed=71)
+    o = make_oracle(prob)
+    try:
+        o.cg_tol = 1e-14
+        dS_o = np.empty_like(S)
+        o.qdata_is_current = False
+        o.mult(S, dS_o)
+    finally:
+        o.close()
+    H1V = prob.H1V
+    monkeypatch.setenv("LGH_VCG_VARIANT", "4")
+    res = {}
+    for merge in ("1", "0"):
+        for dyn in ("1", "0"):
+            monkeypatch.setenv("LGH_SLAB_MERGE", merge)
+            monkeypatch.setenv("LGH_SLAB_DYN", dyn)
+            g = make_gpu(prob)
+            try:
+                assert g.ctx.k1_form() == "slab"
+                g.cg_tol = 1e-14
+                Sd, dS = g.ctx.to_dev(S), g.ctx.zeros(S.size)
+                g.reset_quadrature_data()
+                g.mult(Sd, dS)
+                g.ctx.sync()
+                _, n_merged = g.ctx.test_vcg_merged_faces()
+                assert (n_merged > 0) == (merge == "1")
+                res[merge, dyn] = dS.cpu().numpy()[H1V:2 * H1V]
+            finally:
+                g.close()
+            assert rel_err(res[merge, dyn], dS_o[H1V:2 * H1V]) < 1e-10
+        assert np.array_equal(res[merge, "1"], res[merge, "0"]), "exact accumulation: the result must not depend on the schedule"
+    assert rel_err(res["1", "1"], res["0", "1"]) < 1e-11
+
+
 @pytest.mark.parametrize("tol,max_iter", [(1e-8, 300), (1e-14, 5), (1e-3, 300), (1e-8, 1)], ids=["tol1e-8", "cut-at-5", "tol1e-3", "one-iteration"])
 def test_slab_cg_bookkeeping_exact_rz(tol, max_iter, monkeypatch):
     """The bookkeeping of the lockstep solve when (r, z) lives in exact accumulators (lgh_vcg.hpp, rz_limbs mode: K2 has
