@@ -234,6 +234,7 @@ def moved_bytes(sz, L, ctx, k1_name):
          E-vector, and with compact mass data (lgh_mass_data_form) reads one double per element instead of NQ;
       L2 mass apply: compact data likewise (plane form);
     everything else moves what §8(d) says."""
+    from laghos_amd import _lib
     dim, D, Ld = sz["dim"], sz["D1D"], sz["L1D"]
     NQ, ND, NL, NE, N = sz["NQ"], D ** dim, Ld ** dim, sz["NE"], sz["N"]
     b = dict(algorithmic_bytes(sz))
@@ -249,10 +250,19 @@ def moved_bytes(sz, L, ctx, k1_name):
     L.lgh_qupdate_stores_stress(ctx, ctypes.byref(st))
     if st.value == 0:  # stress kept in registers: the nine stressJinvT planes are not written
         b[2] -= NE * 8 * dim * dim * NQ
-    b[0] = 8 * (N * (2 * dim + 1) + NE * dim * ND) + (8 * NE if k1_compact else 8 * NE * NQ)
+    # the E-vector between K1 and K2 and K2's table as THIS context lays them out (lgh_vcg_layout_stats): the slab K1 sums
+    # the shared x-faces of its sets itself (merged layout: ~17 % fewer values), K2 reads 16 bytes of table per node and
+    # the second 16 only in the wavefronts that need them
+    st4 = (ctypes.c_long * 4)()
+    _lib.check(L.lgh_vcg_layout_stats(ctx, st4))
+    evec, tab = int(st4[0]), int(st4[1]) + int(st4[2])
+    b[0] = 8 * (N * (2 * dim + 1) + dim * evec) + (8 * NE if k1_compact else 8 * NE * NQ)
+    b[1] = 8 * N * (dim * 5 + 1) + 8 * dim * evec + tab + N
     b[5] = NE * 8 * ((1 if l2_compact else NQ) + 2 * NL)
     notes = {0: "r, d_old (dim components) and 1/diag gathered from node vectors, E-vector out; mass data: %s"
                 % ("compact, one factor per element" if k1_compact else "stored table, NQ per element"),
+             1: "r, d read and written, x every second iteration, 1/diag, flag bytes; E-vector %d of %d values per component (%s); "
+                "transposed-restriction table %.1f of %.1f MB fetched" % (evec, NE * ND, "x-faces of a set summed by K1" if st4[3] else "element-local", 1e-6 * tab, 1e-6 * 32 * N),
              5: "mass data: %s" % ("compact, one factor per element" if l2_compact else "stored table"),
              2: "stressJinvT %s" % ("kept in registers (both force products formed in the kernel; lgh_qupdate_store_stress(ctx, 0))" if st.value == 0 else "written (9 planes)")}
     return b, notes, k1_compact
@@ -477,6 +487,12 @@ LEGS = {
                      workload=WORKLOADS["c2"][1] + ", stored mass quadrature table (general-mesh path, LGH_MASS_RANK1=0)"),
     "c2multi": dict(args=WORKLOADS["c2"][0], order=(3, 2), steps=10, warmup=3, force_multi=True,
                     workload=WORKLOADS["c2"][1] + ", N-rank code path on one rank (LGH_FORCE_MULTI=1, RCCL communicator of size 1)"),
+    # the stored-table twins of the N-rank and the HBM-resident legs (round-4 verdict, item 9): what the general-mesh path
+    # costs beyond configs[1]
+    "c2multistored": dict(args=WORKLOADS["c2"][0], order=(3, 2), steps=10, warmup=3, force_multi=True, env={"LGH_MASS_RANK1": "0"},
+                          workload=WORKLOADS["c2"][1] + ", N-rank code path on one rank, stored mass quadrature table"),
+    "c3stored": dict(args=WORKLOADS["c3"][0], order=(3, 2), steps=4, warmup=2, env={"LGH_MASS_RANK1": "0"},
+                     workload=WORKLOADS["c3"][1] + ", stored mass quadrature table (general-mesh path)"),
 }
 
 
@@ -587,7 +603,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="skip the extra legs (64^3 Sedov / Taylor-Green, Q5Q4, developed flow, N-rank path)")
-    ap.add_argument("--legs", default="c3,tg,c5,c2dev,c2stored,c2multi", help="comma-separated extra legs of a single-GPU run")
+    ap.add_argument("--legs", default="c3,tg,c5,c2dev,c2stored,c2multi,c2multistored,c3stored", help="comma-separated extra legs of a single-GPU run")
     ap.add_argument("--transport", choices=("rccl", "shm"), default="rccl",
                     help="several ranks: rccl = the product transport (one GPU per rank, RCCL over xGMI); shm = the cross-process loopback "
                          "transport of lgh_comm.hip (ranks may share one GPU: the torchrun / id broadcast / N-rank code path on a one-GPU box)")

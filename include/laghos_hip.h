@@ -291,6 +291,14 @@ int lgh_k1_form(lgh_ctx *ctx, int *form);
  * 0 = column form; *compact = 1 when that kernel reads one factor per element instead of the NQ-entry table
  * (bench.py's byte accounting follows the kernel that runs, not the kernel id). */
 int lgh_l2_mass_form(lgh_ctx *ctx, int *form, int *compact);
+/* What the mass-apply kernel K1 of the lockstep velocity solve hands to its node kernel K2 in this context, for byte
+ * accounting (bench.py): out[0] = doubles per velocity component of the E-vector between them (NE * D1D^3 in the
+ * element-local layout; about a fifth less where the slab form of K1 sums the shared x-faces of a set of five zones
+ * itself), out[1] = bytes of the transposed-restriction table K2 always reads (16 per node: contributions 1..4),
+ * out[2] = bytes of its second half (contributions 5..8) in the 64-node blocks that need it, out[3] = E-vector entries
+ * K1 has summed into a neighbour's.  Replaces nothing in the reference: there the E -> L sum is H1R^T
+ * (laghos_assembly.cpp:121) inside every operator apply. */
+int lgh_vcg_layout_stats(lgh_ctx *ctx, long out[4]);
 
 /* ---- multi-GPU: element blocks per rank, shared H1 nodes summed
  * over RCCL, dot products / dt all-reduced.  unique_id is the 128-byte

@@ -87,6 +87,7 @@ SYMBOLS = {
     "lgh_table_symmetry": (_I, [_P, c_int_p, c_int_p]),
     "lgh_k1_form": (_I, [_P, c_int_p]),
     "lgh_l2_mass_form": (_I, [_P, c_int_p, c_int_p]),
+    "lgh_vcg_layout_stats": (_I, [_P, ctypes.POINTER(ctypes.c_long)]),
     "lgh_mass_data_form": (_I, [_P, c_int_p]),
     "lgh_mass_data_changed": (_I, [_P]),
     "lgh_comm_stats": (_I, [_P, c_int_p, ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_long), c_int_p, c_int_p]),

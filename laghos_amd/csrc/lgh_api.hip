@@ -79,6 +79,26 @@ vec_dot_k(const double *x, const double *y, const double *w, long n, double *par
    }
 }
 __global__ void set_double_k(double *p, double v) { *p = v; }
+// qdata.dt_est = v: the estimate itself and, behind it, the partial minima the row-form update folds its candidates into
+__global__ void __launch_bounds__(256) dt_est_set_k(double *p, double v)
+{
+   if (threadIdx.x == 0) { p[0] = v; }
+   for (int s = threadIdx.x; s < kDtSlots; s += blockDim.x) { p[kDtSlotStride * (1 + s)] = __builtin_inf(); }
+}
+// ... and the fold in front of every read: estimate = min(estimate, partial minima) in a fixed tree (a minimum does not
+// depend on the order anyway); the slots go back to +inf
+__global__ void __launch_bounds__(256) dt_est_fold_k(double *p)
+{
+   __shared__ double red[16];
+   double m = __builtin_inf();
+   for (int s = threadIdx.x; s < kDtSlots; s += blockDim.x)
+   {
+      m = fmin(m, p[kDtSlotStride * (1 + s)]);
+      p[kDtSlotStride * (1 + s)] = __builtin_inf();
+   }
+   m = block_min(m, red);
+   if (threadIdx.x == 0) { p[0] = fmin(p[0], m); }
+}
 
 static int grid_for(long n) { return (int)std::min<long>(std::max<long>((n + 255) / 256, 1), 2048); }
 
@@ -393,7 +413,7 @@ static int create_impl(const lgh_config *cfg, lgh_ctx *c, const int kid)
    LGH_TRY(dev_alloc_zero(&c->massD, nq + 2048)); // (one set of the matrix-core K1 behind the last element: its pipeline prefetches without predicates)
    LGH_TRY(dev_alloc_zero(&c->diagV, (size_t)c->N));
    LGH_TRY(dev_alloc_zero(&c->dinvV, (size_t)c->N));
-   LGH_TRY(dev_alloc_zero(&c->dt_est_dev, 1));
+   LGH_TRY(dev_alloc_zero(&c->dt_est_dev, (size_t)kDtSlotStride * (1 + kDtSlots)));
    {
       const char *env = getenv("LGH_FUSED_FTV"); // A/B: 0 = F^T v always by its own kernel
       if (!(env && env[0] == '0'))
@@ -423,8 +443,10 @@ static int create_impl(const lgh_config *cfg, lgh_ctx *c, const int kid)
    LGH_HIP_CHECK(hipHostMalloc((void **)&c->host_pinned, 96 * sizeof(double), hipHostMallocDefault));
    LGH_HIP_CHECK(hipEventCreate(&c->timers.ev[0]));
    LGH_HIP_CHECK(hipEventCreate(&c->timers.ev[1]));
-   const double inf = std::numeric_limits<double>::infinity();
-   LGH_HIP_CHECK(hipMemcpy(c->dt_est_dev, &inf, sizeof(double), hipMemcpyHostToDevice));
+   {
+      const std::vector<double> infs((size_t)kDtSlotStride * (1 + kDtSlots), std::numeric_limits<double>::infinity());
+      LGH_HIP_CHECK(hipMemcpy(c->dt_est_dev, infs.data(), infs.size() * sizeof(double), hipMemcpyHostToDevice));
+   }
 #undef LGH_TRY
    return LGH_OK;
 }
@@ -583,13 +605,15 @@ int lgh_get_h0(lgh_ctx *c, double *h0) { LGH_CHECK_ARG(c && h0); *h0 = c->h0; re
 int lgh_set_dt_est(lgh_ctx *c, double v)
 {
    LGH_CHECK_ARG(c);
-   hipLaunchKernelGGL(set_double_k, dim3(1), dim3(1), 0, c->stream, c->dt_est_dev, v);
+   hipLaunchKernelGGL(dt_est_set_k, dim3(1), dim3(256), 0, c->stream, c->dt_est_dev, v);
    LGH_HIP_CHECK(hipGetLastError());
    return LGH_OK;
 }
 int lgh_get_dt_est(lgh_ctx *c, double *v)
 {
    LGH_CHECK_ARG(c && v);
+   hipLaunchKernelGGL(dt_est_fold_k, dim3(1), dim3(256), 0, c->stream, c->dt_est_dev);
+   LGH_HIP_CHECK(hipGetLastError());
    LGH_HIP_CHECK(hipMemcpyAsync(c->host_pinned + 8, c->dt_est_dev, sizeof(double), hipMemcpyDeviceToHost, c->stream));
    LGH_HIP_CHECK(hipMemcpyAsync(c->host_pinned + 9, c->dev_flags + 4, sizeof(int), hipMemcpyDeviceToHost, c->stream));
    LGH_HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -1127,6 +1151,11 @@ int lgh_test_vcg_k1(lgh_ctx *c, const double *r, const double *d_old, const doub
 {
    LGH_CHECK_ARG(c && r && (first || d_old) && rz && rz_prev && y_E && den);
    return vcg_test_k1(c, r, d_old, rz, rz_prev, first, y_E, den);
+}
+int lgh_vcg_layout_stats(lgh_ctx *c, long out[4])
+{
+   LGH_CHECK_ARG(c && out);
+   return vcg_layout_stats(c, out);
 }
 int lgh_test_vcg_merged_faces(lgh_ctx *c, unsigned char *mask, long *n_merged)
 {

@@ -119,7 +119,8 @@ struct lgh_ctx
                                           // mass operators for compact mass data on a tensor-product rule (nullptr: no such rule, or LGH_MASS_KRON=0)
    double *w1d = nullptr;   // one-dimensional weights when the rule is a tensor product, W[qx + Q (qy + Q qz)] = w[qx] w[qy] w[qz] (checked by lgh_create; nullptr otherwise)
    int mass_rank1;
-   double *dt_est_dev;   // 1 double: running min of the point-wise estimate
+   double *dt_est_dev;   // running min of the point-wise estimate: [0] the estimate, then kDtSlots partial minima 128 bytes apart (the row-form
+                         // update sends its candidates there by non-returning atomic min; lgh_get_dt_est folds them into [0])
    // Force products formed inside the fused QUpdate.  Validity is by construction, not by address: `fused_*_valid` says
    // that the product belongs to the quadrature data as it stands (set by lgh_qupdate, cleared by everything that can
    // change stressJinvT: lgh_reset_quadrature_data, lgh_qdata_stressJinvT, lgh_set_fused_forces, the set-up), and
@@ -431,8 +432,10 @@ bool vcg_fused_init_ok(const lgh_ctx *c);
 int partition_nodes_by_cost(lgh_ctx *c, int W, int **out, const std::vector<int> *valence = nullptr);
 int make_ellz(lgh_ctx *c, unsigned **out, const int *ell = nullptr, int deg = 0);
 int vcg_test_merged_faces(lgh_ctx *c, unsigned char *mask, long *n_merged); // lgh_test_vcg_merged_faces
+int vcg_layout_stats(lgh_ctx *c, long out[4]); // lgh_vcg_layout_stats
 int make_essbits(lgh_ctx *c, uint8_t **out);
 void vcg_free(lgh_ctx *c);
+constexpr int kDtSlots = 256, kDtSlotStride = 16; // doubles; slot s at dt_est_dev[kDtSlotStride * (1 + s)]
 constexpr int kYePad = 16; // doubles behind every Y_E plane of the CG; the first one (slot NE*ND) stays 0.0
 bool vcg_available(const lgh_ctx *c);
 int vcg_test_k1(lgh_ctx *c, const double *r, const double *d_old, const double rz[3], const double rz_prev[3], int first,

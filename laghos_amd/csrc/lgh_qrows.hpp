@@ -82,15 +82,30 @@ template <int N> __device__ __forceinline__ void row_load(const double *__restri
 // executes: 64^3 TG 3.42 -> 3.10 ms per call.  With viscosity the same build loses (614 -> 694 us at C2), and an
 // instantiation WITHOUT the branch needs more registers, not fewer (177 uncapped; capped it spills 49 into code that
 // runs: 5.10 ms) - profiles/r4_q_occupancy.txt.  So: one source, two register budgets, chosen by a.visc.
-template <int D, int Q, int L, int MINW>
+// TRACE (debug, LGH_Q_TRACE=<file>): thread 0 of every workgroup stamps the 100 MHz wall clock at the stage boundaries
+// (16 words per workgroup: 12 stamps, then xcc << 32 | hw_id) - where a workgroup's life goes, and what shares a CU
+// with what (tools/q_trace_summary.py).  An instantiation of its own: the production kernel carries none of it.
+constexpr int kQTraceRec = 16;
+constexpr int kQrowsEpwDefault = 1; // elements per workgroup of the Q3Q2 update (LGH_Q_EPW)
+// EPW (round 5): elements a workgroup works through one after the other (consecutive elements: x-neighbours).  What it
+// buys is not arithmetic: a workgroup slot of a CU stands empty for ~1.5 us between two workgroups (tear-down, dispatch,
+// LDS allocation - a tenth of the update with one element per workgroup, profiles/r5_q_stage_trace.txt), the 1-D tables go
+// to LDS once per workgroup, and the element -> node map entry of the NEXT element (one register per thread) is asked
+// for a whole element ahead, so that its gathers leave at once instead of behind a first memory round trip.  Nothing
+// else is carried from one element to the next (round 4's software-pipelined form carried the gathers themselves and
+// died of its registers, profiles/r4_q_pipelined_negative.txt).
+template <int D, int Q, int L, int MINW, bool TRACE = false, int EPW = 1>
 __global__ void __launch_bounds__(Q *Q *Q, MINW)
-qrows_kernel(const QArgs a)
+qrows_kernel(const QArgs a, unsigned long long *trace = nullptr)
 {
+   static_assert(!TRACE || EPW == 1, "the stage trace stamps one element per workgroup");
+   unsigned long long tstamp[12];
+#define LGH_QSTAMP(K_) do { if (TRACE) { tstamp[K_] = wall_clock64(); } } while (0)
+   LGH_QSTAMP(0);
    using S = QRows<D, Q, L>;
    constexpr int ND = S::ND, NQ = S::NQ, NL = S::NL, NF = S::NF, NT = NQ;
    constexpr int DD = D * D, QQ = Q * Q;
    __shared__ __attribute__((aligned(16))) double smem[S::TOTAL];
-   __shared__ double red[16];
    double *const sR1 = smem;
    double *const sU = sR1;                       // [f][dz][dy][dx]
    double *const sX = sR1 + S::SU;               // [B|G][f][qx][dz][dy]
@@ -106,32 +121,65 @@ qrows_kernel(const QArgs a)
    double *const sE1 = sE + NL;                  // [lz][ly][qx]   (F^T v: [lz][ly][qx] again, on the way back)
    double *const sE2 = sE1 + L * L * Q;          // [lz][qy][qx]
 
-   const int lt = threadIdx.x;
-   const int tx = lt % Q, ty = (lt / Q) % Q, tz = lt / QQ;
+   const int lt0 = threadIdx.x;
    // element of this workgroup: workgroup b runs on XCD b % 8 (observed); swz = log2 of the run of consecutive elements
    // that stay on one XCD (runs are dealt to the XCDs in turn); swz < 0: one contiguous eighth of the mesh per XCD
-   int e = blockIdx.x;
-   if (a.q_swz < 0) { e = xcd_swizzle(blockIdx.x, gridDim.x); }
+   int e0 = blockIdx.x;
+   if (a.q_swz < 0) { e0 = xcd_swizzle(blockIdx.x, gridDim.x); }
    else if (a.q_swz > 0)
    {
       const int R = 1 << a.q_swz, span = 8 * R, b = blockIdx.x;
-      if (b < (int)(gridDim.x / span) * span) { e = (b / span) * span + (b & 7) * R + ((b >> 3) & (R - 1)); }
+      if (b < (int)(gridDim.x / span) * span) { e0 = (b / span) * span + (b & 7) * R + ((b >> 3) & (R - 1)); }
    }
-   const size_t eq = (size_t)e * NQ + lt;
+   e0 *= EPW;
    const size_t plane = (size_t)a.NE * NQ;
 
-   // ---- P0: tables (q-major), gathers, point data: every global read of the element before the first barrier
-   for (int i = lt; i < Q * D; i += NT)
+   // ---- tables (q-major): once per workgroup
+   for (int i = lt0; i < Q * D; i += NT)
    {
       const int q = i / D, d = i - q * D;
       sTB[i] = a.B[q + Q * d];
       sTG[i] = a.G[q + Q * d];
    }
-   for (int i = lt; i < Q * L; i += NT)
+   for (int i = lt0; i < Q * L; i += NT)
    {
       const int q = i / L, l = i - q * L;
       sTL[i] = a.Bl[q + Q * l];
    }
+   constexpr bool ONE_SWEEP = (3 * ND <= NT); // every thread gathers at most one node (Q3Q2: 192 of 216 threads)
+   int m_next = 0;
+   if (EPW > 1 && ONE_SWEEP && lt0 < 3 * ND) { m_next = a.map[(size_t)e0 * ND + lt0 % ND]; }
+   double cand = __builtin_inf();
+#pragma unroll 1
+   for (int it = 0; it < EPW; it++)
+   {
+   // (EPW > 1: the thread index is opaque in every iteration - otherwise the compiler hoists every address and index of the
+   //  stages out of the loop and keeps them in registers across the point body: 213 instead of 152)
+   int lt = lt0;
+   if (EPW > 1) { asm volatile("" : "+v"(lt)); }
+   const int tx = lt % Q, ty = (lt / Q) % Q, tz = lt / QQ;
+   const int e = e0 + it;
+   if (EPW > 1)
+   {
+      if (e >= a.NE) { break; }
+      if (it > 0) { __syncthreads(); } // (the last stage of the element before has read sW / sE1: the gathers may overwrite them)
+   }
+   const size_t eq = (size_t)e * NQ + lt;
+   // ---- P0: gathers, point data: every global read of the element before the first barrier
+   if (EPW > 1 && ONE_SWEEP)
+   {
+      const int m = m_next;
+      if (lt < 3 * ND)
+      {
+         const int c = lt / ND;
+         const size_t n = (size_t)c * a.N + m;
+         sU[lt] = a.x[n];
+         sU[lt + 3 * ND] = a.v[n];
+         if (it + 1 < EPW && e + 1 < a.NE) { m_next = a.map[(size_t)(e + 1) * ND + lt % ND]; } // (used a whole element from now)
+      }
+   }
+   else
+   {
    for (int i = lt; i < 3 * ND; i += NT)
    {
       const int c = i / ND, d = i - c * ND;
@@ -139,13 +187,16 @@ qrows_kernel(const QArgs a)
       sU[i] = a.x[n];
       sU[i + 3 * ND] = a.v[n];
    }
+   }
    for (int i = lt; i < NL; i += NT) { sE[i] = a.e[(size_t)e * NL + i]; }
    double J0i[9];
 #pragma unroll
    for (int k = 0; k < 9; k++) { J0i[k] = a.Jac0inv_soa[eq + plane * k]; }
    const double rdw = a.rho0DetJ0w_in[eq];
    const double weight = a.W[lt];
+   LGH_QSTAMP(1); // loads issued
    __syncthreads();
+   LGH_QSTAMP(2); // gathers, tables in LDS
 
    // ---- P1: X stage, rows (which, f, dz, dy); the L2 field's x stage on the last threads
    for (int i = lt; i < 2 * NF * DD; i += NT)
@@ -172,6 +223,7 @@ qrows_kernel(const QArgs a)
       }
    }
    __syncthreads();
+   LGH_QSTAMP(3); // X stage
 
    // ---- P2: Y stage, rows (part, f, qx, dz): part 0 = B on the G array (d/dx), 1 = G on the B array (d/dy), 2 = B on B (for d/dz)
    for (int i = lt; i < 3 * NF * Q * D; i += NT)
@@ -200,6 +252,7 @@ qrows_kernel(const QArgs a)
       }
    }
    __syncthreads();
+   LGH_QSTAMP(4); // Y stage
 
    // ---- P3: Z stage of this thread's point and the point-wise body
    double J[9], dV[9], e_val = 0.0;
@@ -233,8 +286,11 @@ qrows_kernel(const QArgs a)
 #pragma unroll
       for (int lz = 0; lz < L; lz++) { e_val = fma(sTL[tz * L + lz], sE2[(lz * Q + ty) * Q + tx], e_val); }
    }
+   LGH_QSTAMP(5); // Z stage (this wavefront)
    double ftv = 0.0, sjw[9];
-   const double cand = qpoint_body<3>(a, e, eq, weight, J, dV, e_val, plane, J0i, rdw, ftv, sjw);
+   cand = fmin(cand, qpoint_body<3>(a, e, eq, weight, J, dV, e_val, plane, J0i, rdw, ftv, sjw));
+   LGH_QSTAMP(6); // point body (this wavefront)
+   tstamp[7] = tstamp[8] = tstamp[9] = tstamp[10] = 0;
 
    const bool do_f = (a.force_e != nullptr), do_t = (a.erhs_q != nullptr);
    if (do_f || do_t)
@@ -248,6 +304,7 @@ qrows_kernel(const QArgs a)
       }
       if (do_t) { sS[pq] = ftv; }
       __syncthreads();
+      LGH_QSTAMP(7); // every wavefront's body done, stress in LDS
 
       // ---- P5: contraction over qz, rows (k, qy, qx); F^T v: rows (qy, qx)
       if (do_f)
@@ -278,6 +335,7 @@ qrows_kernel(const QArgs a)
          }
       }
       __syncthreads();
+      LGH_QSTAMP(8); // qz contraction
 
       // ---- P6: contraction over qy, rows (k, dz, qx); F^T v: rows (lz, qx)
       if (do_f)
@@ -310,6 +368,7 @@ qrows_kernel(const QArgs a)
          }
       }
       __syncthreads();
+      LGH_QSTAMP(9); // qy contraction
 
       // ---- P7: contraction over qx and the sum over the three reference directions, rows (c, dz, dy) -> E-vector;
       //          F^T v: rows (lz, ly) -> L2 vector
@@ -350,12 +409,37 @@ qrows_kernel(const QArgs a)
          }
       }
    }
-   const double bmin = block_min(cand, red);
-   double total;
-   if (grid_min_last_block(bmin, a.partials, a.ticket, red, total))
+   } // elements of this workgroup
+   LGH_QSTAMP(10); // qx contraction, outputs stored
+   // q_dt_est = qdata.dt_est; Min() (:1374, :1406).  Round 5: no workgroup reduction, no ticket, no last workgroup - the
+   // stage trace (profiles/r5_q_stage_trace.txt) showed a workgroup spending the last tenth of its life (1.2 us) in the
+   // two dependent atomic round trips of the ticketed fold while it held its third of the CU.  The candidates are
+   // non-negative doubles (or +inf), whose order is the order of their bit patterns as unsigned integers: every
+   // wavefront folds its lanes on the DPP path and sends ONE non-returning 64-bit unsigned atomic min to one of kDtSlots
+   // partial minima (by workgroup: ~130 000 atomics per call on ONE word cost more than the fold they replaced - 620 ->
+   // 850 us, profiles/r5_q_stage_trace.txt; spread over 256 lines they cost nothing); lgh_get_dt_est folds the slots.
+   // A minimum does not depend on the order of its operands: the same bits as the ordered fold.
    {
-      if (lt == 0) { *a.result = fmin(*a.result, total); } // q_dt_est = qdata.dt_est; Min() (:1374, :1406)
+      const int lane = lt0 & 63, nact = min(64, NT - (lt0 & ~63));
+      const double wmin = wave_min(cand, lane, nact);
+      if (lane == 0 && wmin < __builtin_inf())
+      {
+         unsigned long long *slot = (unsigned long long *)(a.result + kDtSlotStride * (1 + (blockIdx.x % kDtSlots)));
+         (void)__hip_atomic_fetch_min(slot, (unsigned long long)__double_as_longlong(wmin), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
    }
+   if (TRACE && lt0 == 0 && trace)
+   {
+      LGH_QSTAMP(11);
+      unsigned xcc = 0, hwid = 0;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+      unsigned long long *rec = trace + (size_t)kQTraceRec * blockIdx.x;
+      for (int k = 0; k < 12; k++) { rec[k] = tstamp[k]; }
+      rec[12] = ((unsigned long long)xcc << 32) | hwid;
+      rec[13] = (unsigned long long)e0;
+   }
+#undef LGH_QSTAMP
 }
 
 // kernel ids the row form is instantiated for (3D; Q5Q4 keeps the point form with two points per thread: the slices of
@@ -369,13 +453,58 @@ static bool qrows_available(const lgh_ctx *c)
    }
    return false;
 }
+// debug: LGH_Q_TRACE=<file>: the Q3Q2 update through the traced instantiation; the stamps of the LAST call are written when
+// the context is destroyed or at the next traced call (qrows_trace_dump)
+static unsigned long long *q_trace_dev = nullptr;
+static int q_trace_n = 0;
+static void qrows_trace_dump(lgh_ctx *c)
+{
+   const char *path = getenv("LGH_Q_TRACE");
+   if (!path || !q_trace_dev || q_trace_n <= 0) { return; }
+   (void)hipStreamSynchronize(c->stream);
+   std::vector<unsigned long long> h((size_t)kQTraceRec * q_trace_n);
+   if (hipMemcpy(h.data(), q_trace_dev, h.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) { return; }
+   FILE *f = fopen(path, "w");
+   if (!f) { return; }
+   for (int i = 0; i < q_trace_n; i++)
+   {
+      fprintf(f, "%d", i);
+      for (int k = 0; k < 14; k++) { fprintf(f, " %llu", h[(size_t)kQTraceRec * i + k]); }
+      fprintf(f, "\n");
+   }
+   fclose(f);
+}
 template <int MINW6> static int launch_qrows_w(lgh_ctx *c, const QArgs &a)
 {
+   if (c->kid == 0x346 && getenv("LGH_Q_TRACE"))
+   {
+      if (q_trace_n != c->NE)
+      {
+         if (q_trace_dev) { (void)hipFree(q_trace_dev); q_trace_dev = nullptr; }
+         LGH_HIP_CHECK(hipMalloc((void **)&q_trace_dev, (size_t)kQTraceRec * c->NE * 8));
+         q_trace_n = c->NE;
+      }
+      hipLaunchKernelGGL((qrows_kernel<4, 6, 3, MINW6, true>), dim3(c->NE), dim3(216), 0, c->stream, a, q_trace_dev);
+      LGH_HIP_CHECK(hipGetLastError());
+      static int calls = 0;
+      const char *nenv = getenv("LGH_Q_TRACE_CALL"); // which call to dump (default 40: a developed bench window)
+      if (++calls == (nenv ? atoi(nenv) : 40)) { qrows_trace_dump(c); }
+      return LGH_OK;
+   }
    switch (c->kid)
    {
       case 0x322: hipLaunchKernelGGL((qrows_kernel<2, 2, 1, 1>), dim3(c->NE), dim3(8), 0, c->stream, a); break;
       case 0x334: hipLaunchKernelGGL((qrows_kernel<3, 4, 2, 1>), dim3(c->NE), dim3(64), 0, c->stream, a); break;
-      case 0x346: hipLaunchKernelGGL((qrows_kernel<4, 6, 3, MINW6>), dim3(c->NE), dim3(216), 0, c->stream, a); break;
+      case 0x346:
+      {
+         // elements per workgroup (LGH_Q_EPW=1/2/3/4 for A/B; see the kernel's header comment)
+         static const int epw = [] { const char *e = getenv("LGH_Q_EPW"); const int v = e ? atoi(e) : kQrowsEpwDefault; return (v >= 1 && v <= 4) ? v : kQrowsEpwDefault; }();
+         if (epw == 2) { hipLaunchKernelGGL((qrows_kernel<4, 6, 3, (MINW6 < 3 ? 3 : MINW6), false, 2>), dim3(ceil_div(c->NE, 2)), dim3(216), 0, c->stream, a, (unsigned long long *)nullptr); }
+         else if (epw == 3) { hipLaunchKernelGGL((qrows_kernel<4, 6, 3, (MINW6 < 3 ? 3 : MINW6), false, 3>), dim3(ceil_div(c->NE, 3)), dim3(216), 0, c->stream, a, (unsigned long long *)nullptr); }
+         else if (epw == 4) { hipLaunchKernelGGL((qrows_kernel<4, 6, 3, (MINW6 < 3 ? 3 : MINW6), false, 4>), dim3(ceil_div(c->NE, 4)), dim3(216), 0, c->stream, a, (unsigned long long *)nullptr); }
+         else { hipLaunchKernelGGL((qrows_kernel<4, 6, 3, MINW6>), dim3(c->NE), dim3(216), 0, c->stream, a); }
+         break;
+      }
       case 0x358: hipLaunchKernelGGL((qrows_kernel<5, 8, 4, 1>), dim3(c->NE), dim3(512), 0, c->stream, a); break;
       default: return unknown_kernel(c->kid);
    }

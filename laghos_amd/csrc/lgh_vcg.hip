@@ -17,6 +17,8 @@
 
 namespace lgh
 {
+typedef unsigned v4u_ __attribute__((ext_vector_type(4)));
+
 
 // ---- K1: y_e^c = B^T D_e B d_e^c for the unconverged components, d^c = z^c + beta_c d^c.
 // Persistent workgroups: the grid is one resident wave of workgroups; each walks
@@ -1313,8 +1315,12 @@ vcg_update_k(const VcgArgs a)
 //  * 1024 workgroup partials instead of 3566 for the ticketed reduction;
 //  * write-through and non-temporal stores of d, r, x were tried (no gain) and are gone.
 
-template <bool XU, int U>
-__global__ void __launch_bounds__(512)
+// MINW (round 5): wavefronts per SIMD the register allocation admits (the second argument of HIP's __launch_bounds__):
+// 4 = the budget of rounds 2-4 (up to 128 VGPRs: two workgroups of eight wavefronts per CU), 6 = at most 80 (three).  The kernel is a chain of dependent memory round trips per pass
+// (table -> element contributions -> stores), and what hides them is the number of wavefronts a CU holds; the second
+// table (slots 4..7) is summed in a branch of its own so that its 24 registers exist only there.
+template <bool XU, int U, int MINW = 4>
+__global__ void __launch_bounds__(512, MINW)
 vcg_update_p_k(const VcgArgs a)
 {
    constexpr int NT = 512;
@@ -1366,8 +1372,9 @@ vcg_update_p_k(const VcgArgs a)
       return;
    }
    const bool xload = XU && it > 2;
-   const unsigned rowb = 4u * (unsigned)a.N, compb = 8u * (unsigned)a.N;
+   const unsigned compb = 8u * (unsigned)a.N;
    const unsigned zoff = 8u * (unsigned)(a.ye_stride - kYePad); // byte offset of the zero slot (make_ellz)
+   const char *const ellhi = (const char *)a.ellz + (size_t)16 * (size_t)a.N; // slots 4..7
    double part[kVC] = {0.0, 0.0, 0.0};
    for (int base = n0; base < n1; base += NT * U)
    {
@@ -1380,13 +1387,21 @@ vcg_update_p_k(const VcgArgs a)
          ok[u] = n < n1;
          nn[u] = (unsigned)(ok[u] ? n : n0);
       }
-      unsigned ix[U][8];
+      // ELL rows as two tables of four offsets per node (16 bytes each): slots 0..3 with one load per node; slots 4..7 -
+      // only a vertex node of the mesh has more than four contributions, with the merged E-vector of the slab K1 only
+      // where a set boundary meets an element edge in y and z - are fetched when some node of the wavefront uses them
+      // (rows hold their contributions first, so slot 3 tells): a ninth of the wavefronts, 16 of the table's 32 bytes per
+      // node for the others
+      unsigned ix[U][4];
+      bool hi_any = false;
 #pragma unroll
       for (int u = 0; u < U; u++)
       {
-#pragma unroll
-         for (int j = 0; j < 8; j++) { ix[u][j] = *(const unsigned *)((const char *)a.ellz + (4u * nn[u] + (unsigned)j * rowb)); }
+         const v4u_ q0 = *(const v4u_ *)((const char *)a.ellz + 16u * nn[u]);
+         ix[u][0] = q0[0]; ix[u][1] = q0[1]; ix[u][2] = q0[2]; ix[u][3] = q0[3];
+         hi_any = hi_any || (q0[3] != zoff);
       }
+      const bool hi = !a.k2_skip || __any(hi_any);
       double di[U], ro[U][kVC], dol[U][kVC], xo[U][kVC];
       unsigned es[U];
 #pragma unroll
@@ -1401,44 +1416,81 @@ vcg_update_p_k(const VcgArgs a)
             ro[u][k] = vcg_ld(a.r, vb);
             dol[u][k] = vcg_ld(a.d, vb);
             xo[u][k] = 0.0;
-            if (XU) { xo[u][k] = vcg_ld(a.x, vb); }
+            if (XU && MINW < 6) { xo[u][k] = vcg_ld(a.x, vb); }
          }
       }
       // Slot j of the ELL rows is only fetched when some node of the wavefront has a j-th contribution (rows hold
       // their contributions first): a wave of consecutive nodes of a tensor-product mesh rarely needs all 8 (a
       // node needs 1, 2, 4 or 8), and the loads of absent slots - all lanes at the zero slot - still occupy the
       // address path.
-      bool need[8];
+      bool need[4];
       need[0] = true;
 #pragma unroll
-      for (int j = 1; j < 8; j++)
+      for (int j = 1; j < 4; j++)
       {
          bool any = false;
 #pragma unroll
          for (int u = 0; u < U; u++) { any = any || (ix[u][j] != zoff); }
          need[j] = !a.k2_skip || __any(any);
       }
-      double ye[U][kVC][8];
-#pragma unroll
-      for (int j = 0; j < 8; j++)
+      double zsum[U][kVC]; // ascending contribution order (absent slots add 0.0): the sum of vcg_update_k
       {
-         if (need[j])
+         double ye[U][kVC][4];
+#pragma unroll
+         for (int j = 0; j < 4; j++)
          {
+            if (need[j])
+            {
+#pragma unroll
+               for (int k = 0; k < kVC; k++)
+               {
+                  const double *yc = a.YE + (size_t)k * a.ye_stride;
+#pragma unroll
+                  for (int u = 0; u < U; u++) { ye[u][k][j] = vcg_ld(yc, ix[u][j]); }
+               }
+            }
+            else
+            {
+#pragma unroll
+               for (int k = 0; k < kVC; k++)
+               {
+#pragma unroll
+                  for (int u = 0; u < U; u++) { ye[u][k][j] = 0.0; }
+               }
+            }
+         }
+#pragma unroll
+         for (int u = 0; u < U; u++)
+         {
+#pragma unroll
+            for (int k = 0; k < kVC; k++) { zsum[u][k] = ((0.0 + ye[u][k][0]) + ye[u][k][1]) + ye[u][k][2]; zsum[u][k] += ye[u][k][3]; }
+         }
+      }
+      if (XU && MINW >= 6 && xload)
+      {
+         // (six wavefronts per SIMD: x is asked for once the element contributions have been summed - its three registers
+         //  per node would otherwise be live beside their 24, and the budget of 80 does not hold both; the other
+         //  wavefronts of the SIMD cover the round trip)
+#pragma unroll
+         for (int u = 0; u < U; u++)
+         {
+#pragma unroll
+            for (int k = 0; k < kVC; k++) { asm volatile("" : "+v"(zsum[u][k])); xo[u][k] = vcg_ld(a.x, 8u * nn[u] + (unsigned)k * compb); }
+         }
+      }
+      if (hi)
+      {
+         // contributions 5..8 (a ninth of the wavefronts): second table, then the values, added behind the first four
+#pragma unroll
+         for (int u = 0; u < U; u++)
+         {
+            const v4u_ q1 = *(const v4u_ *)(ellhi + 16u * nn[u]);
 #pragma unroll
             for (int k = 0; k < kVC; k++)
             {
                const double *yc = a.YE + (size_t)k * a.ye_stride;
-#pragma unroll
-               for (int u = 0; u < U; u++) { ye[u][k][j] = vcg_ld(yc, ix[u][j]); }
-            }
-         }
-         else
-         {
-#pragma unroll
-            for (int k = 0; k < kVC; k++)
-            {
-#pragma unroll
-               for (int u = 0; u < U; u++) { ye[u][k][j] = 0.0; }
+               const double y4 = vcg_ld(yc, q1[0]), y5 = vcg_ld(yc, q1[1]), y6 = vcg_ld(yc, q1[2]), y7 = vcg_ld(yc, q1[3]);
+               zsum[u][k] = (((zsum[u][k] + y4) + y5) + y6) + y7;
             }
          }
       }
@@ -1462,9 +1514,7 @@ vcg_update_p_k(const VcgArgs a)
          for (int k = 0; k < kVC; k++)
          {
             const unsigned vb = 8u * nn[u] + (unsigned)k * compb;
-            double zs = 0.0; // ascending contribution order (absent slots add 0.0 at the end): the sum of vcg_update_k
-#pragma unroll
-            for (int j = 0; j < 8; j++) { zs += ye[u][k][j]; }
+            double zs = zsum[u][k];
             if (anysh && ((es[u] >> 3) & 1u)) { zs = ysh[u][k]; }
             const double z_ = ((es[u] >> k) & 1u) ? 0.0 : zs;
             const double zold = __dmul_rn(ro[u][k], di[u]); // z of the previous iterate, not stored
@@ -1690,7 +1740,10 @@ vcg_ellz_k(const int *__restrict__ ell, unsigned *__restrict__ ellz, const size_
    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
    if (i >= n_all) { return; }
    const int p = (i < n_have) ? ell[i] : -1; // rows beyond the mesh's valence: absent
-   ellz[i] = 8u * (unsigned)(p < 0 ? zslot : p);
+   // in: slot-major (slot j of node n at j * N + n); out: two tables of four slots per node, [n][j] for j < 4 and, behind
+   // it, [n][j - 4] for the rest (vcg_update_p_k reads a table entry as one 16-byte load)
+   const size_t N = n_all / 8, j = i / N, n = i - j * N;
+   ellz[(j < 4 ? 0 : 4 * N) + 4 * n + (j & 3)] = 8u * (unsigned)(p < 0 ? zslot : p);
 }
 
 // Node phase: a node costs a fixed part (its vectors, the ELL row) plus a part per element contribution
@@ -2239,9 +2292,13 @@ static void vcg_launch_k2p(lgh_ctx *c, const VcgPlan &plan, const VcgArgs &a, co
    kt_begin(c, LGH_KERNEL_CG_UPDATE_H1);
    const char *uenv = getenv("LGH_K2_U"); // A/B: nodes per thread and pass (2: 182 VGPRs, one workgroup per CU resident)
    const int u2 = (uenv && uenv[0] == '2') ? 1 : 0;
-#define LGH_K2P_LAUNCH(XU_, U_) hipLaunchKernelGGL((vcg_update_p_k<XU_, U_>), dim3(plan.aux->grid2), dim3(512), 0, c->stream, a)
-   if (it & 1) { if (u2) { LGH_K2P_LAUNCH(false, 2); } else { LGH_K2P_LAUNCH(false, 1); } }
-   else { if (u2) { LGH_K2P_LAUNCH(true, 2); } else { LGH_K2P_LAUNCH(true, 1); } }
+   // LGH_K2_OCC (A/B): 4 = the register budget of rounds 2-4 for both launches, 6 = at most 80 registers for both (the launch
+   // that updates x then spills 7), default: 80 for the launch without x, the old budget for the one with it
+   static const int occ = [] { const char *e = getenv("LGH_K2_OCC"); return (e && e[0] == '4') ? 0 : (e && e[0] == '6') ? 2 : 1; }();
+   const int occ3 = (it & 1) ? (occ >= 1) : (occ == 2);
+#define LGH_K2P_LAUNCH(XU_, U_, MINW_) hipLaunchKernelGGL((vcg_update_p_k<XU_, U_, MINW_>), dim3(plan.aux->grid2), dim3(512), 0, c->stream, a)
+   if (it & 1) { if (u2) { LGH_K2P_LAUNCH(false, 2, 2); } else if (occ3) { LGH_K2P_LAUNCH(false, 1, 6); } else { LGH_K2P_LAUNCH(false, 1, 4); } }
+   else { if (u2) { LGH_K2P_LAUNCH(true, 2, 2); } else if (occ3) { LGH_K2P_LAUNCH(true, 1, 6); } else { LGH_K2P_LAUNCH(true, 1, 4); } }
 #undef LGH_K2P_LAUNCH
    kt_end(c, LGH_KERNEL_CG_UPDATE_H1);
 }
@@ -2481,6 +2538,47 @@ int vcg_test_merged_faces(lgh_ctx *c, unsigned char *mask, long *n_merged)
    if (rc2) { return rc2; }
    memcpy(mask, L.sec.data(), nE);
    *n_merged = (long)L.n_merged;
+   return LGH_OK;
+}
+
+// lgh_vcg_layout_stats: what K1 hands to K2 in this context, for byte accounting (bench.py's moved_bytes): out[0] = doubles
+// per component plane K1 writes and K2 reads (NE * ND element-local; less with the merged layout), out[1] = bytes of the
+// ELL table K2 always reads (slots 0..3: 16 per node), out[2] = bytes of its second table (slots 4..7) in the 64-node
+// blocks that hold a node with more than four contributions (what the wavefronts of K2 fetch of it, to the granularity
+// of a wavefront), out[3] = E-vector entries K1 has summed into a neighbour's (0: element-local layout)
+int vcg_layout_stats(lgh_ctx *c, long out[4])
+{
+   out[0] = (long)c->NE * c->ND; out[1] = 16L * c->N; out[2] = 16L * c->N; out[3] = 0;
+   if (!vcg_supported(c)) { return LGH_OK; }
+   VcgPlan plan;
+   int rc = vcg_prepare(c, nullptr, nullptr, 0.0, plan);
+   if (rc) { return rc; }
+   const VcgArgs &a = plan.a;
+   if (a.settab)
+   {
+      SlabLayout L;
+      rc = slab_merge_layout(c, L);
+      if (rc) { return rc; }
+      long used = 0;
+      for (size_t i = 0; i < L.pos.size(); i++) { used = std::max(used, (long)L.pos[i] + 1); }
+      out[0] = used;
+      out[3] = (long)L.n_merged;
+   }
+   const size_t N = (size_t)c->N;
+   if (a.deg > 4)
+   {
+      std::vector<int> row((size_t)(a.deg - 4) * N);
+      LGH_HIP_CHECK(hipMemcpy(row.data(), a.ell + 4 * N, row.size() * sizeof(int), hipMemcpyDeviceToHost));
+      long blocks = 0;
+      for (size_t b = 0; b < N; b += 64)
+      {
+         bool any = false;
+         for (size_t n = b; n < std::min(N, b + 64) && !any; n++) { any = row[n] >= 0; } // (rows hold their contributions first: slot 4 tells)
+         blocks += any ? 1 : 0;
+      }
+      out[2] = 16L * 64 * blocks;
+   }
+   else { out[2] = 0; }
    return LGH_OK;
 }
 

@@ -67,8 +67,12 @@ def _in_process(nranks, pgrid, block, steps):
     return out[0]
 
 
-@pytest.mark.parametrize("nproc,pgrid", [(2, (2, 1, 1)), (4, (2, 2, 1))], ids=["2ranks", "4ranks"])
-def test_bench_gpus_n_over_the_cross_process_transport(nproc, pgrid):
+@pytest.mark.parametrize("nproc,pgrid,slab", [(2, (2, 1, 1), False), (4, (2, 2, 1), False), (2, (2, 1, 1), True)], ids=["2ranks", "4ranks", "2ranks-slab-words"])
+def test_bench_gpus_n_over_the_cross_process_transport(nproc, pgrid, slab, monkeypatch):
+    # slab: the kernels config 4's ranks run (slab K1 with the merged E-vector, exact accumulators) on 8^3-zone ranks -
+    # (r, z) then crosses the ranks as accumulator WORDS (exchange_words, round 5), here through the shm transport
+    if slab:
+        monkeypatch.setenv("LGH_VCG_VARIANT", "4")
     steps, warmup, block = 3, 2, 8
     d = _torchrun_bench(nproc, ["--transport", "shm", "--block", str(block), "--steps", str(steps), "--warmup", str(warmup)])
     assert d["n_gpus"] == nproc and d["steps"] == steps and d["warmup"] == warmup and d["scaling"] == "weak"

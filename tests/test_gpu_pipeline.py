@@ -471,6 +471,12 @@ MULTI_RANK_CASES = [
     (8, (8, 8, 8), 1, 0, (3, 2), {"LGH_VCG_VARIANT": "4"}), (3, (9, 6, 6), 1, 1, (3, 2), {"LGH_VCG_VARIANT": "4"}),
     (2, (8, 8, 8), 1, 0, (3, 2), {"LGH_VCG_VARIANT": "4", "LGH_COMM2": "0", "LGH_HALO_PIGGYBACK": "0"}),
     (4, (8, 8, 4), 7, 1, (3, 2), {"LGH_VCG_VARIANT": "4", "LGH_SLAB_DEFER": "0"}),
+    # round 5: ranks of 8^3 zones (rows of 8: x-chains, merged E-vector) with (r, z) crossing the ranks as exact accumulator
+    # words (all-pairs partitions; one message round, no combine kernel), and the ticketed (r, z) the other partitions keep
+    (2, (16, 8, 8), 1, 0, (3, 2), {"LGH_VCG_VARIANT": "4"}), (8, (16, 16, 16), 1, 0, (3, 2), {"LGH_VCG_VARIANT": "4"}),
+    (8, (8, 8, 8), 1, 1, (3, 2), {"LGH_VCG_VARIANT": "4"}),
+    (8, (8, 8, 8), 1, 0, (3, 2), {"LGH_VCG_VARIANT": "4", "LGH_RZ_LIMBS": "0"}),
+    (2, (16, 8, 8), 1, 0, (3, 2), {"LGH_VCG_VARIANT": "4", "LGH_SLAB_MERGE": "0"}),
     # the exchanges with their own pack kernels (default: the shared-node gather and K2 fill the send buffers themselves)
     (8, (8, 8, 8), 1, 0, (3, 2), {"LGH_HALO_FUSED_PACK": "0"}), (3, (9, 6, 6), 1, 1, (3, 2), {"LGH_HALO_FUSED_PACK": "0"}),
     # the high-order forms of K1 / K2 on several ranks (BASELINE config 5 is an 8-GPU Q5Q4 run)
