@@ -86,19 +86,10 @@ template <int N> __device__ __forceinline__ void row_load(const double *__restri
 // (16 words per workgroup: 12 stamps, then xcc << 32 | hw_id) - where a workgroup's life goes, and what shares a CU
 // with what (tools/q_trace_summary.py).  An instantiation of its own: the production kernel carries none of it.
 constexpr int kQTraceRec = 16;
-constexpr int kQrowsEpwDefault = 1; // elements per workgroup of the Q3Q2 update (LGH_Q_EPW)
-// EPW (round 5): elements a workgroup works through one after the other (consecutive elements: x-neighbours).  What it
-// buys is not arithmetic: a workgroup slot of a CU stands empty for ~1.5 us between two workgroups (tear-down, dispatch,
-// LDS allocation - a tenth of the update with one element per workgroup, profiles/r5_q_stage_trace.txt), the 1-D tables go
-// to LDS once per workgroup, and the element -> node map entry of the NEXT element (one register per thread) is asked
-// for a whole element ahead, so that its gathers leave at once instead of behind a first memory round trip.  Nothing
-// else is carried from one element to the next (round 4's software-pipelined form carried the gathers themselves and
-// died of its registers, profiles/r4_q_pipelined_negative.txt).
-template <int D, int Q, int L, int MINW, bool TRACE = false, int EPW = 1>
+template <int D, int Q, int L, int MINW, bool TRACE = false>
 __global__ void __launch_bounds__(Q *Q *Q, MINW)
 qrows_kernel(const QArgs a, unsigned long long *trace = nullptr)
 {
-   static_assert(!TRACE || EPW == 1, "the stage trace stamps one element per workgroup");
    unsigned long long tstamp[12];
 #define LGH_QSTAMP(K_) do { if (TRACE) { tstamp[K_] = wall_clock64(); } } while (0)
    LGH_QSTAMP(0);
@@ -121,72 +112,38 @@ qrows_kernel(const QArgs a, unsigned long long *trace = nullptr)
    double *const sE1 = sE + NL;                  // [lz][ly][qx]   (F^T v: [lz][ly][qx] again, on the way back)
    double *const sE2 = sE1 + L * L * Q;          // [lz][qy][qx]
 
-   const int lt0 = threadIdx.x;
+   const int lt = threadIdx.x;
+   const int tx = lt % Q, ty = (lt / Q) % Q, tz = lt / QQ;
    // element of this workgroup: workgroup b runs on XCD b % 8 (observed); swz = log2 of the run of consecutive elements
    // that stay on one XCD (runs are dealt to the XCDs in turn); swz < 0: one contiguous eighth of the mesh per XCD
-   int e0 = blockIdx.x;
-   if (a.q_swz < 0) { e0 = xcd_swizzle(blockIdx.x, gridDim.x); }
+   int e = blockIdx.x;
+   if (a.q_swz < 0) { e = xcd_swizzle(blockIdx.x, gridDim.x); }
    else if (a.q_swz > 0)
    {
       const int R = 1 << a.q_swz, span = 8 * R, b = blockIdx.x;
-      if (b < (int)(gridDim.x / span) * span) { e0 = (b / span) * span + (b & 7) * R + ((b >> 3) & (R - 1)); }
+      if (b < (int)(gridDim.x / span) * span) { e = (b / span) * span + (b & 7) * R + ((b >> 3) & (R - 1)); }
    }
-   e0 *= EPW;
+   const size_t eq = (size_t)e * NQ + lt;
    const size_t plane = (size_t)a.NE * NQ;
 
-   // ---- tables (q-major): once per workgroup
-   for (int i = lt0; i < Q * D; i += NT)
+   // ---- P0: tables (q-major), gathers, point data: every global read of the element before the first barrier
+   for (int i = lt; i < Q * D; i += NT)
    {
       const int q = i / D, d = i - q * D;
       sTB[i] = a.B[q + Q * d];
       sTG[i] = a.G[q + Q * d];
    }
-   for (int i = lt0; i < Q * L; i += NT)
+   for (int i = lt; i < Q * L; i += NT)
    {
       const int q = i / L, l = i - q * L;
       sTL[i] = a.Bl[q + Q * l];
    }
-   constexpr bool ONE_SWEEP = (3 * ND <= NT); // every thread gathers at most one node (Q3Q2: 192 of 216 threads)
-   int m_next = 0;
-   if (EPW > 1 && ONE_SWEEP && lt0 < 3 * ND) { m_next = a.map[(size_t)e0 * ND + lt0 % ND]; }
-   double cand = __builtin_inf();
-#pragma unroll 1
-   for (int it = 0; it < EPW; it++)
-   {
-   // (EPW > 1: the thread index is opaque in every iteration - otherwise the compiler hoists every address and index of the
-   //  stages out of the loop and keeps them in registers across the point body: 213 instead of 152)
-   int lt = lt0;
-   if (EPW > 1) { asm volatile("" : "+v"(lt)); }
-   const int tx = lt % Q, ty = (lt / Q) % Q, tz = lt / QQ;
-   const int e = e0 + it;
-   if (EPW > 1)
-   {
-      if (e >= a.NE) { break; }
-      if (it > 0) { __syncthreads(); } // (the last stage of the element before has read sW / sE1: the gathers may overwrite them)
-   }
-   const size_t eq = (size_t)e * NQ + lt;
-   // ---- P0: gathers, point data: every global read of the element before the first barrier
-   if (EPW > 1 && ONE_SWEEP)
-   {
-      const int m = m_next;
-      if (lt < 3 * ND)
-      {
-         const int c = lt / ND;
-         const size_t n = (size_t)c * a.N + m;
-         sU[lt] = a.x[n];
-         sU[lt + 3 * ND] = a.v[n];
-         if (it + 1 < EPW && e + 1 < a.NE) { m_next = a.map[(size_t)(e + 1) * ND + lt % ND]; } // (used a whole element from now)
-      }
-   }
-   else
-   {
    for (int i = lt; i < 3 * ND; i += NT)
    {
       const int c = i / ND, d = i - c * ND;
       const size_t n = (size_t)c * a.N + a.map[(size_t)e * ND + d];
       sU[i] = a.x[n];
       sU[i + 3 * ND] = a.v[n];
-   }
    }
    for (int i = lt; i < NL; i += NT) { sE[i] = a.e[(size_t)e * NL + i]; }
    double J0i[9];
@@ -288,7 +245,7 @@ qrows_kernel(const QArgs a, unsigned long long *trace = nullptr)
    }
    LGH_QSTAMP(5); // Z stage (this wavefront)
    double ftv = 0.0, sjw[9];
-   cand = fmin(cand, qpoint_body<3>(a, e, eq, weight, J, dV, e_val, plane, J0i, rdw, ftv, sjw));
+   const double cand = qpoint_body<3>(a, e, eq, weight, J, dV, e_val, plane, J0i, rdw, ftv, sjw);
    LGH_QSTAMP(6); // point body (this wavefront)
    tstamp[7] = tstamp[8] = tstamp[9] = tstamp[10] = 0;
 
@@ -409,7 +366,6 @@ qrows_kernel(const QArgs a, unsigned long long *trace = nullptr)
          }
       }
    }
-   } // elements of this workgroup
    LGH_QSTAMP(10); // qx contraction, outputs stored
    // q_dt_est = qdata.dt_est; Min() (:1374, :1406).  Round 5: no workgroup reduction, no ticket, no last workgroup - the
    // stage trace (profiles/r5_q_stage_trace.txt) showed a workgroup spending the last tenth of its life (1.2 us) in the
@@ -420,7 +376,7 @@ qrows_kernel(const QArgs a, unsigned long long *trace = nullptr)
    // 850 us, profiles/r5_q_stage_trace.txt; spread over 256 lines they cost nothing); lgh_get_dt_est folds the slots.
    // A minimum does not depend on the order of its operands: the same bits as the ordered fold.
    {
-      const int lane = lt0 & 63, nact = min(64, NT - (lt0 & ~63));
+      const int lane = lt & 63, nact = min(64, NT - (lt & ~63));
       const double wmin = wave_min(cand, lane, nact);
       if (lane == 0 && wmin < __builtin_inf())
       {
@@ -428,7 +384,7 @@ qrows_kernel(const QArgs a, unsigned long long *trace = nullptr)
          (void)__hip_atomic_fetch_min(slot, (unsigned long long)__double_as_longlong(wmin), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
    }
-   if (TRACE && lt0 == 0 && trace)
+   if (TRACE && lt == 0 && trace)
    {
       LGH_QSTAMP(11);
       unsigned xcc = 0, hwid = 0;
@@ -437,7 +393,7 @@ qrows_kernel(const QArgs a, unsigned long long *trace = nullptr)
       unsigned long long *rec = trace + (size_t)kQTraceRec * blockIdx.x;
       for (int k = 0; k < 12; k++) { rec[k] = tstamp[k]; }
       rec[12] = ((unsigned long long)xcc << 32) | hwid;
-      rec[13] = (unsigned long long)e0;
+      rec[13] = (unsigned long long)e;
    }
 #undef LGH_QSTAMP
 }
@@ -453,8 +409,8 @@ static bool qrows_available(const lgh_ctx *c)
    }
    return false;
 }
-// debug: LGH_Q_TRACE=<file>: the Q3Q2 update through the traced instantiation; the stamps of the LAST call are written when
-// the context is destroyed or at the next traced call (qrows_trace_dump)
+// debug: LGH_Q_TRACE=<file>: the Q3Q2 update through the traced instantiation; the stamps of call number LGH_Q_TRACE_CALL
+// (default 40: inside the timed window of a bench run) are written to the file (qrows_trace_dump)
 static unsigned long long *q_trace_dev = nullptr;
 static int q_trace_n = 0;
 static void qrows_trace_dump(lgh_ctx *c)
@@ -495,16 +451,7 @@ template <int MINW6> static int launch_qrows_w(lgh_ctx *c, const QArgs &a)
    {
       case 0x322: hipLaunchKernelGGL((qrows_kernel<2, 2, 1, 1>), dim3(c->NE), dim3(8), 0, c->stream, a); break;
       case 0x334: hipLaunchKernelGGL((qrows_kernel<3, 4, 2, 1>), dim3(c->NE), dim3(64), 0, c->stream, a); break;
-      case 0x346:
-      {
-         // elements per workgroup (LGH_Q_EPW=1/2/3/4 for A/B; see the kernel's header comment)
-         static const int epw = [] { const char *e = getenv("LGH_Q_EPW"); const int v = e ? atoi(e) : kQrowsEpwDefault; return (v >= 1 && v <= 4) ? v : kQrowsEpwDefault; }();
-         if (epw == 2) { hipLaunchKernelGGL((qrows_kernel<4, 6, 3, (MINW6 < 3 ? 3 : MINW6), false, 2>), dim3(ceil_div(c->NE, 2)), dim3(216), 0, c->stream, a, (unsigned long long *)nullptr); }
-         else if (epw == 3) { hipLaunchKernelGGL((qrows_kernel<4, 6, 3, (MINW6 < 3 ? 3 : MINW6), false, 3>), dim3(ceil_div(c->NE, 3)), dim3(216), 0, c->stream, a, (unsigned long long *)nullptr); }
-         else if (epw == 4) { hipLaunchKernelGGL((qrows_kernel<4, 6, 3, (MINW6 < 3 ? 3 : MINW6), false, 4>), dim3(ceil_div(c->NE, 4)), dim3(216), 0, c->stream, a, (unsigned long long *)nullptr); }
-         else { hipLaunchKernelGGL((qrows_kernel<4, 6, 3, MINW6>), dim3(c->NE), dim3(216), 0, c->stream, a); }
-         break;
-      }
+      case 0x346: hipLaunchKernelGGL((qrows_kernel<4, 6, 3, MINW6>), dim3(c->NE), dim3(216), 0, c->stream, a); break;
       case 0x358: hipLaunchKernelGGL((qrows_kernel<5, 8, 4, 1>), dim3(c->NE), dim3(512), 0, c->stream, a); break;
       default: return unknown_kernel(c->kid);
    }

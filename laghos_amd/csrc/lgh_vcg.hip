@@ -1878,6 +1878,7 @@ struct VcgAux
    long long *rzl = nullptr;   // exact accumulators of (r, z), 3 sets (rz_limbs mode)
    int grid2 = 0;
    // merged E-vector layout of the slab K1 (slab_merge_layout): its set table and the tables of K2 for that layout
+   int rz_words_all = -1;      // several ranks: every rank can exchange (r, z) as accumulator words (-1: not asked yet)
    unsigned *settab = nullptr;
    int *ellm = nullptr;
    int degm = 0;
@@ -2150,7 +2151,27 @@ static int vcg_prepare(lgh_ctx *c, double *B, double *X, double rel_tol, VcgPlan
    const char *rzenv = getenv("LGH_RZ_LIMBS");
    // (several ranks, round 5: all-pairs partitions, where the words of every rank reach every other in one exchange)
    // (a communicator of size 1 - LGH_FORCE_MULTI - has nobody to exchange with: the words are complete as they are)
-   long long *rzl = (limbs && (!multi || ((halo_can_piggyback(c) || c->nranks == 1) && c->t_deg <= 8)) && !(rzenv && rzenv[0] == '0')) ? aux->rzl : nullptr;
+   bool rz_words = limbs && (!multi || ((halo_can_piggyback(c) || c->nranks == 1) && c->t_deg <= 8)) && !(rzenv && rzenv[0] == '0');
+   if (multi && c->nranks > 1)
+   {
+      // Which exchange follows K2 - accumulator words or three doubles - must be the same on every rank, and whether a rank
+      // CAN use the words depends on its own kernels (the slab K1 is dispatched by the rank's zone count): decided
+      // collectively, once per set of tables (a MIN over the ranks; every rank builds its tables in its first solve)
+      if (aux->rz_words_all < 0)
+      {
+         const double mine = rz_words ? 1.0 : 0.0;
+         LGH_HIP_CHECK(hipStreamSynchronize(c->stream));
+         LGH_HIP_CHECK(hipMemcpy(c->scal + 12, &mine, sizeof(double), hipMemcpyHostToDevice)); // (pageable host memory: synchronous copies)
+         rc = allreduce_dev(c, c->scal + 12, 1, 1);
+         if (rc) { return rc; }
+         double all = 0.0;
+         LGH_HIP_CHECK(hipStreamSynchronize(c->stream));
+         LGH_HIP_CHECK(hipMemcpy(&all, c->scal + 12, sizeof(double), hipMemcpyDeviceToHost));
+         aux->rz_words_all = (all > 0.5) ? 1 : 0;
+      }
+      rz_words = rz_words && aux->rz_words_all == 1;
+   }
+   long long *rzl = rz_words ? aux->rzl : nullptr;
    {
       const char *e0 = getenv("LGH_SLAB_DEFER");
       if (e0 && e0[0] == '0') { rzl = nullptr; } // (needs the deferred fold of (d, A d) as well)
