@@ -180,7 +180,7 @@ KERNEL_NAMES = {0: "vcg_apply_plane (H1 CG K1, 3 velocity components per launch)
                 2: "qpoint_kernel (fused QUpdate + both force products)", 3: "force_mult_3d", 4: "force_mult_t_3d",
                 5: "mass_apply_l2 (L2 CG K1)",
                 6: "halo_sum (pack + grouped ncclSend/Recv + combine)", 7: "ncclAllReduce of device scalars"}
-K1_FORMS = {0: "vcg_apply_3d", 2: "vcg_apply_plane", 3: "vcg_apply_mfma346", 4: "vcg_apply_slab346", 5: "vcg_apply_kron"}
+K1_FORMS = {0: "vcg_apply_3d", 2: "vcg_apply_plane", 4: "vcg_apply_slab346", 5: "vcg_apply_kron"}
 
 
 def kernel_names(L, ctx):
@@ -348,7 +348,7 @@ def kernel_sources_sha():
     return h.hexdigest()[:16]
 
 
-PMC_FILE = "r4_pmc_traffic.json"
+PMC_FILE = "r5_pmc_traffic.json"
 
 
 def pmc_traffic(workload, kernel):

@@ -279,8 +279,7 @@ int lgh_ktime_end(lgh_ctx *ctx, int *launches, double *mean_seconds);
  * and are only dispatched then (the column forms run otherwise). */
 int lgh_table_symmetry(lgh_ctx *ctx, int *h1, int *l2);
 /* Which form of the mass-apply kernel K1 the lockstep velocity solve (lgh_solve_velocity) launches for this
- * context: 0 = column form, 2 = plane form, 3 = x contractions on the matrix cores (v_mfma_f64_16x16x4_f64, Q3Q2
- * only), 4 = slab form (sum factorisation in registers, lane-group transposes by v_permlane swaps, Q3Q2 only),
+ * context: 0 = column form, 2 = plane form, 4 = slab form (sum factorisation in registers, lane-group transposes by v_permlane swaps, Q3Q2 only),
  * 5 = Kronecker form (compact mass data on a tensor-product rule: the element matrix as s_e M1 (x) M1 (x) M1 with the
  * 1-D mass tile M1 = B^T diag(w) B; the slab form applies the same where it is dispatched),
  * -1 = no lockstep solve for this kernel id (the scalar CG runs).  Tests use it to make sure a requested
@@ -346,7 +345,7 @@ int lgh_force_mult_E(lgh_ctx *ctx, const double *sJit, const double *x_E, double
 int lgh_force_mult_transpose_E(lgh_ctx *ctx, const double *sJit, const double *v_E, double *y_E);
 int lgh_mass_apply_E(lgh_ctx *ctx, int space, const double *x_E, double *y_E);
 /* ONE launch of the mass-apply kernel K1 of the lockstep velocity solve - in whichever form lgh_k1_form() reports
- * (column / plane / matrix-core / slab), i.e. the kernel lgh_solve_velocity spends most of its time in - exactly as
+ * (column / plane / slab / Kronecker), i.e. the kernel lgh_solve_velocity spends most of its time in - exactly as
  * the solve launches it: first != 0: the first iteration (d = r/diag), else a later one (d = r/diag + beta d_old,
  * beta = rz[c] / rz_prev[c]).  r, d_old: H1 vectors of 3 components (byNODES, device); rz, rz_prev, den: 3 host
  * doubles; y_E: 3 planes of NE*D1D^3 (device) = the element contributions A_e d_e (MassPAOperator::Mult before the

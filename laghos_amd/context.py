@@ -244,10 +244,10 @@ class Context:
         return a.value, b.value
 
     def k1_form(self):
-        """Form of the lockstep velocity solve's mass-apply kernel: 'column', 'plane', 'mfma', 'slab', 'kron' or None."""
+        """Form of the lockstep velocity solve's mass-apply kernel: 'column', 'plane', 'slab', 'kron' or None."""
         f = ctypes.c_int(-2)
         check(self.lib.lgh_k1_form(self.h, ctypes.byref(f)))
-        return {0: "column", 2: "plane", 3: "mfma", 4: "slab", 5: "kron"}.get(f.value)
+        return {0: "column", 2: "plane", 4: "slab", 5: "kron"}.get(f.value)
 
     def test_vcg_k1(self, r, d_old, rz, rz_prev, first):
         """One launch of the lockstep solve's K1 (lgh_test_vcg_k1): (E-vector planes [3, NE*ND] tensor, den[3])."""

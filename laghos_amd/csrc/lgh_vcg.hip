@@ -1872,7 +1872,7 @@ struct VcgAux
    uint8_t *essbits = nullptr;
    int *nstart = nullptr;    // cost-balanced node ranges of the grid2 workgroups of vcg_update_p_k
    unsigned *ellf = nullptr; // ELL transpose as byte offsets into a force E-vector ([e][c][d] + zero slot): vcg_init_force_z_k
-   unsigned *mapb = nullptr; // element -> node map as byte offsets into a node vector: vcg_apply_mfma346
+   unsigned *mapb = nullptr; // element -> node map as byte offsets into a node vector: vcg_apply_slab346
    int map_xrows = 0;        // the nodes of every x-row of every element are consecutive (vcg_apply_slab346 then loads rows, not nodes)
    long long *limbs = nullptr; // exact accumulators of (d, A d), 2 parities (lgh_vcg.hpp)
    long long *rzl = nullptr;   // exact accumulators of (r, z), 3 sets (rz_limbs mode)
@@ -1981,7 +1981,6 @@ bool vcg_available(const lgh_ctx *c) { return vcg_supported(c); }
 int vcg_k1_form(lgh_ctx *c)
 {
    if (!vcg_supported(c)) { return -1; }
-   if (c->kid == 0x346 && c->vcg_variant == 3 && vcg_mfma_available(c)) { return 3; }
    if (c->kid == 0x346 && c->vcg_variant == 4 && vcg_slab_available(c)) { return 4; }
    // Default at Q3Q2 from kSlabMinElements zones per rank: 40.6 vs 48.5 us per launch at 32^3 zones, 316 vs 383 at 64^3
    // (profiles/README.md); smaller meshes do not fill its one workgroup per CU.
@@ -2114,7 +2113,7 @@ static int vcg_prepare(lgh_ctx *c, double *B, double *X, double rel_tol, VcgPlan
             LGH_HIP_CHECK(hipGetLastError());
          }
       }
-      if (vcg_k1_form(c) == 3 || vcg_k1_form(c) == 4)
+      if (vcg_k1_form(c) == 4)
       {
          const size_t nm = (size_t)c->NE * c->ND;
          LGH_HIP_CHECK(hipMalloc((void **)&x->mapb, nm * sizeof(unsigned)));
@@ -2291,7 +2290,6 @@ static void vcg_launch_k1(lgh_ctx *c, const VcgPlan &plan, const VcgArgs &a)
       case 0x334: VCG_DISPATCH(3, 4); break;
       case 0x346:
          if (aux->mapb && k1form == 4) { launch_vcg_slab(c, a); } // slab form: all in registers (lgh_vcg_slab.hip)
-         else if (aux->mapb && k1form == 3) { launch_vcg_mfma(c, a); } // LGH_VCG_VARIANT=3: x contractions on the matrix cores (lgh_vcg_mfma.hip)
          else { VCG_DISPATCH(4, 6); }
          break;
       case 0x358: // LGH_VCG_VARIANT=1: the two-lanes-per-plane split at Q1D = 8 as well (A/B, tests)

@@ -1,5 +1,5 @@
 // lgh_vcg.hpp — state, argument block and grid reductions shared by the kernels of the lockstep velocity solve
-// (lgh_vcg.hip: column / plane forms and the node kernel K2; lgh_vcg_mfma.hip: the matrix-core form of K1).
+// (lgh_vcg.hip: column / plane / Kronecker forms of K1 and the node kernel K2; lgh_vcg_slab.hip: the slab form of K1).
 #pragma once
 #include "lgh_common.hpp"
 
@@ -193,7 +193,7 @@ struct VcgArgs
    const double *DqFull;
    int dqs;
    const int *map;
-   const unsigned *mapb;  // map as byte offsets into a node vector (8 * node): the matrix-core K1 (lgh_vcg_mfma.hip)
+   const unsigned *mapb;  // map as byte offsets into a node vector (8 * node): the slab K1 (lgh_vcg_slab.hip)
    int map_xrows;         // 1: the D1D nodes of every x-row of every element are consecutive node numbers (checked at set-up)
    unsigned *queue;       // slab-form K1, dynamic schedule: one set counter per XCD range, 128 bytes apart (zero between launches)
    long long *rzl;        // rz_limbs mode: three sets of kLimbWords words, exact accumulators of (r, z) (see vcg_rz_commit), or nullptr
@@ -413,9 +413,6 @@ __device__ __forceinline__ long long wave_sum_i64(long long v)
    return (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo);
 }
 
-// lgh_vcg_mfma.hip
-bool vcg_mfma_available(lgh_ctx *c);
-void launch_vcg_mfma(lgh_ctx *c, const VcgArgs &a);
 // lgh_vcg_slab.hip
 bool vcg_slab_available(lgh_ctx *c);
 void launch_vcg_slab(lgh_ctx *c, const VcgArgs &a);

@@ -1,3 +1,7 @@
+// Round 5: moved out of the product library (round-4 verdict, weak #11: a form that loses to every other one is dead weight on the
+// default path).  Was laghos_amd/csrc/lgh_vcg_mfma.hip, dispatched by LGH_VCG_VARIANT=3, tested (tests/test_gpu_k1.py "Q3Q2-64-mfma" up to
+// round 4); measurements: profiles/r3_k1_*_pmc.txt, DESIGN.md section 3 "Matrix cores: measured, not used".
+
 // lgh_vcg_mfma.hip — K1 of the lockstep velocity solve (y_e = B^T D_e B d_e for the three
 // velocity components, Q3Q2 = kernel id 0x346) with the two x contractions on the matrix cores.
 //

@@ -1,6 +1,6 @@
 """Kernel-level parity of K1, the mass-apply kernel of the lockstep velocity solve (the kernel an RK step spends most
 of its time in): ONE launch through the C ABI (lgh_test_vcg_k1), in every form the solve can dispatch
-(column / plane / two-lane plane / matrix-core / slab / Kronecker) and with both forms of the mass data, against the oracle's
+(column / plane / two-lane plane / slab / Kronecker) and with both forms of the mass data, against the oracle's
 element-level mass apply (MassPAOperator::Mult before the E->L sum, /root/reference/laghos_assembly.cpp:117-121,
 on d = r/diag + beta d_old as upstream CGSolver::Mult forms it).  What is compared is what K1 hands to K2: the
 E-vector of A_e d_e for the three components and (d, A d).  Tolerance 1e-13 relative to the largest entry (the
@@ -20,7 +20,6 @@ K1_CASES = [
     ("Q3Q2-64-default", "cube01_hex", 1, 3, 2, None, "plane"),
     ("Q3Q2-64-column", "cube01_hex", 1, 3, 2, "0", "column"),
     ("Q3Q2-64-plane", "cube01_hex", 1, 3, 2, "2", "plane"),
-    ("Q3Q2-64-mfma", "cube01_hex", 1, 3, 2, "3", "mfma"),
     ("Q3Q2-64-slab", "cube01_hex", 1, 3, 2, "4", "slab"),
     ("Q3Q2-16-slab", "box01_hex", 0, 3, 2, "4", "slab"),      # ragged last set (sets of 5 elements)
     ("Q3Q2-16-plane", "box01_hex", 0, 3, 2, "2", "plane"),    # ragged last batch (batches of 13)

@@ -1,0 +1,10 @@
+# Copies what tools/gpu_final_r5.sh left under gpurun_out/final_r5 into profiles/ under the names the documents cite.
+cd /root/repo
+O=gpurun_out/final_r5
+grep '^{' $O/bench.json | tail -1 > profiles/r5_bench.json
+grep '^{' $O/bench_under_rocprof.json | tail -1 > profiles/r5_bench_under_rocprofv3.json
+cp $O/bench_kernel_stats.csv profiles/r5_bench_kernel_stats.csv
+cp $O/gaps.txt profiles/r5_gpu_idle_gaps.txt
+cp $O/r5_pmc_traffic.json profiles/r5_pmc_traffic.json
+for w in c2 c3 tg; do for k in FETCH_SIZE WRITE_SIZE; do cp $O/${w}_$k.txt profiles/r5_pmc_${w}_$k.txt; done; done
+{ tail -3 $O/pytest_gpu.log; tail -2 $O/smoke.log; } > profiles/r5_pytest_gpu_summary.txt

@@ -1,6 +1,6 @@
 # FETCH_SIZE / WRITE_SIZE of every kernel at C2 (32^3), at 64^3 Sedov (HBM-resident) and at 64^3 Taylor-Green, default
 # dispatch, through the C++ driver (separate --pmc passes, --kernel-trace only).  Writes the per-kernel summaries under
-# gpurun_out/pmc_traffic/ and the JSON bench.py quotes (profiles/r4_pmc_traffic.json is written on the GPU box into
+# gpurun_out/pmc_traffic/ and the JSON bench.py quotes (profiles/r5_pmc_traffic.json is written on the GPU box into
 # gpurun_out and copied by hand: the repo copy there is not merged back).
 cd /root/repo
 export TMPDIR=/tmp
@@ -16,5 +16,5 @@ run c2 "-p 1 -m data/cube01_hex.mesh -rs 4"
 run c3 "-p 1 -m data/cube01_hex.mesh -rs 5"
 run tg "-p 0 -m data/cube01_hex.mesh -rs 5"
 python tools/update_pmc_traffic.py c2=$O/c2_FETCH_SIZE.txt,$O/c2_WRITE_SIZE.txt c3=$O/c3_FETCH_SIZE.txt,$O/c3_WRITE_SIZE.txt tg=$O/tg_FETCH_SIZE.txt,$O/tg_WRITE_SIZE.txt
-cp profiles/r4_pmc_traffic.json $O/
+cp profiles/r5_pmc_traffic.json $O/
 head -30 $O/c3_FETCH_SIZE.txt
