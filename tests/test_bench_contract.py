@@ -88,7 +88,7 @@ def _check_line(d, text):
     # parity block: the bench's own problem against the oracle, printed with the number it belongs to
     assert d["parity"]["pass"] is True and d["parity"]["e_norm_rel_diff"] <= 1e-9 and d["parity"]["rk4_steps"] == 3
     # the other single-GPU configs of BASELINE.json as extra legs: value, ms_per_step, roofline kernel and fraction only
-    for leg in ("c3", "tg", "c5", "c2dev", "c2stored", "c2multi"):
+    for leg in [l for l in ("c3", "tg", "c5", "c2dev", "c2stored", "c2multi", "c2multistored", "c3stored") if l in d["legs"]]:
         g = d["legs"][leg]
         assert g["value"] > 0 and g["ms_per_step"] > 0 and 0 < g["frac"] < 1 and g["kernel"], leg
         assert set(g) <= {"value", "ms_per_step", "kernel", "frac", "force_mass_frac", "ms_per_step_minus_single_rank_path"}, leg
@@ -113,10 +113,34 @@ def test_compact_line_of_a_full_record_fits_the_driver():
     assert line["value"] == full["value"] and line["ms_per_step"] == full["ms_per_step"]  # what the driver's clock is held against: unrounded
 
 
+def test_committed_line_is_what_the_driver_reads():
+    """profiles/r5_bench.json is the stdout line of `python bench.py` on an MI355X (tools/gpu_final_r5.sh), byte for byte what
+    the driver's `python bench.py --gpus 1 --steps 20 --warmup 5` prints last: it holds the contract, fits the driver's
+    8 KB, quotes counter traffic of this very build (sha over the kernel sources) and is the compact form of the full
+    record written beside it (profiles/r5_bench_detail.json)."""
+    with open(os.path.join(ROOT, "profiles", "r5_bench.json")) as f:
+        text = [l for l in f.read().splitlines() if l.startswith("{")][0]
+    d = json.loads(text)
+    _check_line(d, text)
+    assert d["steps"] == 20 and d["warmup"] == 5
+    assert d["roofline"]["traffic"] is not None and d["roofline"]["traffic_source"].startswith("profiles/r5_pmc_traffic.json")
+    assert "compact" in d["config"]["mass_data"]  # the operator substitution decided by a device check is named in the line
+    for leg in ("c2multistored", "c3stored"):      # the stored-table twins of the N-rank and the 64^3 legs (round-4 verdict, item 9)
+        assert 0 < d["legs"][leg]["value"] < d["legs"][leg.replace("stored", "")]["value"]
+    bench = _bench()
+    with open(os.path.join(ROOT, "profiles", "r5_bench_detail.json")) as f:
+        full = json.load(f)
+    again = bench.compact_line(full, d["detail"])
+    assert again == d
+    # the full record prices K2 with the layout that ran: merged E-vector (fewer values than NE * ND), two-table ELL
+    k2 = [v for k, v in full["kernels"].items() if k.startswith("vcg_update_p_k")][0]
+    assert "summed by K1" in k2["moves"] and k2["bytes_per_launch"] == d["roofline"]["bytes_per_launch"]
+
+
 def test_profiled_run_agrees_with_the_plain_run():
     """The same command under rocprofv3 --kernel-trace --stats: same workload, throughput within
     the profiler's overhead."""
-    a, b = _line("r4_bench.json"), _line("r4_bench_under_rocprofv3.json")
+    a, b = _line("r5_bench.json"), _line("r5_bench_under_rocprofv3.json")
     assert a["config"]["workload"] == b["config"]["workload"]
     assert 0.8 * a["value"] < b["value"] <= 1.05 * a["value"]
 
