@@ -36,3 +36,51 @@ def make_gpu(prob, **kw):
 def make_oracle(prob, **kw):
     from oracle.driver import Hydro
     return Hydro(prob, **kw)
+
+
+class PermutedProblem:
+    """The same discrete problem as `base` under a random renumbering of the H1 nodes and a random order of the zones -
+    what a general mesh library hands the operators (MFEM numbers vertices, then edge, face and interior dofs, and orders
+    its elements its own way; the reference takes whatever `H1.GetElementRestriction` / the mesh give it).  Only the
+    element-local dof order stays lexicographic: that IS the interface (laghos_assembly.cpp:296-514 index the E-vector so).
+    None of the structure the kernels exploit when they find it survives: no x-chains of zones (merged E-vector), no
+    consecutive x-rows of nodes (row loads of the slab K1), no locality between a zone and its neighbours."""
+
+    def __init__(self, base, seed=7, permute_nodes=True, permute_elements=True):
+        rng = np.random.default_rng(seed)
+        self.base = base
+        N, NE = base.N, base.NE
+        self.node_perm = rng.permutation(N) if permute_nodes else np.arange(N)       # old node i -> new node node_perm[i]
+        self.elem_perm = rng.permutation(NE) if permute_elements else np.arange(NE)  # new zone j = old zone elem_perm[j]
+        hm = np.asarray(base.h1map).reshape(NE, base.ND)
+        self.h1map = np.ascontiguousarray(self.node_perm[hm[self.elem_perm]].astype(np.int32))
+        self.ess = [np.sort(self.node_perm[np.asarray(e, dtype=np.int64)]).astype(np.int32) for e in base.ess]
+        own = np.empty(N)
+        own[self.node_perm] = np.asarray(base.owner)
+        self.owner = own
+
+    def __getattr__(self, name):  # everything that does not depend on the numbering
+        return getattr(self.base, name)
+
+    def nodes(self, v):
+        """a node vector of `dim` (or 1) components in the new numbering"""
+        v = np.asarray(v).reshape(-1, self.base.N)
+        out = np.empty_like(v)
+        out[:, self.node_perm] = v
+        return out.reshape(-1)
+
+    def zones(self, a, per_zone):
+        return np.asarray(a).reshape(self.base.NE, per_zone)[self.elem_perm].reshape(-1)
+
+    def state(self, S):
+        """a state vector [x | v | e] of the base problem in the new numbering"""
+        b = self.base
+        return np.concatenate([self.nodes(S[:b.H1V]), self.nodes(S[b.H1V:2 * b.H1V]), self.zones(S[2 * b.H1V:], b.NL)])
+
+    def initial_state(self):
+        b = self.base
+        S, rho_l2, gamma, rho0_q = b.initial_state()
+        return self.state(S), self.zones(rho_l2, b.NL), np.asarray(gamma)[self.elem_perm].copy(), self.zones(rho0_q, b.NQ)
+
+    def accel_source(self):
+        return self.nodes(self.base.accel_source())

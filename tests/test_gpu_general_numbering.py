@@ -1,0 +1,136 @@
+"""The operators on a mesh whose numbering has no structure: random renumbering of the H1 nodes, random order of the zones
+(tests/helpers.py::PermutedProblem).  Every mesh of BASELINE.json comes out of this repository's own Cartesian generator -
+lexicographic nodes, zones x-fastest - and the kernels use what they FIND of that (x-chains of zones -> merged E-vector,
+consecutive x-rows of nodes -> row loads, neighbouring zones on one XCD); what the reference hands its operators is
+MFEM's numbering (vertices, then edge / face / interior dofs; `H1.GetElementRestriction`, laghos_assembly.cpp:557-565),
+which has none of it.  These cases run the general path of every kernel of the hot path: against the oracle on the same
+permuted problem (which knows nothing but the element -> node map), and against the un-permuted run - the discrete
+problem is the same, so `|e|`, the time step and the state agree to round-off (sums run in another order)."""
+import numpy as np
+import pytest
+
+from helpers import PermutedProblem, deformed_state, make_gpu, make_oracle, rel_err, seeded
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # (id, problem kwargs, LGH_VCG_VARIANT)
+    ("3D-Q3Q2-512-default", dict(mesh="cube01_hex", rs=2, order_v=3, order_e=2, problem=1), None),
+    ("3D-Q3Q2-512-slab", dict(mesh="cube01_hex", rs=2, order_v=3, order_e=2, problem=1), "4"),
+    ("3D-Q2Q1-512", dict(mesh="cube01_hex", rs=2, order_v=2, order_e=1, problem=1), None),
+    ("3D-Q4Q3-16-kron", dict(mesh="box01_hex", rs=0, order_v=4, order_e=3, problem=3), None),
+    ("2D-Q3Q2-64", dict(mesh="square01_quad", rs=2, order_v=3, order_e=2, problem=1), None),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_rhs_on_a_permuted_mesh_vs_oracle_and_vs_the_structured_mesh(case, monkeypatch):
+    """One evaluation of dS/dt (quadrature update, both force products, three H1 solves, the L2 solve; CG to 1e-13) on a
+    distorted state: HIP path on the permuted problem against (a) the oracle on the same permuted problem, (b) the HIP path
+    on the structured problem, mapped through the permutation."""
+    from oracle.fem import Problem
+    _, kw, variant = case
+    monkeypatch.delenv("LGH_VCG_VARIANT", raising=False)
+    if variant is not None:
+        monkeypatch.setenv("LGH_VCG_VARIANT", variant)
+    base = Problem(**kw)
+    perm = PermutedProblem(base, seed=11)
+    S_b = deformed_state(base, seed=23)
+    S_p = perm.state(S_b)
+    H1V = base.H1V
+
+    def rhs_gpu(prob, S):
+        g = make_gpu(prob, cg_tol=1e-13)
+        try:
+            form = g.ctx.k1_form()
+            _, n_merged = g.ctx.test_vcg_merged_faces() if prob.dim == 3 else (None, 0)
+            Sd, dS = g.ctx.to_dev(S), g.ctx.zeros(S.size)
+            g.reset_quadrature_data()
+            g.reset_time_step_estimate()
+            g.mult(Sd, dS)
+            dt = g.get_time_step_estimate(Sd)
+            g.ctx.sync()
+            return dS.cpu().numpy(), dt, form, n_merged
+        finally:
+            g.close()
+
+    dS_p, dt_p, form_p, merged_p = rhs_gpu(perm, S_p)
+    dS_b, dt_b, form_b, merged_b = rhs_gpu(base, S_b)
+    assert form_p == form_b
+    if variant == "4":
+        assert form_p == "slab" and merged_b > 0 and merged_p == 0  # the zones of a set are no neighbours any more: nothing to merge
+    o = make_oracle(perm, cg_tol=1e-13)
+    try:
+        dS_o = np.empty_like(S_p)
+        o.qdata_is_current = False
+        o.reset_time_step_estimate()
+        o.mult(S_p, dS_o)
+        dt_o = o.get_time_step_estimate(S_p)
+    finally:
+        o.close()
+    for name, sl in (("dv", slice(H1V, 2 * H1V)), ("de", slice(2 * H1V, None))):
+        assert rel_err(dS_p[sl], dS_o[sl]) < 1e-9, (name, "vs the oracle on the permuted mesh")
+        assert rel_err(dS_p[sl], perm.state(dS_b)[sl]) < 1e-9, (name, "vs the structured mesh")
+    assert np.array_equal(dS_p[:H1V], S_p[H1V:2 * H1V])  # dx/dt = v
+    assert abs(dt_p - dt_o) <= 1e-12 * dt_o and abs(dt_p - dt_b) <= 1e-12 * dt_b
+
+
+def test_k1_and_mass_operators_on_a_permuted_mesh(monkeypatch):
+    """The mass operators alone, kernel by kernel, on the permuted 512-zone Q3Q2 mesh: MassPAOperator::Mult on both spaces
+    and one launch of the slab K1 (node gathers instead of row loads, element-local E-vector in every set) vs the oracle."""
+    from oracle.driver import _dp
+    from oracle.fem import Problem
+    base = Problem(mesh="cube01_hex", rs=2, order_v=3, order_e=2, problem=1)
+    perm = PermutedProblem(base, seed=13)
+    monkeypatch.setenv("LGH_VCG_VARIANT", "4")
+    g, o = make_gpu(perm), make_oracle(perm)
+    try:
+        N, NE, ND = perm.N, perm.NE, perm.ND
+        xv, xe = seeded(N, 301), seeded(perm.L2V, 302)
+        yv, ye = g.ctx.empty(N), g.ctx.empty(perm.L2V)
+        g.ctx.mass_set_ess(-1)
+        g.ctx.mass_mult(0, g.ctx.to_dev(xv), yv)
+        g.ctx.mass_mult(1, g.ctx.to_dev(xe), ye)
+        g.ctx.sync()
+        assert rel_err(yv.cpu().numpy(), o.mass_mult(0, xv)) < 2e-12
+        assert rel_err(ye.cpu().numpy(), o.mass_mult(1, xe)) < 2e-12
+        r, d_old = seeded(3 * N, 303), seeded(3 * N, 304)
+        dinv = 1.0 / np.asarray(o.diagV)
+        rz = np.array([float(np.dot(r[c * N:(c + 1) * N] ** 2, dinv)) for c in range(3)])
+        rz_prev = rz * np.array([1.7, 0.6, 1.1])
+        yE, den = g.ctx.test_vcg_k1(g.ctx.to_dev(r), g.ctx.to_dev(d_old), rz, rz_prev, False)
+        yE = yE.cpu().numpy()
+        hmap = np.asarray(perm.h1map).reshape(NE, ND)
+        for c in range(3):
+            d = r[c * N:(c + 1) * N] * dinv + (rz[c] / rz_prev[c]) * d_old[c * N:(c + 1) * N]
+            xE = np.ascontiguousarray(d[hmap].reshape(-1))
+            yE_o = np.empty(NE * ND)
+            o.L.lgo_mass_apply_E(o.h, 0, _dp(xE), _dp(yE_o))
+            assert rel_err(yE[c], yE_o) < 2e-12, c
+            assert abs(den[c] - float(np.dot(xE, yE_o))) <= 2e-12 * abs(den[c]), c
+    finally:
+        g.close()
+        o.close()
+
+
+def test_time_steps_on_a_permuted_mesh_reproduce_the_structured_run():
+    """Ten RK4 steps of 3D Sedov Q3Q2 (512 zones) from t = 0 with the real dt controller: the permuted mesh takes the same
+    steps with the same dt and ends at the same |e| as the structured one (round-off), and at the oracle's."""
+    from laghos_amd.hydro import TimeLoop
+    from oracle.fem import Problem
+    base = Problem(mesh="cube01_hex", rs=2, order_v=3, order_e=2, problem=1)
+    perm = PermutedProblem(base, seed=17)
+    out = {}
+    for name, prob in (("structured", base), ("permuted", perm)):
+        g = make_gpu(prob)
+        try:
+            loop = TimeLoop(g, t_final=1e9)
+            for _ in range(10):
+                assert loop.step()
+            out[name] = (loop.t, loop.dt, loop.steps, g.e_norm(loop.S))
+        finally:
+            g.close()
+    (t_s, dt_s, ti_s, e_s), (t_p, dt_p, ti_p, e_p) = out["structured"], out["permuted"]
+    assert ti_s == ti_p  # (accepted + repeated steps)
+    assert abs(t_p - t_s) <= 1e-11 * t_s and abs(dt_p - dt_s) <= 1e-10 * dt_s
+    assert abs(e_p - e_s) <= 1e-9 * e_s
