@@ -205,8 +205,11 @@ def mass_data_note(sim):
     L = _lib.load()
     form = ctypes.c_int(-1)
     L.lgh_mass_data_form(sim.L.laghos_sim_context(sim.h), ctypes.byref(form))
+    j0 = ctypes.c_int(0)
+    L.lgh_jac0inv_form(sim.L.laghos_sim_context(sim.h), ctypes.byref(j0))
     return {1: "compact W[q]*s_e (device check of every stored entry, rel 1e-12; affine zones, zone-constant rho0)",
-            0: "stored table D[q,e] (the reference's form)"}.get(form.value, "not decided yet (no mass apply ran)")
+            0: "stored table D[q,e] (the reference's form)"}.get(form.value, "not decided yet (no mass apply ran)") + \
+        ("; Jac0inv one per zone (zone-constant, device check, 1e-12)" if j0.value == 1 else "; Jac0inv per point")
 
 
 def algorithmic_bytes(sz):
@@ -250,6 +253,12 @@ def moved_bytes(sz, L, ctx, k1_name):
     L.lgh_qupdate_stores_stress(ctx, ctypes.byref(st))
     if st.value == 0:  # stress kept in registers: the nine stressJinvT planes are not written
         b[2] -= NE * 8 * dim * dim * NQ
+    j0c, qf = ctypes.c_int(0), ctypes.c_int(0)
+    L.lgh_jac0inv_form(ctx, ctypes.byref(j0c))
+    L.lgh_qupdate_form(ctx, ctypes.byref(qf))
+    jac0_compact = j0c.value == 1 and qf.value == 1  # (the row form reads one inverse Jacobian per zone; the point form the stored values)
+    if jac0_compact:
+        b[2] -= NE * 8 * dim * dim * (NQ - 1)
     # the E-vector between K1 and K2 and K2's table as THIS context lays them out (lgh_vcg_layout_stats): the slab K1 sums
     # the shared x-faces of its sets itself (merged layout: ~17 % fewer values), K2 reads 16 bytes of table per node and
     # the second 16 only in the wavefronts that need them
@@ -264,7 +273,7 @@ def moved_bytes(sz, L, ctx, k1_name):
              1: "r, d read and written, x every second iteration, 1/diag, flag bytes; E-vector %d of %d values per component (%s); "
                 "transposed-restriction table %.1f of %.1f MB fetched" % (evec, NE * ND, "x-faces of a set summed by K1" if st4[3] else "element-local", 1e-6 * tab, 1e-6 * 32 * N),
              5: "mass data: %s" % ("compact, one factor per element" if l2_compact else "stored table"),
-             2: "stressJinvT %s" % ("kept in registers (both force products formed in the kernel; lgh_qupdate_store_stress(ctx, 0))" if st.value == 0 else "written (9 planes)")}
+             2: "Jac0inv %s; stressJinvT %s" % ("one per zone (zone-constant: device check at set-up)" if jac0_compact else "per point", "kept in registers (both force products formed in the kernel; lgh_qupdate_store_stress(ctx, 0))" if st.value == 0 else "written (9 planes)")}
     return b, notes, k1_compact
 
 

@@ -85,6 +85,12 @@ double *lgh_mass_D(lgh_ctx *ctx);
  * on the device (every entry to 1e-12 relative, the size of the rounding of the stored entries; LGH_MASS_RANK1_TOL) at the first mass apply after lgh_setup_rho0detj0() or after lgh_mass_D() was
  * called: a caller that writes through the lgh_mass_D() pointer calls lgh_mass_D() again after its last write. */
 int lgh_mass_data_form(lgh_ctx *ctx, int *form);
+/* Form of qdata.Jac0inv (laghos_solver.cpp:1195) the row-form quadrature update reads: *compact = 1: one inverse Jacobian per
+ * zone - lgh_setup_rho0detj0 found Jac0inv the same at every point of every zone (each entry against the zone's first point,
+ * to 1e-12 of the zone's largest entry; LGH_JAC0_TOL), which is what an affine initial zone has - nine doubles per zone
+ * instead of nine per quadrature point (15.5 of the 20.5 KB the update streams per zone at Q3Q2); 0: the point values
+ * (a curved initial mesh; LGH_JAC0_COMPACT=0).  The arrays of lgh_qdata_Jac0inv() are written in full either way. */
+int lgh_jac0inv_form(lgh_ctx *ctx, int *compact);
 /* A caller that keeps the lgh_mass_D() pointer and writes the table after a mass apply has run says so with this call
  * (calling lgh_mass_D() again does the first half too): the compact form is tested for again at the next apply,
  * and the Jacobi diagonal (lgh_mass_diag, OperatorJacobiSmoother of laghos_solver.cpp:266-270) is reassembled from the

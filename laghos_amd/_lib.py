@@ -89,6 +89,7 @@ SYMBOLS = {
     "lgh_l2_mass_form": (_I, [_P, c_int_p, c_int_p]),
     "lgh_vcg_layout_stats": (_I, [_P, ctypes.POINTER(ctypes.c_long)]),
     "lgh_mass_data_form": (_I, [_P, c_int_p]),
+    "lgh_jac0inv_form": (_I, [_P, c_int_p]),
     "lgh_mass_data_changed": (_I, [_P]),
     "lgh_comm_stats": (_I, [_P, c_int_p, ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_long), c_int_p, c_int_p]),
     "lgh_qupdate_set_tiny_grad": (_I, [_P, _D]),

@@ -280,6 +280,12 @@ class Context:
         check(self.lib.lgh_mass_data_form(self.h, ctypes.byref(f)))
         return "rank1" if f.value == 1 else "stored"
 
+    def jac0inv_form(self):
+        """'compact' when the row-form update reads one Jac0inv per zone (lgh_jac0inv_form), 'stored' otherwise."""
+        f = ctypes.c_int(-1)
+        check(self.lib.lgh_jac0inv_form(self.h, ctypes.byref(f)))
+        return "compact" if f.value == 1 else "stored"
+
     def qupdate_store_stress(self, on):
         """0: lgh_qupdate keeps the stress in registers (stressJinvT is not written; its readers refuse)."""
         check(self.lib.lgh_qupdate_store_stress(self.h, int(bool(on))))

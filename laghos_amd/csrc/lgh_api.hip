@@ -409,6 +409,7 @@ static int create_impl(const lgh_config *cfg, lgh_ctx *c, const int kid)
    LGH_TRY(dev_alloc_zero(&c->stressJinvT, nq * dim * dim));
    LGH_TRY(dev_alloc_zero(&c->Jac0inv, nq * dim * dim));
    LGH_TRY(dev_alloc_zero(&c->Jac0inv_soa, nq * dim * dim));
+   LGH_TRY(dev_alloc_zero(&c->Jac0inv_e, (size_t)cfg->NE * dim * dim));
    LGH_TRY(dev_alloc_zero(&c->rho0DetJ0w, nq));
    LGH_TRY(dev_alloc_zero(&c->massD, nq + 2048)); // (one set of the matrix-core K1 behind the last element: its pipeline prefetches without predicates)
    LGH_TRY(dev_alloc_zero(&c->diagV, (size_t)c->N));
@@ -458,7 +459,7 @@ int lgh_destroy(lgh_ctx *c)
    (void)hipStreamSynchronize(c->stream);
    void *ptrs[] = {c->B, c->G, c->Bl, c->W, c->w1d, c->M1h, c->M1l, c->gamma, c->h1map, c->t_off, c->t_idx, c->t_ell, c->essmask[0],
                    c->essmask[1], c->essmask[2], c->ess[0], c->ess[1], c->ess[2], c->owner,
-                   c->stressJinvT, c->Jac0inv, c->Jac0inv_soa, c->rho0DetJ0w, c->massD, c->diagV, c->dinvV,
+                   c->stressJinvT, c->Jac0inv, c->Jac0inv_soa, c->Jac0inv_e, c->rho0DetJ0w, c->massD, c->diagV, c->dinvV,
                    c->dt_est_dev, c->erhs_q, c->v_snap, c->dev_flags, c->ones_l2, c->massS, c->ones_ne, c->force_e_q, c->XE, c->YE, c->cg_r, c->cg_z, c->cg_d0, c->cg_d1, c->cg_y,
                    c->partials, c->tickets, c->cgs, c->scal, c->vcg_s, c->vcg_vec, c->vcg_partials,
                    c->vcg_tickets};
@@ -1151,6 +1152,12 @@ int lgh_test_vcg_k1(lgh_ctx *c, const double *r, const double *d_old, const doub
 {
    LGH_CHECK_ARG(c && r && (first || d_old) && rz && rz_prev && y_E && den);
    return vcg_test_k1(c, r, d_old, rz, rz_prev, first, y_E, den);
+}
+int lgh_jac0inv_form(lgh_ctx *c, int *compact)
+{
+   LGH_CHECK_ARG(c && compact);
+   *compact = (c->jac0_compact == 1) ? 1 : 0;
+   return LGH_OK;
 }
 int lgh_vcg_layout_stats(lgh_ctx *c, long out[4])
 {

@@ -110,6 +110,8 @@ struct lgh_ctx
    // QuadratureData + mass PA data
    double *stressJinvT, *Jac0inv, *rho0DetJ0w, *massD, *diagV, *dinvV;
    double *Jac0inv_soa;  // plane-major copy of Jac0inv for coalesced reads in QUpdate
+   double *Jac0inv_e;    // dim*dim per zone: Jac0inv where it is the same at every point of a zone (an affine initial zone; jac0_compact)
+   int jac0_compact;     // 1: the row-form update reads Jac0inv_e (checked at lgh_setup_rho0detj0), 0: the point values
    // Rank-1 form of the mass data: where detJ0 and rho0 are constant inside every element (affine elements, piecewise
    // constant density - every mesh and problem of data/), massD[q + NQ e] = W[q] * massS[e] to the last bit or two;
    // the mass kernels then read 8 bytes per element instead of 8 NQ.  -1: not looked at yet (set-up, lgh_mass_D handed
@@ -132,7 +134,8 @@ struct lgh_ctx
    unsigned long qgen;   // counts lgh_qupdate / invalidations (lgh_quadrature_generation)
    int *dev_flags;       // 8 device ints, one owner each: [0] / [2] "v differs from v_snap" of the current lgh_solve_energy (main /
                          // second stream), [1] "x differs from ones" of lgh_force_mult, [3] "mass table is not W[q]*s_e" (mass_data),
-                         // [4] "an energy right-hand side was poisoned" (poison_if_k; read and cleared by lgh_get_dt_est)
+                         // [4] "an energy right-hand side was poisoned" (poison_if_k; read and cleared by lgh_get_dt_est),
+                         // [5] "Jac0inv varies inside a zone" (jac0_compact_k, lgh_setup_rho0detj0)
    double *ones_l2;      // L2V ones: the operator's own `one` (laghos_solver.cpp:170-171), allocated on first use
    int stress_store;            // lgh_qupdate_store_stress: 1 (default) = lgh_qupdate writes the nine stressJinvT planes; 0 = the stress stays in registers
    int stress_current;          // stressJinvT holds the stress of the current quadrature data (consumers refuse it otherwise)

@@ -35,6 +35,7 @@ struct QArgs
    const double *rho0DetJ0w_in;
    const double *Jac0inv_in;
    const double *Jac0inv_soa; // [q + NQ*e + NE*NQ*k], k = i + dim*j (internal copy)
+   const double *Jac0inv_e;   // row form of the update: [k + dim*dim*e] where Jac0inv is the same at every point of a zone (else nullptr)
    double *Jac0inv_soa_out;
    double *stressJinvT;
    // setup outputs

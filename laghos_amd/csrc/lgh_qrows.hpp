@@ -86,7 +86,10 @@ template <int N> __device__ __forceinline__ void row_load(const double *__restri
 // (16 words per workgroup: 12 stamps, then xcc << 32 | hw_id) - where a workgroup's life goes, and what shares a CU
 // with what (tools/q_trace_summary.py).  An instantiation of its own: the production kernel carries none of it.
 constexpr int kQTraceRec = 16;
-template <int D, int Q, int L, int MINW, bool TRACE = false>
+// J0C (round 5): Jac0inv is the same at every point of a zone (checked at lgh_setup_rho0detj0; a.Jac0inv_e): nine doubles per zone
+// in scalar registers instead of nine per point in vector registers - 15.5 of the 20.5 KB a zone streams at Q3Q2, and the
+// first thing a workgroup waits for (profiles/r5_q_map_formula_negative.txt: its load phase is bound by this stream).
+template <int D, int Q, int L, int MINW, bool TRACE = false, bool J0C = false>
 __global__ void __launch_bounds__(Q *Q *Q, MINW)
 qrows_kernel(const QArgs a, unsigned long long *trace = nullptr)
 {
@@ -147,8 +150,16 @@ qrows_kernel(const QArgs a, unsigned long long *trace = nullptr)
    }
    for (int i = lt; i < NL; i += NT) { sE[i] = a.e[(size_t)e * NL + i]; }
    double J0i[9];
+   if (J0C)
+   {
 #pragma unroll
-   for (int k = 0; k < 9; k++) { J0i[k] = a.Jac0inv_soa[eq + plane * k]; }
+      for (int k = 0; k < 9; k++) { J0i[k] = uniform_f64(a.Jac0inv_e[(size_t)9 * e + k]); } // (e is wave-uniform: scalar registers)
+   }
+   else
+   {
+#pragma unroll
+      for (int k = 0; k < 9; k++) { J0i[k] = a.Jac0inv_soa[eq + plane * k]; }
+   }
    const double rdw = a.rho0DetJ0w_in[eq];
    const double weight = a.W[lt];
    LGH_QSTAMP(1); // loads issued
@@ -440,28 +451,34 @@ template <int MINW6> static int launch_qrows_w(lgh_ctx *c, const QArgs &a)
          LGH_HIP_CHECK(hipMalloc((void **)&q_trace_dev, (size_t)kQTraceRec * c->NE * 8));
          q_trace_n = c->NE;
       }
-      hipLaunchKernelGGL((qrows_kernel<4, 6, 3, MINW6, true>), dim3(c->NE), dim3(216), 0, c->stream, a, q_trace_dev);
+      if (a.Jac0inv_e) { hipLaunchKernelGGL((qrows_kernel<4, 6, 3, MINW6, true, true>), dim3(c->NE), dim3(216), 0, c->stream, a, q_trace_dev); }
+      else { hipLaunchKernelGGL((qrows_kernel<4, 6, 3, MINW6, true, false>), dim3(c->NE), dim3(216), 0, c->stream, a, q_trace_dev); }
       LGH_HIP_CHECK(hipGetLastError());
       static int calls = 0;
       const char *nenv = getenv("LGH_Q_TRACE_CALL"); // which call to dump (default 40: a developed bench window)
       if (++calls == (nenv ? atoi(nenv) : 40)) { qrows_trace_dump(c); }
       return LGH_OK;
    }
+#define LGH_QROWS(D_, Q_, L_, W_, NT_) do { if (a.Jac0inv_e) { hipLaunchKernelGGL((qrows_kernel<D_, Q_, L_, W_, false, true>), dim3(c->NE), dim3(NT_), 0, c->stream, a, (unsigned long long *)nullptr); } \
+                                           else { hipLaunchKernelGGL((qrows_kernel<D_, Q_, L_, W_, false, false>), dim3(c->NE), dim3(NT_), 0, c->stream, a, (unsigned long long *)nullptr); } } while (0)
    switch (c->kid)
    {
-      case 0x322: hipLaunchKernelGGL((qrows_kernel<2, 2, 1, 1>), dim3(c->NE), dim3(8), 0, c->stream, a); break;
-      case 0x334: hipLaunchKernelGGL((qrows_kernel<3, 4, 2, 1>), dim3(c->NE), dim3(64), 0, c->stream, a); break;
-      case 0x346: hipLaunchKernelGGL((qrows_kernel<4, 6, 3, MINW6>), dim3(c->NE), dim3(216), 0, c->stream, a); break;
-      case 0x358: hipLaunchKernelGGL((qrows_kernel<5, 8, 4, 1>), dim3(c->NE), dim3(512), 0, c->stream, a); break;
+      case 0x322: LGH_QROWS(2, 2, 1, 1, 8); break;
+      case 0x334: LGH_QROWS(3, 4, 2, 1, 64); break;
+      case 0x346: LGH_QROWS(4, 6, 3, MINW6, 216); break;
+      case 0x358: LGH_QROWS(5, 8, 4, 1, 512); break;
       default: return unknown_kernel(c->kid);
    }
+#undef LGH_QROWS
    LGH_HIP_CHECK(hipGetLastError());
    return LGH_OK;
 }
 static int launch_qrows(lgh_ctx *c, const QArgs &a)
 {
    const char *oenv = getenv("LGH_Q_OCC4"); // A/B: 0 = the three-wavefront build for every context, 1 = the four-wavefront build
-   const bool w4 = oenv ? oenv[0] == '1' : !a.visc;
+   // (round 5: with one Jac0inv per zone in scalar registers the 128-register build spills 11 instead of 26 and wins with
+   //  viscosity as well - 591 -> 584 us at C2, 3.96 -> 3.75 ms at 64^3 Sedov, profiles/r5_q_jac0inv_ab.txt)
+   const bool w4 = oenv ? oenv[0] == '1' : (!a.visc || a.Jac0inv_e != nullptr);
    return w4 ? launch_qrows_w<4>(c, a) : launch_qrows_w<1>(c, a);
 }
 

@@ -16,6 +16,7 @@ int qupdate(lgh_ctx *c, const double *S)
    a.result = c->dt_est_dev;
    // lgh_qupdate_store_stress(ctx, 0): with both force products formed from registers nobody reads the nine stressJinvT
    // planes (43 % of this kernel's bytes) - they are not written; every reader checks stress_current and refuses
+   a.Jac0inv_e = (c->jac0_compact == 1) ? c->Jac0inv_e : nullptr;
    const bool keep = !c->stress_store && a.erhs_q && a.force_e && c->v_snap;
    if (keep) { a.stressJinvT = nullptr; }
    // 3D up to Q4Q3: the form with row-owned contraction stages (lgh_qrows.hpp); LGH_Q_FORM=0: the point form (A/B, tests)

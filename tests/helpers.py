@@ -84,3 +84,30 @@ class PermutedProblem:
 
     def accel_source(self):
         return self.nodes(self.base.accel_source())
+
+
+class CurvedInitialMesh:
+    """The same problem on an initial mesh whose zones are NOT affine: every interior node of the structured mesh is moved by
+    a smooth random fraction of the mesh width before anything is set up.  Nothing the kernels find on a Cartesian mesh
+    holds any more: Jac0inv varies inside a zone (no compact form), rho0 detJ0 w is not W[q] s_e (stored mass table, no
+    Kronecker form) - the reference's data makes neither assumption (laghos_solver.cpp:1170-1261, laghos_assembly.cpp:92-95)."""
+
+    def __init__(self, base, amp=0.08, seed=3):
+        self.base = base
+        S, self._rho_l2, self._gamma, self._rho0_q = base.initial_state()
+        rng = np.random.default_rng(seed)
+        h = min(np.min(np.diff(b)) for b in base.breaks) / base.order_v
+        X = S[:base.H1V].reshape(base.dim, base.N).copy()
+        free = np.ones(base.N, dtype=bool)
+        for e in base.ess:                     # boundary nodes stay on the boundary (all of them: simplest)
+            free[np.asarray(e, dtype=np.int64)] = False
+        X[:, free] += amp * h * rng.uniform(-1, 1, (base.dim, int(free.sum())))
+        self._S = np.concatenate([X.reshape(-1), S[base.H1V:]])
+
+    def __getattr__(self, name):
+        return getattr(self.base, name)
+
+    def initial_state(self):
+        # (rho0 at the quadrature points of the moved mesh would be rho0(x_q); problems with constant rho0 - Sedov, Taylor-Green -
+        #  keep their values)
+        return self._S.copy(), self._rho_l2, self._gamma, self._rho0_q

@@ -995,6 +995,10 @@ KERNEL_SWITCHES = [
     ((3, 2), {"LGH_FUSED_INIT": "0"}, "bits"),
     ((3, 2), {"LGH_OVERLAP": "0"}, "bits"),
     ((3, 2), {"LGH_K2_SKIP": "0"}, "bits"),
+    ((3, 2), {"LGH_JAC0_COMPACT": "0"}, "tol"),
+    ((4, 3), {"LGH_JAC0_COMPACT": "0"}, "tol"),
+    ((3, 2), {"LGH_K2_OCC": "4"}, "bits"),
+    ((3, 2), {"LGH_K2_OCC": "6"}, "bits"),
     ((3, 2), {"LGH_FUSED_FTV": "0"}, "tol"),
     ((3, 2), {"LGH_FUSED_F1": "0"}, "tol"),
     ((3, 2), {"LGH_FUSED_FTV": "0", "LGH_FUSED_F1": "0"}, "tol"),
