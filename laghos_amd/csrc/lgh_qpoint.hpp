@@ -87,6 +87,12 @@ __device__ __forceinline__ double qpoint_body(const QArgs &a, const int e, const
 #pragma unroll
    for (int d = 0; d < DIM; d++) { stress[d * DIM + d] = -P; }
    double visc_coeff = 0.0;
+   // stress : grad v, the integrand of ForceMultTranspose at this point (laghos_assembly.cpp:859-872: sum over (c, gd) of
+   // stressJinvT(q, gd, c) d v_c / d xi_gd = (stress Jinv^T) : dV = stress : (dV Jinv) - and the stress is symmetric, so the
+   // symmetrised gradient the viscosity branch holds anyway serves).  Formed where that gradient exists (round 5): dV is
+   // dead from there on - 18 registers less across the eigen-decomposition; the value differs from the other association
+   // of the same sum by round-off only.
+   double s_dot_g;
    if (VISC && a.visc)
    {
       sm::matmul<DIM>(dV, Jinv, sgrad_v);
@@ -135,6 +141,19 @@ __device__ __forceinline__ double qpoint_body(const QArgs &a, const int e, const
       visc_coeff += 0.5 * R * H * S * vorticity_coeff * (1.0 - smooth_step_01(mu - 2.0 * eps, eps));
 #pragma unroll
       for (int k = 0; k < DIM2; k++) { stress[k] += visc_coeff * sgrad_v[k]; }
+      s_dot_g = 0.0;
+#pragma unroll
+      for (int k = 0; k < DIM2; k++) { s_dot_g += stress[k] * sgrad_v[k]; }
+   }
+   else
+   {
+      // no viscosity: stress = -P I, stress : grad v = -P div v, div v = trace(dV Jinv)
+      double divv = 0.0;
+#pragma unroll
+      for (int i = 0; i < DIM; i++)
+#pragma unroll
+         for (int d = 0; d < DIM; d++) { divv += dV[i + DIM * d] * Jinv[d + DIM * i]; }
+      s_dot_g = -P * divv;
    }
    const double sv = sm::min_singular<DIM>(J);
    const double h_min = sv / a.h1order;
@@ -146,14 +165,7 @@ __device__ __forceinline__ double qpoint_body(const QArgs &a, const int e, const
    else if (idt > 0.0) { dt_cand = a.cfl / idt; }
    sm::matmul_abt<DIM>(stress, Jinv, stressJiT);
    const double wd = weight * detJ;
-   // integrand of ForceMultTranspose at this point (laghos_assembly.cpp:859-872): sum over (c, gd) of
-   // stressJinvT(q, gd, c) * d v_c / d xi_gd - the gradient is in registers here, the stress just formed
-   {
-      double acc = 0.0;
-#pragma unroll
-      for (int k = 0; k < DIM2; k++) { acc += stressJiT[k] * dV[k]; }
-      ftv = acc * wd;
-   }
+   ftv = s_dot_g * wd;
 #pragma unroll
    for (int vd = 0; vd < DIM; vd++)
 #pragma unroll
