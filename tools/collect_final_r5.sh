@@ -8,3 +8,5 @@ cp $O/gaps.txt profiles/r5_gpu_idle_gaps.txt
 cp $O/r5_pmc_traffic.json profiles/r5_pmc_traffic.json
 for w in c2 c3 tg; do for k in FETCH_SIZE WRITE_SIZE; do cp $O/${w}_$k.txt profiles/r5_pmc_${w}_$k.txt; done; done
 { tail -3 $O/pytest_gpu.log; tail -2 $O/smoke.log; } > profiles/r5_pytest_gpu_summary.txt
+cp $O/q_pmc.txt profiles/r5_sq_counters.txt
+cp $O/bench_detail.json profiles/r5_bench_detail.json

@@ -8,6 +8,12 @@ rm -rf $O; mkdir -p $O
 bash tools/gpu_pmc_traffic.sh > $O/pmc_traffic.log 2>&1
 cp gpurun_out/pmc_traffic/*.txt $O/ 2>/dev/null
 cp profiles/r5_pmc_traffic.json $O/ 2>/dev/null
+# SQ counters of the quadrature update on the final build (two passes, --kernel-trace only): instructions per wavefront, LDS conflicts
+APP="./laghos_amd/laghos -p 1 -m data/cube01_hex.mesh -rs 4 -ok 3 -ot 2 -ms 3 -pa"
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $O/qa -o a --output-format csv -- $APP > $O/qa.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_WAVES -d $O/qb -o b --output-format csv -- $APP > $O/qb.log 2>&1
+for P in qa qb; do python tools/pmc_summary.py $O/$P qrows_kernel vcg_update_p_k vcg_apply_slab346 >> $O/q_pmc.txt; done
+find $O/qa $O/qb -name "*.csv" -delete
 timeout 1500 python -m pytest tests -q -m gpu > $O/pytest_gpu.log 2>&1; tail -3 $O/pytest_gpu.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; tail -2 $O/smoke.log
 timeout 1200 python bench.py --detail $O/bench_detail.json > $O/bench.json 2> $O/bench.err
