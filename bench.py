@@ -698,7 +698,7 @@ def main():
             time.sleep(2.0)
             if time.time() - progress["t"] > a.watchdog:
                 sys.stderr.write("[bench.py rank %d/%d] no progress for %.0f s in '%s' - a collective probably does not match "
-                                 "across the ranks (try LGH_COMM2=0 LGH_HALO_PIGGYBACK=0); giving up\n" % (rank, world, a.watchdog, progress["where"]))
+                                 "across the ranks (try LGH_COMM2=0, then LGH_RZ_LIMBS=0, then LGH_HALO_PIGGYBACK=0 on every rank); giving up\n" % (rank, world, a.watchdog, progress["where"]))
                 sys.stderr.flush()
                 os._exit(3)
     if world > 1:
