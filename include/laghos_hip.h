@@ -212,6 +212,11 @@ int lgh_solve_energy_end(lgh_ctx *ctx, int *l2_iters);
 /* ---- vector helpers on the context stream (device pointers) */
 int lgh_vec_set(lgh_ctx *ctx, double *y, double a, long n);              /* y = a */
 int lgh_vec_copy(lgh_ctx *ctx, double *y, const double *x, long n);      /* y = x */
+/* z1 = a1 x1 + b1 y and z2 = a2 x2 + b2 y in one pass over y: the two combinations an explicit RK stage forms from the same
+ * increment k (upstream RK4Solver::Step: the next stage state and the running sum of the solution).  The same expressions
+ * as lgh_vec_axpby - the same bits as two calls.  z2 may be x2; z1 and z2 must differ. */
+int lgh_vec_axpby_pair(lgh_ctx *ctx, double *z1, double a1, const double *x1, double b1, double *z2, double a2, const double *x2, double b2,
+                       const double *y, long n);
 int lgh_vec_axpby(lgh_ctx *ctx, double *z, double a, const double *x, double b,
                   const double *y, long n);                                /* z = a x + b y */
 int lgh_vec_dot(lgh_ctx *ctx, const double *x, const double *y, long n, double *result); /* sync */

@@ -70,6 +70,7 @@ SYMBOLS = {
     "lgh_vec_set": (_I, [_P, _P, _D, _L]),
     "lgh_vec_copy": (_I, [_P, _P, _P, _L]),
     "lgh_vec_axpby": (_I, [_P, _P, _D, _P, _D, _P, _L]),
+    "lgh_vec_axpby_pair": (_I, [_P, _P, _D, _P, _D, _P, _D, _P, _D, _P, _L]),
     "lgh_vec_dot": (_I, [_P, _P, _P, _L, c_dbl_p]),
     "lgh_internal_energy": (_I, [_P, _P, c_dbl_p]),
     "lgh_kinetic_energy": (_I, [_P, _P, c_dbl_p]),

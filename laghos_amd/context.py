@@ -365,6 +365,9 @@ class Context:
     def vec_axpby(self, z, a, x, b, y):
         check(self.lib.lgh_vec_axpby(self.h, _ptr(z), a, _ptr(x), b, _ptr(y), z.numel()))
 
+    def vec_axpby_pair(self, z1, a1, x1, b1, z2, a2, x2, b2, y):
+        check(self.lib.lgh_vec_axpby_pair(self.h, _ptr(z1), a1, _ptr(x1), b1, _ptr(z2), a2, _ptr(x2), b2, _ptr(y), z1.numel()))
+
     def vec_copy(self, y, x):
         check(self.lib.lgh_vec_copy(self.h, _ptr(y), _ptr(x), y.numel()))
 

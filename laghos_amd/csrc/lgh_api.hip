@@ -52,6 +52,19 @@ vec_axpby2_k(double2 *z, double a, const double2 *x, double b, const double2 *y,
       z[i] = make_double2(fma(a, x0.x, __dmul_rn(b, y0.x)), fma(a, x0.y, __dmul_rn(b, y0.y)));
    }
 }
+// Two RK stage combinations that share their increment y in one pass (round 5): z1 = a1 x1 + b1 y, z2 = a2 x2 + b2 y with the
+// expressions of vec_axpby2_k - the same bits as two calls; z2 may alias x2 (z += b k), z1 and z2 must not overlap.
+__global__ void __launch_bounds__(256)
+vec_axpby_pair_k(double2 *z1, double a1, const double2 *x1, double b1, double2 *z2, double a2, const double2 *x2, double b2, const double2 *y, long n2)
+{
+   const long stride = (long)gridDim.x * blockDim.x;
+   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n2; i += stride)
+   {
+      const double2 y0 = y[i], p = x1[i], q = x2[i];
+      z1[i] = make_double2(fma(a1, p.x, __dmul_rn(b1, y0.x)), fma(a1, p.y, __dmul_rn(b1, y0.y)));
+      z2[i] = make_double2(fma(a2, q.x, __dmul_rn(b2, y0.x)), fma(a2, q.y, __dmul_rn(b2, y0.y)));
+   }
+}
 __global__ void __launch_bounds__(256) vec_neg_k(double *y, long n)
 {
    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) { y[i] = -y[i]; }
@@ -122,6 +135,28 @@ int vec_axpby(lgh_ctx *c, double *z, double a, const double *x, double b, const 
    else { hipLaunchKernelGGL(vec_axpby_k, dim3(grid_for(n)), dim3(256), 0, c->stream, z, a, x, b, y, n); }
    LGH_HIP_CHECK(hipGetLastError());
    return LGH_OK;
+}
+int vec_axpby_pair(lgh_ctx *c, double *z1, double a1, const double *x1, double b1, double *z2, double a2, const double *x2, double b2,
+                   const double *y, long n)
+{
+   if (n <= 0) { return LGH_OK; }
+   if (n >= 4096 && (((uintptr_t)z1 | (uintptr_t)x1 | (uintptr_t)z2 | (uintptr_t)x2 | (uintptr_t)y) & 15u) == 0)
+   {
+      const long n2 = n / 2;
+      hipLaunchKernelGGL(vec_axpby_pair_k, dim3(grid_for(n2)), dim3(256), 0, c->stream, (double2 *)z1, a1, (const double2 *)x1, b1, (double2 *)z2, a2,
+                         (const double2 *)x2, b2, (const double2 *)y, n2);
+      LGH_HIP_CHECK(hipGetLastError());
+      if (n & 1)
+      {
+         hipLaunchKernelGGL(vec_axpby_k, dim3(1), dim3(64), 0, c->stream, z1 + 2 * n2, a1, x1 + 2 * n2, b1, y + 2 * n2, 1L);
+         hipLaunchKernelGGL(vec_axpby_k, dim3(1), dim3(64), 0, c->stream, z2 + 2 * n2, a2, x2 + 2 * n2, b2, y + 2 * n2, 1L);
+      }
+      LGH_HIP_CHECK(hipGetLastError());
+      return LGH_OK;
+   }
+   int rc = vec_axpby(c, z1, a1, x1, b1, y, n);
+   if (rc) { return rc; }
+   return vec_axpby(c, z2, a2, x2, b2, y, n);
 }
 int vec_neg_inplace(lgh_ctx *c, double *y, long n)
 {
@@ -864,9 +899,38 @@ int lgh_solve_velocity(lgh_ctx *c, const double *S, double *dS_dt, const double 
 // No host look: the comparison leaves a flag, the force kernel returns at once when it is 0, the copy when it is not.
 __global__ void __launch_bounds__(256) vec_differs_k(const double *__restrict__ a, const double *__restrict__ b, const long n, int *flag)
 {
-   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
    // (compared as bit patterns: -0.0 vs 0.0 or a NaN payload count as different - the kernel then simply runs)
-   if (i < n && __double_as_longlong(a[i]) != __double_as_longlong(b[i])) { *flag = 1; }
+   // grid-stride, 16-byte loads where both vectors allow them (round 5: one element per thread reached 2 TB/s at 64^3)
+   const long stride = (long)gridDim.x * blockDim.x, t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+   bool diff = false;
+   if (((((uintptr_t)a) | ((uintptr_t)b)) & 15u) == 0)
+   {
+      const longlong2 *a2 = (const longlong2 *)a, *b2 = (const longlong2 *)b;
+      for (long i = t; i < n / 2; i += stride)
+      {
+         const longlong2 p = a2[i], q = b2[i];
+         diff = diff || p.x != q.x || p.y != q.y;
+      }
+      if ((n & 1) && t == 0) { diff = diff || __double_as_longlong(a[n - 1]) != __double_as_longlong(b[n - 1]); }
+   }
+   else
+   {
+      for (long i = t; i < n; i += stride) { diff = diff || __double_as_longlong(a[i]) != __double_as_longlong(b[i]); }
+   }
+   if (diff) { *flag = 1; }
+}
+// e_rhs = F^T v of the quadrature update unless the velocity differs from the one it was formed for; then (the stress being in
+// registers only) NaN and the error word (rounds 3-4: two launches, poison and copy)
+__global__ void __launch_bounds__(256) erhs_take_or_poison_k(double *__restrict__ y, const double *__restrict__ x, const long n, const int *__restrict__ flag, int *err)
+{
+   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+   if (*flag != 0)
+   {
+      if (i < n) { y[i] = __builtin_nan(""); }
+      if (i == 0) { *err = 1; }
+      return;
+   }
+   if (i < n) { y[i] = x[i]; }
 }
 __global__ void __launch_bounds__(256) copy_unless_k(double *__restrict__ y, const double *__restrict__ x, const long n, const int *__restrict__ flag)
 {
@@ -874,33 +938,26 @@ __global__ void __launch_bounds__(256) copy_unless_k(double *__restrict__ y, con
    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
    if (i < n) { y[i] = x[i]; }
 }
-__global__ void __launch_bounds__(256) poison_if_k(double *y, long n, const int *flag, int *err)
-{
-   if (*flag == 0) { return; }
-   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-   if (i < n) { y[i] = __builtin_nan(""); }
-   if (i == 0) { *err = 1; }
-}
 static int energy_rhs(lgh_ctx *c, const double *v_h1, double *e_rhs)
 {
    if (c->erhs_q && c->fused_ftv_valid)
    {
       int *flag = c->dev_flags + (c->on_stream2 ? 2 : 0);
       LGH_HIP_CHECK(hipMemsetAsync(flag, 0, sizeof(int), c->stream));
-      hipLaunchKernelGGL(vec_differs_k, dim3(ceil_div(c->H1V, 256)), dim3(256), 0, c->stream, v_h1, c->v_snap, (long)c->H1V, flag);
+      hipLaunchKernelGGL(vec_differs_k, dim3(grid_for((c->H1V + 1) / 2)), dim3(256), 0, c->stream, v_h1, c->v_snap, (long)c->H1V, flag);
       LGH_HIP_CHECK(hipGetLastError());
       if (c->stress_current)
       {
          const int rc = force_mult_t_L(c, c->stressJinvT, v_h1, e_rhs, flag); // (runs only for a different v)
          if (rc) { return rc; }
+         hipLaunchKernelGGL(copy_unless_k, dim3(ceil_div(c->L2V, 256)), dim3(256), 0, c->stream, e_rhs, c->erhs_q, (long)c->L2V, flag);
       }
       else
       {
          // the stress was kept in registers: a velocity other than the state's cannot be served - the right-hand side
          // becomes NaN on the device (nothing downstream can look right) and the next lgh_get_dt_est reports it
-         hipLaunchKernelGGL(poison_if_k, dim3(ceil_div(c->L2V, 256)), dim3(256), 0, c->stream, e_rhs, (long)c->L2V, flag, c->dev_flags + 4);
+         hipLaunchKernelGGL(erhs_take_or_poison_k, dim3(ceil_div(c->L2V, 256)), dim3(256), 0, c->stream, e_rhs, c->erhs_q, (long)c->L2V, flag, c->dev_flags + 4);
       }
-      hipLaunchKernelGGL(copy_unless_k, dim3(ceil_div(c->L2V, 256)), dim3(256), 0, c->stream, e_rhs, c->erhs_q, (long)c->L2V, flag);
       LGH_HIP_CHECK(hipGetLastError());
       return LGH_OK;
    }
@@ -1013,6 +1070,12 @@ int lgh_vec_axpby(lgh_ctx *c, double *z, double a, const double *x, double b, co
 {
    LGH_CHECK_ARG(c && z && x && y);
    return vec_axpby(c, z, a, x, b, y, n);
+}
+int lgh_vec_axpby_pair(lgh_ctx *c, double *z1, double a1, const double *x1, double b1, double *z2, double a2, const double *x2, double b2,
+                       const double *y, long n)
+{
+   LGH_CHECK_ARG(c && z1 && x1 && z2 && x2 && y && z1 != z2);
+   return vec_axpby_pair(c, z1, a1, x1, b1, z2, a2, x2, b2, y, n);
 }
 int lgh_vec_dot(lgh_ctx *c, const double *x, const double *y, long n, double *result)
 {

@@ -134,7 +134,7 @@ struct lgh_ctx
    unsigned long qgen;   // counts lgh_qupdate / invalidations (lgh_quadrature_generation)
    int *dev_flags;       // 8 device ints, one owner each: [0] / [2] "v differs from v_snap" of the current lgh_solve_energy (main /
                          // second stream), [1] "x differs from ones" of lgh_force_mult, [3] "mass table is not W[q]*s_e" (mass_data),
-                         // [4] "an energy right-hand side was poisoned" (poison_if_k; read and cleared by lgh_get_dt_est),
+                         // [4] "an energy right-hand side was poisoned" (erhs_take_or_poison_k; read and cleared by lgh_get_dt_est),
                          // [5] "Jac0inv varies inside a zone" (jac0_compact_k, lgh_setup_rho0detj0)
    double *ones_l2;      // L2V ones: the operator's own `one` (laghos_solver.cpp:170-171), allocated on first use
    int stress_store;            // lgh_qupdate_store_stress: 1 (default) = lgh_qupdate writes the nine stressJinvT planes; 0 = the stress stays in registers
@@ -463,6 +463,8 @@ int test_singular(lgh_ctx *c, int dim, int n, const double *A, double *sv);
 int test_sqrt(lgh_ctx *c, int n, const double *x, double *y);
 int vec_set(lgh_ctx *c, double *y, double a, long n);
 int vec_axpby(lgh_ctx *c, double *z, double a, const double *x, double b, const double *y, long n);
+int vec_axpby_pair(lgh_ctx *c, double *z1, double a1, const double *x1, double b1, double *z2, double a2, const double *x2, double b2,
+                   const double *y, long n);
 int vec_neg_inplace(lgh_ctx *c, double *y, long n);
 int vec_zero_list(lgh_ctx *c, double *y, const int *list, int n);
 int vec_dot(lgh_ctx *c, const double *x, const double *y, const double *w, long n, double *dev_out);

@@ -246,6 +246,11 @@ void LagrangianHydroOperator::Add(Vector &z, double a, const Vector &x, double b
 {
    LGH_VERIFY(lgh_vec_axpby(ctx, z.Write(), a, x.Read(), b, y.Read(), z.Size()));
 }
+void LagrangianHydroOperator::Add2(Vector &z1, double a1, const Vector &x1, double b1, Vector &z2, double a2, const Vector &x2, double b2,
+                                   const Vector &y) const
+{
+   LGH_VERIFY(lgh_vec_axpby_pair(ctx, z1.Write(), a1, x1.Read(), b1, z2.Write(), a2, x2.Read(), b2, y.Read(), z1.Size()));
+}
 void LagrangianHydroOperator::Copy(Vector &y, const Vector &x) const
 {
    LGH_VERIFY(lgh_vec_copy(ctx, y.Write(), x.Read(), y.Size()));
@@ -397,15 +402,13 @@ void RK4Solver::Step(Vector &S, double &t, double &dt)
    //   1  |  0    0    1
    // -----+-------------------
    //      | 1/6  1/3  1/3  1/6
+   // (the two combinations of a stage share their increment k: one pass over it - Add2 - with the bits of the two Adds)
    f->Mult(S, k);
-   f->Add(y, 1.0, S, dt / 2, k);
-   f->Add(z, 1.0, S, dt / 6, k);
+   f->Add2(y, 1.0, S, dt / 2, z, 1.0, S, dt / 6, k);
    f->Mult(y, k);
-   f->Add(y, 1.0, S, dt / 2, k);
-   f->Add(z, 1.0, z, dt / 3, k);
+   f->Add2(y, 1.0, S, dt / 2, z, 1.0, z, dt / 3, k);
    f->Mult(y, k);
-   f->Add(y, 1.0, S, dt, k);
-   f->Add(z, 1.0, z, dt / 3, k);
+   f->Add2(y, 1.0, S, dt, z, 1.0, z, dt / 3, k);
    f->Mult(y, k);
    f->Add(S, 1.0, z, dt / 6, k);
    t += dt;

@@ -97,6 +97,8 @@ public:
    double AllReduce(double v, int op) const;
    // z = a x + b y on the context stream
    void Add(Vector &z, double a, const Vector &x, double b, const Vector &y) const;
+   // z1 = a1 x1 + b1 y, z2 = a2 x2 + b2 y: two stage combinations of one increment in one pass (the bits of two Adds)
+   void Add2(Vector &z1, double a1, const Vector &x1, double b1, Vector &z2, double a2, const Vector &x2, double b2, const Vector &y) const;
    void Copy(Vector &y, const Vector &x) const;
    void Sync() const;
 };

@@ -1077,3 +1077,27 @@ def test_kernel_switches(order, switches, claim, monkeypatch):
     assert rel_err(dS[2 * H1V:], dS_o[2 * H1V:]) < (1e-10 if order != (5, 4) else 1e-8)  # (cond ~ 1e6 at order 4)
     if claim == "bits":
         assert np.array_equal(dS, dS_def)
+
+
+@pytest.mark.parametrize("n", [5, 4096, 4097, 1000003])
+def test_vec_axpby_pair_has_the_bits_of_two_axpbys(n):
+    """lgh_vec_axpby_pair (the two combinations an RK stage forms from one increment, in one pass over it) against two
+    lgh_vec_axpby calls: bit for bit, odd lengths and the in-place form z2 = z2 + b k included.  The C++ driver's RK4 uses
+    the pair, the Python driver two calls: test_cpp_driver_matches_python_driver holds whole runs to the same bits."""
+    from oracle.fem import Problem
+    g = make_gpu(Problem(mesh="cube01_hex", rs=0, order_v=2, order_e=1, problem=1))
+    try:
+        S, k, zin = seeded(n, 401), seeded(n, 402), seeded(n, 403)
+        Sd, kd = g.ctx.to_dev(S), g.ctx.to_dev(k)
+        y1, z1 = g.ctx.empty(n), g.ctx.to_dev(zin)
+        y2, z2 = g.ctx.empty(n), g.ctx.to_dev(zin)
+        import torch
+        torch.cuda.synchronize()
+        g.ctx.vec_axpby(y1, 1.0, Sd, 0.37, kd)
+        g.ctx.vec_axpby(z1, 1.0, z1, 0.11, kd)
+        g.ctx.vec_axpby_pair(y2, 1.0, Sd, 0.37, z2, 1.0, z2, 0.11, kd)
+        g.ctx.sync()
+        assert np.array_equal(y1.cpu().numpy(), y2.cpu().numpy()) and np.array_equal(z1.cpu().numpy(), z2.cpu().numpy())
+        assert np.array_equal(y1.cpu().numpy(), 1.0 * S + 0.37 * k) or rel_err(y1.cpu().numpy(), S + 0.37 * k) < 1e-15
+    finally:
+        g.close()
