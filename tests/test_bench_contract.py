@@ -157,3 +157,24 @@ def test_weak_scaling_layout_of_the_bench():
         # holds the Python mirror against the C++ code)
         assert bench.partition_grid((32 * px, 32 * py, 32 * pz), n) == (px, py, pz)
     assert bench.usable_cpus() >= 1
+
+
+def test_line_survives_an_oversized_record():
+    """Whatever a future leg or rank count adds to the record, the stdout line stays parseable: compact_line keeps the
+    per-leg entries to five figures, and main() drops `legs` and `comm` before it would print more than 8 KB (the emergency
+    exit that round 4 did not have).  Here: a record with 200 legs."""
+    bench = _bench()
+    with open(os.path.join(ROOT, "profiles", "r5_bench_detail.json")) as f:
+        full = json.load(f)
+    one = full["legs"]["c3"]
+    full["legs"] = {"leg%03d" % i: one for i in range(200)}
+    line = bench.compact_line(full, "x")
+    text = json.dumps(line, separators=(",", ":"))
+    assert len(text) > bench.LINE_LIMIT            # (this record would not fit ...)
+    for key in ("legs", "comm"):                   # ... and this is what main() does about it
+        line.pop(key, None)
+    text = json.dumps(line, separators=(",", ":"))
+    assert len(text) <= bench.LINE_LIMIT
+    d = json.loads(text)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "roofline", "cpu_baseline", "parity", "config"):
+        assert key in d
