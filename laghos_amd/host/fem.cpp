@@ -5,6 +5,8 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <numeric>
+#include <random>
 #include <stdexcept>
 
 namespace laghos
@@ -598,8 +600,7 @@ void Discretization::InitialState(std::vector<double> &S, std::vector<double> &r
          S[(size_t)H1V + (size_t)a * N + n] = v[a];
       }
    }
-   for (int a = 0; a < dim; a++)
-      for (int n : ess[a]) { S[(size_t)H1V + (size_t)a * N + n] = 0.0; } // laghos.cpp:576-579
+   // (the essential velocity dofs are zeroed at the end: `ess` is in the numbering the operators get, laghos.cpp:576-579)
    // rho0 and e0: nodal L2 interpolation, then projection to Bernstein (laghos.cpp:589-622)
    std::vector<double> glx, glw;
    GaussLegendre(L, glx, glw);
@@ -662,6 +663,242 @@ void Discretization::InitialState(std::vector<double> &S, std::vector<double> &r
          rho0_q[(size_t)e * NQ + q] = rho0(x); // mass coefficient at the qpts
       }
    }
+   if (!node_perm.empty()) // -renumber: the same fields in the numbering Renumber() gave the nodes and zones
+   {
+      std::vector<double> T(S.size());
+      for (int b = 0; b < 2 * dim; b++)
+         for (int n = 0; n < N; n++) { T[(size_t)b * N + node_perm[n]] = S[(size_t)b * N + n]; }
+      auto zones = [&](const double *in, double *out, int per) {
+         for (int j = 0; j < NE; j++) { std::copy(in + (size_t)elem_perm[j] * per, in + (size_t)(elem_perm[j] + 1) * per, out + (size_t)j * per); }
+      };
+      zones(S.data() + 2 * (size_t)H1V, T.data() + 2 * (size_t)H1V, NL);
+      S.swap(T);
+      std::vector<double> r(rho0_l2.size()), g(gamma.size()), rq(rho0_q.size());
+      zones(rho0_l2.data(), r.data(), NL);
+      zones(gamma.data(), g.data(), 1);
+      zones(rho0_q.data(), rq.data(), NQ);
+      rho0_l2.swap(r);
+      gamma.swap(g);
+      rho0_q.swap(rq);
+   }
+   for (int a = 0; a < dim; a++)
+      for (int n : ess[a]) { S[(size_t)H1V + (size_t)a * N + n] = 0.0; } // laghos.cpp:576-579
+}
+
+// ---- renumbering (`-renumber`) ---------------------------------------------------------------------
+namespace
+{
+// MFEM's local numbering of the vertices, edges and faces of a quadrilateral / hexahedron (upstream mesh/geom; the vertex
+// order is the one of the reference's data/*.mesh files, e.g. /root/reference/data/cube01_hex.mesh:17-24)
+const int kVert[8][3] = {{0, 0, 0}, {1, 0, 0}, {1, 1, 0}, {0, 1, 0}, {0, 0, 1}, {1, 0, 1}, {1, 1, 1}, {0, 1, 1}};
+const int kHexEdge[12][2] = {{0, 1}, {1, 2}, {3, 2}, {0, 3}, {4, 5}, {5, 6}, {7, 6}, {4, 7}, {0, 4}, {1, 5}, {2, 6}, {3, 7}};
+const int kHexFace[6][4] = {{3, 2, 1, 0}, {0, 1, 5, 4}, {1, 2, 6, 5}, {2, 3, 7, 6}, {3, 0, 4, 7}, {4, 5, 6, 7}};
+const int kQuadEdge[4][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 0}};
+
+struct Lattice // one int per point of the integer lattice [0, n0] x [0, n1] x [0, n2]
+{
+   int n[3];
+   std::vector<int> v;
+   explicit Lattice(const int m[3])
+   {
+      for (int a = 0; a < 3; a++) { n[a] = m[a]; }
+      v.assign((size_t)(n[0] + 1) * (n[1] + 1) * (n[2] + 1), -1);
+   }
+   int &at(const int c[3]) { return v[c[0] + (size_t)(n[0] + 1) * (c[1] + (size_t)(n[1] + 1) * c[2])]; }
+};
+
+// The numbering MFEM would give `levels` uniform refinements of the lexicographic (nloc >> levels) base mesh with an H1
+// space of order p on it.  Restated from upstream MFEM (none of it is under /root/reference; SURVEY Appendix A style):
+//  * Mesh::UniformRefinement (quad / hex): the 2^dim children of element i become elements 2^dim i + k, child k at the
+//    parent's vertex k, same orientation; old vertices keep their numbers, then one new vertex per edge, per face (3D), per
+//    element, each class in the coarse mesh's numbering of that entity;
+//  * edges and faces are numbered in the order the elements first meet them (element by element, local edge / face order);
+//  * FiniteElementSpace: vertex dofs, then (p-1) per edge running from its lower to its higher vertex, then (p-1)^2 per
+//    face in the frame of the face's vertices as its first element lists them, then (p-1)^dim interior dofs per element.
+// What matters for the kernels is the CHARACTER of that numbering - nodes of a zone scattered over four ranges, zones along
+// a space-filling tree order - not the last detail of the order inside an entity.
+void MfemLikeNumbering(int dim, const int nloc[3], int levels, int p, std::vector<int> &node_perm, std::vector<int> &elem_perm)
+{
+   int g[3] = {0, 0, 0};
+   for (int a = 0; a < dim; a++)
+   {
+      while (levels > 0 && nloc[a] % (1 << levels)) { levels--; } // (a block that is not 2^levels zones wide: fewer levels)
+   }
+   for (int a = 0; a < dim; a++) { g[a] = nloc[a] >> levels; }
+   const int nchild = 1 << dim, nedge = (dim == 3) ? 12 : 4;
+   const int(*edges)[2] = (dim == 3) ? kHexEdge : kQuadEdge;
+   std::vector<std::array<int, 3>> elems;
+   for (int k = 0; k < std::max(g[2], 1); k++)
+      for (int j = 0; j < g[1]; j++)
+         for (int i = 0; i < g[0]; i++) { elems.push_back({i, j, k}); }
+   Lattice vid(g);
+   int nv = 0;
+   for (size_t i = 0; i < vid.v.size(); i++) { vid.v[i] = nv++; }
+   for (int lev = 0; lev < levels; lev++)
+   {
+      int f[3] = {2 * g[0], 2 * g[1], 2 * g[2]};
+      Lattice fv(f);
+      {
+         int c[3];
+         for (c[2] = 0; c[2] <= g[2]; c[2]++)
+            for (c[1] = 0; c[1] <= g[1]; c[1]++)
+               for (c[0] = 0; c[0] <= g[0]; c[0]++)
+               {
+                  int c2[3] = {2 * c[0], 2 * c[1], 2 * c[2]};
+                  fv.at(c2) = vid.at(c);
+               }
+      }
+      for (const auto &e : elems)
+         for (int le = 0; le < nedge; le++)
+         {
+            int m[3];
+            for (int c = 0; c < 3; c++) { m[c] = 2 * e[c] + kVert[edges[le][0]][c] + kVert[edges[le][1]][c]; }
+            if (fv.at(m) < 0) { fv.at(m) = nv++; }
+         }
+      if (dim == 3)
+      {
+         for (const auto &e : elems)
+            for (int lf = 0; lf < 6; lf++)
+            {
+               int m[3];
+               for (int c = 0; c < 3; c++)
+               {
+                  int sum = 0;
+                  for (int k = 0; k < 4; k++) { sum += kVert[kHexFace[lf][k]][c]; }
+                  m[c] = 2 * e[c] + sum / 2;
+               }
+               if (fv.at(m) < 0) { fv.at(m) = nv++; }
+            }
+      }
+      for (const auto &e : elems)
+      {
+         int m[3] = {2 * e[0] + 1, 2 * e[1] + 1, dim == 3 ? 2 * e[2] + 1 : 0};
+         fv.at(m) = nv++;
+      }
+      std::vector<std::array<int, 3>> fine;
+      fine.reserve(elems.size() * nchild);
+      for (const auto &e : elems)
+         for (int k = 0; k < nchild; k++) { fine.push_back({2 * e[0] + kVert[k][0], 2 * e[1] + kVert[k][1], 2 * e[2] + kVert[k][2]}); }
+      elems.swap(fine);
+      vid = fv;
+      for (int a = 0; a < 3; a++) { g[a] = f[a]; }
+   }
+   const int NE = (int)elems.size();
+   elem_perm.resize(NE);
+   for (int j = 0; j < NE; j++) { elem_perm[j] = elems[j][0] + nloc[0] * (elems[j][1] + nloc[1] * elems[j][2]); }
+   // H1 dofs on the lattice of the nodes
+   int P[3] = {g[0] * p, g[1] * p, g[2] * p};
+   Lattice nid(P);
+   {
+      int c[3];
+      for (c[2] = 0; c[2] <= g[2]; c[2]++)
+         for (c[1] = 0; c[1] <= g[1]; c[1]++)
+            for (c[0] = 0; c[0] <= g[0]; c[0]++)
+            {
+               int cp[3] = {p * c[0], p * c[1], p * c[2]};
+               nid.at(cp) = vid.at(c);
+            }
+   }
+   int next = nv;
+   auto vertex = [&](const std::array<int, 3> &e, int k, int out[3]) {
+      for (int c = 0; c < 3; c++) { out[c] = e[c] + kVert[k][c]; }
+   };
+   if (p > 1)
+   {
+      for (const auto &e : elems)
+         for (int le = 0; le < nedge; le++)
+         {
+            int A[3], B[3];
+            vertex(e, edges[le][0], A);
+            vertex(e, edges[le][1], B);
+            if (vid.at(A) > vid.at(B)) { std::swap_ranges(A, A + 3, B); }
+            int c[3];
+            for (int t = 1; t < p; t++)
+            {
+               for (int a = 0; a < 3; a++) { c[a] = p * A[a] + t * (B[a] - A[a]); }
+               if (t == 1 && nid.at(c) >= 0) { break; }
+               nid.at(c) = next++;
+            }
+         }
+      if (dim == 3)
+      {
+         for (const auto &e : elems)
+            for (int lf = 0; lf < 6; lf++)
+            {
+               int A[3], B[3], Dv[3];
+               vertex(e, kHexFace[lf][0], A);
+               vertex(e, kHexFace[lf][1], B);
+               vertex(e, kHexFace[lf][3], Dv);
+               int c[3];
+               bool seen = false;
+               for (int j = 1; j < p && !seen; j++)
+                  for (int i = 1; i < p; i++)
+                  {
+                     for (int a = 0; a < 3; a++) { c[a] = p * A[a] + i * (B[a] - A[a]) + j * (Dv[a] - A[a]); }
+                     if (i == 1 && j == 1 && nid.at(c) >= 0) { seen = true; break; }
+                     nid.at(c) = next++;
+                  }
+            }
+      }
+      for (const auto &e : elems)
+      {
+         int c[3] = {0, 0, 0};
+         for (int k = 1; k < (dim == 3 ? p : 2); k++)
+            for (int j = 1; j < p; j++)
+               for (int i = 1; i < p; i++)
+               {
+                  c[0] = p * e[0] + i;
+                  c[1] = p * e[1] + j;
+                  c[2] = (dim == 3) ? p * e[2] + k : 0;
+                  nid.at(c) = next++;
+               }
+      }
+   }
+   if ((size_t)next != nid.v.size()) { throw std::runtime_error("MfemLikeNumbering: the dof count does not add up"); }
+   node_perm.assign(nid.v.begin(), nid.v.end()); // the lattice is stored x fastest: the structured node order
+   for (int id : node_perm) { if (id < 0) { throw std::runtime_error("MfemLikeNumbering: a node was left without a number"); } }
+}
+} // namespace
+
+void Discretization::Renumber(const std::string &mode, int levels, unsigned seed)
+{
+   if (mode.empty() || mode == "none" || mode == "lexicographic") { return; }
+   if (!node_perm.empty()) { throw std::runtime_error("Discretization::Renumber: already renumbered"); }
+   std::vector<int> np, ep;
+   if (mode == "mfem")
+   {
+      const int nloc[3] = {part.ne[0], part.ne[1], dim == 3 ? part.ne[2] : 0};
+      MfemLikeNumbering(dim, nloc, levels, tab.order_v, np, ep);
+   }
+   else if (mode == "random")
+   {
+      np.resize(N);
+      ep.resize(NE);
+      std::iota(np.begin(), np.end(), 0);
+      std::iota(ep.begin(), ep.end(), 0);
+      std::mt19937_64 rng(seed);
+      std::shuffle(np.begin(), np.end(), rng);
+      std::shuffle(ep.begin(), ep.end(), rng);
+   }
+   else { throw std::runtime_error("-renumber " + mode + ": expected mfem, random or none"); }
+   if ((int)np.size() != N || (int)ep.size() != NE) { throw std::runtime_error("Discretization::Renumber: sizes do not match the block"); }
+   std::vector<int> hm(h1map.size());
+   for (int j = 0; j < NE; j++)
+      for (int k = 0; k < ND; k++) { hm[(size_t)j * ND + k] = np[h1map[(size_t)ep[j] * ND + k]]; }
+   h1map.swap(hm);
+   for (auto &list : ess)
+   {
+      for (int &n : list) { n = np[n]; }
+      std::sort(list.begin(), list.end());
+   }
+   std::vector<double> own(N);
+   for (int n = 0; n < N; n++) { own[np[n]] = owner[n]; }
+   owner.swap(own);
+   for (auto &list : nbr_nodes)
+      for (int &n : list) { n = np[n]; } // (the order of a list is what the two ranks of a pair share: kept)
+   node_perm.swap(np);
+   elem_perm.swap(ep);
+   numbering = mode;
 }
 
 } // namespace laghos

@@ -81,6 +81,11 @@ struct Discretization
    std::vector<int> nbr_rank;
    std::vector<std::vector<int>> nbr_nodes;
    double blast_energy = 1.0;
+   // `-renumber mfem|random` (Renumber below): the numbering a general mesh library hands the operators instead of this
+   // generator's own lexicographic one.  Empty = identity.
+   std::vector<int> node_perm;             // structured node i is node node_perm[i]
+   std::vector<int> elem_perm;             // zone j is the structured zone elem_perm[j]
+   std::string numbering = "lexicographic";
 
    Discretization(const CartMesh &mesh, int order_v, int order_e, int problem, int nranks = 1,
                   int rank = 0, int order_q = -1, double blast_energy = 1.0);
@@ -88,6 +93,14 @@ struct Discretization
    // S = [x | v | e]; rho0 grid function (L2 dofs), gamma per element, rho0 at qpts
    void InitialState(std::vector<double> &S, std::vector<double> &rho0_l2,
                      std::vector<double> &gamma, std::vector<double> &rho0_q) const;
+   // Renumber the H1 nodes and reorder the zones of this rank's block (h1map, ess, owner, nbr_nodes; InitialState follows):
+   //   "mfem":   the numbering MFEM gives `levels` uniform refinements of the lexicographic base mesh (what upstream Laghos
+   //             hands its operators: laghos.cpp:391, laghos_assembly.cpp:133-134) - zones in refinement-tree order (the
+   //             2^dim children of a zone consecutive, in the order of the parent's vertices), H1 dofs as vertices, then
+   //             edge, face (3D) and interior dofs, each class in the order the zones first meet the entity;
+   //   "random": a seeded random permutation of both.
+   // The element-local dof order stays lexicographic: that is the interface (ElementDofOrdering::LEXICOGRAPHIC).
+   void Renumber(const std::string &mode, int levels, unsigned seed = 1);
    bool impose_visc = false; // -iv (laghos.cpp:648)
    bool UseViscosity() const { return impose_visc || (problem != 0 && problem != 4); } // laghos.cpp:636-648
    int SourceType() const { return problem == 7 ? 2 : ((problem == 0 && dim == 2) ? 1 : 0); } // laghos.cpp:636-647

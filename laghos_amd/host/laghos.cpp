@@ -53,6 +53,12 @@ struct Options
    const char *nccl_id = nullptr;
    bool quiet = false;
    bool store_stress = false;      // -store-stress: qdata.stressJinvT written by every update (the reference's behaviour)
+   // -renumber mfem|random|none: hand the operators the mesh in another numbering of its nodes and zones than this
+   // generator's lexicographic one (Discretization::Renumber) - "mfem" is what upstream Laghos passes through
+   // H1.GetElementRestriction (laghos_assembly.cpp:133-134) after its uniform refinements (laghos.cpp:391).  Not a
+   // reference option: the reference has no choice in the matter.
+   std::string renumber = "none";
+   int renumber_seed = 1;
 };
 
 bool ParseArgs(int argc, const char *const *argv, Options &o, std::string &err)
@@ -80,6 +86,7 @@ bool ParseArgs(int argc, const char *const *argv, Options &o, std::string &err)
       OPT_DBL("-tf", "--t-final", t_final) OPT_DBL("-cfl", "--cfl", cfl) OPT_DBL("-cgt", "--cg-tol", cg_tol)
       OPT_INT("-cgm", "--cg-max-steps", cg_max_iter) OPT_INT("-ms", "--max-steps", max_tsteps)
       OPT_INT("-vs", "--visualization-steps", vis_steps) OPT_INT("-dev", "--dev", dev)
+      OPT_INT("-renumber-seed", "--renumber-seed", renumber_seed)
 #undef OPT_INT
 #undef OPT_DBL
       if (a == "-pa" || a == "--partial-assembly") { o.p_assembly = true; continue; }
@@ -96,6 +103,7 @@ bool ParseArgs(int argc, const char *const *argv, Options &o, std::string &err)
       if (a == "-print" || a == "--print") { o.gfprint = true; continue; }
       if (a == "-store-stress" || a == "--store-stress") { o.store_stress = true; continue; }
       if (a == "-no-store-stress" || a == "--no-store-stress") { o.store_stress = false; continue; }
+      if (a == "-renumber" || a == "--renumber") { if (!(v = need(i))) { return false; } o.renumber = v; continue; }
       if (a == "-k" || a == "--outputfilename") { if (!(v = need(i))) { return false; } o.basename = v; continue; }
       if (a == "-d" || a == "--device") { if (!need(i)) { return false; } continue; } // always the HIP path
       if (a == "-no-vis" || a == "--no-visualization" || a == "-no-visit" || a == "-no-print") { continue; }
@@ -284,6 +292,7 @@ laghos_sim *laghos_sim_create(int argc, const char *const *argv, int nranks, int
       o.dim = mesh.dim;
       s->disc.reset(new Discretization(mesh, o.order_v, o.order_e, o.problem, nranks, rank, o.order_q, o.blast_energy));
       s->disc->impose_visc = o.impose_visc;
+      s->disc->Renumber(o.renumber, o.rs_levels + o.rp_levels, (unsigned)o.renumber_seed);
    }
    catch (const std::exception &e)
    {
@@ -515,8 +524,10 @@ struct laghos_host_disc
    std::unique_ptr<Discretization> d;
    std::vector<double> S0, rho0_l2, gamma, rho0_q;
 };
-laghos_host_disc *laghos_host_disc_create(const char *mesh, int rs, int order_v, int order_e, int problem,
-                                          double blast_energy, int nranks, int rank)
+// renumber: NULL / "none", "mfem" or "random" (Discretization::Renumber; kinds 100 / 101 of laghos_host_disc_get then
+// return node_perm / elem_perm)
+laghos_host_disc *laghos_host_disc_create_renumbered(const char *mesh, int rs, int order_v, int order_e, int problem,
+                                                     double blast_energy, int nranks, int rank, const char *renumber, int seed)
 {
    try
    {
@@ -524,6 +535,7 @@ laghos_host_disc *laghos_host_disc_create(const char *mesh, int rs, int order_v,
       for (int l = 0; l < rs; l++) { m.UniformRefinement(); }
       std::unique_ptr<laghos_host_disc> h(new laghos_host_disc());
       h->d.reset(new Discretization(m, order_v, order_e, problem, nranks, rank, -1, blast_energy));
+      if (renumber) { h->d->Renumber(renumber, rs, (unsigned)seed); }
       h->d->InitialState(h->S0, h->rho0_l2, h->gamma, h->rho0_q);
       return h.release();
    }
@@ -532,6 +544,11 @@ laghos_host_disc *laghos_host_disc_create(const char *mesh, int rs, int order_v,
       std::fprintf(stderr, "laghos_host_disc_create: %s\n", e.what());
       return nullptr;
    }
+}
+laghos_host_disc *laghos_host_disc_create(const char *mesh, int rs, int order_v, int order_e, int problem,
+                                          double blast_energy, int nranks, int rank)
+{
+   return laghos_host_disc_create_renumbered(mesh, rs, order_v, order_e, problem, blast_energy, nranks, rank, nullptr, 0);
 }
 void laghos_host_disc_destroy(laghos_host_disc *h) { delete h; }
 long laghos_host_disc_size(laghos_host_disc *h, int kind)
@@ -548,6 +565,8 @@ long laghos_host_disc_size(laghos_host_disc *h, int kind)
       case 8: return (long)d.owner.size();
       case 9: return (long)d.W.size();
       case 10: return (long)d.nbr_rank.size();
+      case 100: return (long)d.node_perm.size();
+      case 101: return (long)d.elem_perm.size();
       default:
          if (kind - 11 < (int)d.nbr_nodes.size()) { return (long)d.nbr_nodes[kind - 11].size(); }
          return -1;
@@ -568,6 +587,8 @@ void laghos_host_disc_get(laghos_host_disc *h, int kind, void *out)
       case 8: cp(d.owner.data(), d.owner.size() * sizeof(double)); break;
       case 9: cp(d.W.data(), d.W.size() * sizeof(double)); break;
       case 10: cp(d.nbr_rank.data(), d.nbr_rank.size() * sizeof(int)); break;
+      case 100: cp(d.node_perm.data(), d.node_perm.size() * sizeof(int)); break;
+      case 101: cp(d.elem_perm.data(), d.elem_perm.size() * sizeof(int)); break;
       default: cp(d.nbr_nodes[kind - 11].data(), d.nbr_nodes[kind - 11].size() * sizeof(int));
    }
 }

@@ -59,6 +59,8 @@ def load():
         L.laghos_host_tables.argtypes = [I, I, P, P, P, P, P, P]
         L.laghos_host_disc_create.restype = P
         L.laghos_host_disc_create.argtypes = [ctypes.c_char_p, I, I, I, I, D, I, I]
+        L.laghos_host_disc_create_renumbered.restype = P
+        L.laghos_host_disc_create_renumbered.argtypes = [ctypes.c_char_p, I, I, I, I, D, I, I, ctypes.c_char_p, I]
         L.laghos_host_disc_destroy.argtypes = [P]
         L.laghos_host_disc_size.restype = Lg
         L.laghos_host_disc_size.argtypes = [P, I]
@@ -168,10 +170,12 @@ def host_tables(order_v, order_e):
     return dict(qpts=qp, qwts=qw, gll=gll, B=B.reshape(D, Q).T, G=G.reshape(D, Q).T, Bl=Bl.reshape(Ld, Q).T)
 
 
-def host_disc(mesh, rs, order_v, order_e, problem, blast_energy=1.0, nranks=1, rank=0):
-    """Arrays of the C++ Discretization for one rank (host only, no GPU)."""
+def host_disc(mesh, rs, order_v, order_e, problem, blast_energy=1.0, nranks=1, rank=0, renumber=None, seed=1):
+    """Arrays of the C++ Discretization for one rank (host only, no GPU); renumber = "mfem" / "random": after
+    Discretization::Renumber (`-renumber`), with node_perm / elem_perm in the result."""
     L = load()
-    h = L.laghos_host_disc_create(mesh.encode(), rs, order_v, order_e, problem, blast_energy, nranks, rank)
+    h = L.laghos_host_disc_create_renumbered(mesh.encode(), rs, order_v, order_e, problem, blast_energy, nranks, rank,
+                                             renumber.encode() if renumber else None, seed)
     if not h:
         raise RuntimeError("laghos_host_disc_create failed")
 
@@ -186,5 +190,6 @@ def host_disc(mesh, rs, order_v, order_e, problem, blast_energy=1.0, nranks=1, r
                ess=[get(5, np.int32), get(6, np.int32), get(7, np.int32)], owner=get(8, np.float64),
                W=get(9, np.float64), nbr_rank=get(10, np.int32))
     out["nbr_nodes"] = [get(11 + k, np.int32) for k in range(len(out["nbr_rank"]))]
+    out["node_perm"], out["elem_perm"] = get(100, np.int32), get(101, np.int32)
     L.laghos_host_disc_destroy(h)
     return out

@@ -223,3 +223,71 @@ def test_owner_and_neighbours_from_group_lists(nranks):
     nn = ctypes.c_int(0)
     assert lib.lgh_groups_to_neighbors(0, 4, 1, ip(one), ip(bad), None, ip(z), ip(z), ow.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
                                        ctypes.byref(nn), ip(z), ip(z), 2, ip(z), 0) != 0
+
+
+RENUMBER_CASES = [("cube01_hex", 2, 3, 2, 1, "mfem"), ("cube01_hex", 1, 2, 1, 0, "mfem"), ("box01_hex", 1, 4, 3, 3, "mfem"),
+                  ("square01_quad", 3, 3, 2, 1, "mfem"), ("rectangle01_quad", 1, 2, 1, 3, "mfem"), ("cube01_hex", 1, 1, 0, 1, "mfem"),
+                  ("cube01_hex", 2, 3, 2, 1, "random"), ("square01_quad", 2, 2, 1, 1, "random")]
+
+
+@pytest.mark.parametrize("mesh,rs,ok,ot,prob,mode", RENUMBER_CASES)
+def test_renumbered_discretization_is_the_same_discrete_problem(mesh, rs, ok, ot, prob, mode):
+    """`-renumber mfem|random` (Discretization::Renumber): node_perm / elem_perm are permutations, and every array of the
+    renumbered discretisation is the structured one seen through them - same zones with the same nodes in the same
+    element-local (lexicographic) order, same boundary nodes, same initial state."""
+    base = host_lib.host_disc(mesh, rs, ok, ot, prob)
+    d = host_lib.host_disc(mesh, rs, ok, ot, prob, renumber=mode, seed=5)
+    N, NE = base["owner"].size, base["gamma"].size
+    ND, NL, NQ = base["h1map"].size // NE, base["rho0_l2"].size // NE, base["rho0_q"].size // NE
+    npm, epm = d["node_perm"].astype(np.int64), d["elem_perm"].astype(np.int64)
+    assert np.array_equal(np.sort(npm), np.arange(N)) and np.array_equal(np.sort(epm), np.arange(NE))
+    assert not np.array_equal(npm, np.arange(N))
+    hb = base["h1map"].reshape(NE, ND)
+    assert np.array_equal(d["h1map"].reshape(NE, ND), npm[hb[epm]])
+    dim = 3 if "hex" in mesh else 2
+    for a in range(dim):
+        assert np.array_equal(d["ess"][a], np.sort(npm[base["ess"][a]]))
+    H1V = dim * N
+    for b in range(2 * dim):
+        assert np.array_equal(d["S0"][b * N:(b + 1) * N][npm], base["S0"][b * N:(b + 1) * N])
+    assert np.array_equal(d["S0"][2 * H1V:].reshape(NE, NL), base["S0"][2 * H1V:].reshape(NE, NL)[epm])
+    assert np.array_equal(d["rho0_l2"].reshape(NE, NL), base["rho0_l2"].reshape(NE, NL)[epm])
+    assert np.array_equal(d["rho0_q"].reshape(NE, NQ), base["rho0_q"].reshape(NE, NQ)[epm])
+    assert np.array_equal(d["gamma"], base["gamma"][epm])
+
+
+def test_mfem_like_numbering_has_the_structure_of_an_mfem_space():
+    """What `-renumber mfem` restates of upstream MFEM (fem.cpp::MfemLikeNumbering): vertex dofs first, then (p-1) per edge,
+    (p-1)^2 per face, (p-1)^3 per zone; the 8 children of a refined zone consecutive, in the order of the parent's vertices
+    (data/cube01_hex.mesh's vertex order); vertices of the base mesh keep their numbers through the refinements."""
+    rs, p = 2, 3
+    d = host_lib.host_disc("cube01_hex", rs, p, 2, 1, renumber="mfem")
+    n = 2 << rs                       # zones per axis
+    nn = n * p + 1
+    NE, ND = n ** 3, (p + 1) ** 3
+    hm = d["h1map"].reshape(NE, ND).astype(np.int64)
+    nvert, nedge, nface = (n + 1) ** 3, 3 * n * (n + 1) ** 2, 3 * n * n * (n + 1)
+    loc = np.arange(ND)
+    dx, dy, dz = loc % 4, (loc // 4) % 4, loc // 16
+    on = ((dx % p == 0).astype(int) + (dy % p == 0) + (dz % p == 0))   # 3: vertex, 2: edge, 1: face, 0: interior
+    lo = {3: 0, 2: nvert, 1: nvert + (p - 1) * nedge, 0: nvert + (p - 1) * nedge + (p - 1) ** 2 * nface}
+    hi = {3: nvert, 2: lo[1], 1: lo[0], 0: nn ** 3}
+    for kind in (3, 2, 1, 0):
+        ids = hm[:, on == kind]
+        assert ids.min() >= lo[kind] and ids.max() < hi[kind], kind
+    # interior dofs: zone j owns a block of (p-1)^3 consecutive numbers, lexicographic inside
+    assert np.array_equal(hm[:, on == 0], lo[0] + (p - 1) ** 3 * np.arange(NE)[:, None] + np.arange((p - 1) ** 3)[None, :])
+    # refinement-tree order: zones 8i .. 8i+7 are the children of one parent at offsets of the hex vertex order
+    ep = d["elem_perm"].astype(np.int64)
+    ex, ey, ez = ep % n, (ep // n) % n, ep // (n * n)
+    vert = np.array([(0, 0, 0), (1, 0, 0), (1, 1, 0), (0, 1, 0), (0, 0, 1), (1, 0, 1), (1, 1, 1), (0, 1, 1)])
+    for k in range(8):
+        assert np.array_equal(ex[k::8] - ex[0::8], np.full(NE // 8, vert[k, 0]))
+        assert np.array_equal(ey[k::8] - ey[0::8], np.full(NE // 8, vert[k, 1]))
+        assert np.array_equal(ez[k::8] - ez[0::8], np.full(NE // 8, vert[k, 2]))
+    assert np.all(ex[0::8] % 2 == 0) and np.all(ey[0::8] % 2 == 0) and np.all(ez[0::8] % 2 == 0)
+    # the 27 vertices of the base mesh keep the numbers 0..26 (lexicographic, as in the mesh file)
+    npm = d["node_perm"].astype(np.int64).reshape(nn, nn, nn)       # [z, y, x]
+    step = p * n // 2
+    base_ids = npm[::step, ::step, ::step].reshape(-1)
+    assert np.array_equal(base_ids, np.arange(27))
