@@ -310,6 +310,24 @@ int lgh_l2_mass_form(lgh_ctx *ctx, int *form, int *compact);
  * (laghos_assembly.cpp:121) inside every operator apply. */
 int lgh_vcg_layout_stats(lgh_ctx *ctx, long out[4]);
 
+/* The order in which the library walks the zones and numbers the nodes of its OWN vectors (the velocity solve's r, d, x,
+ * 1/diag, E-vector and tables; the zone order of lgh_qupdate).  The reference hands its operators whatever numbering the mesh
+ * library has - H1.GetElementRestriction(LEXICOGRAPHIC) of an MFEM space: vertex, edge, face, interior dofs; zones in the
+ * order UniformRefinement leaves them (laghos_assembly.cpp:133-134, laghos.cpp:391) - and only the element-local dof order is
+ * part of the interface.  lgh_create therefore finds the structure itself, from h1_map alone: zones are neighbours along a
+ * local axis when the D1D x D1D nodes of their facing faces coincide position by position; a flood fill gives the zones of a
+ * structured block integer coordinates; zones are then taken row by row and the nodes numbered along those rows.  The
+ * caller's vectors keep the caller's numbering: they are read / written through the permutation once per solve.
+ *   out[0] = 1: the mesh is a set of structured blocks (else the caller's order is kept: general path);
+ *   out[1] = 1: the internal order IS the caller's (nothing is permuted; e.g. a lexicographic Cartesian generator);
+ *   out[2] = connected components; out[3..5] = zones of the first component along its local x, y, z.
+ * LGH_ORDER=0 keeps the caller's order everywhere (A/B).  Replaces nothing in the reference: MFEM's numbering is what it is. */
+int lgh_mesh_order(lgh_ctx *ctx, long out[8]);
+/* The same analysis as a host helper (no GPU, no context; tests, and callers that want to look at the order before they
+ * create a context): zorder[i] = the caller's zone that comes i-th, nnum[n] = internal number of the caller's node n (both
+ * the identity when out[0] == 0 or dim != 3); out as above. */
+int lgh_mesh_order_host(int dim, int NE, int N, int D1D, const int *h1_map, int *zorder, int *nnum, long out[8]);
+
 /* ---- multi-GPU: element blocks per rank, shared H1 nodes summed
  * over RCCL, dot products / dt all-reduced.  unique_id is the 128-byte
  * ncclUniqueId produced by lgh_comm_unique_id on rank 0 and broadcast by the

@@ -249,6 +249,12 @@ class Context:
         check(self.lib.lgh_k1_form(self.h, ctypes.byref(f)))
         return {0: "column", 2: "plane", 4: "slab", 5: "kron"}.get(f.value)
 
+    def mesh_order(self):
+        """lgh_mesh_order: dict(structured, identity, components, extent) - the library's own zone order / node numbering."""
+        o = (ctypes.c_long * 8)()
+        check(self.lib.lgh_mesh_order(self.h, o))
+        return dict(structured=bool(o[0]), identity=bool(o[1]), components=int(o[2]), extent=(int(o[3]), int(o[4]), int(o[5])))
+
     def test_vcg_k1(self, r, d_old, rz, rz_prev, first):
         """One launch of the lockstep solve's K1 (lgh_test_vcg_k1): (E-vector planes [3, NE*ND] tensor, den[3])."""
         y = self.empty(3 * self.NE * self.ND)

@@ -392,6 +392,7 @@ static int create_impl(const lgh_config *cfg, lgh_ctx *c, const int kid)
    LGH_TRY(dev_alloc_copy(&c->gamma, cfg->gamma, (size_t)c->NE));
    const size_t nmap = (size_t)c->NE * c->ND;
    LGH_TRY(dev_alloc_copy(&c->h1map, cfg->h1_map, nmap));
+   LGH_TRY(mesh_order_build(c, cfg->h1_map)); // the library's own zone order and node numbering (lgh_order.hip)
    // transpose of the restriction in CSR form (ascending element order per node)
    {
       std::vector<int> off((size_t)c->N + 1, 0), idx(nmap);
@@ -509,6 +510,7 @@ int lgh_destroy(lgh_ctx *c)
    }
    cg_l2_free(c);
    vcg_free(c);
+   mesh_order_free(c);
    if (c->stream2)
    {
       (void)hipStreamSynchronize(c->stream2);
@@ -616,6 +618,7 @@ double *lgh_qdata_rho0DetJ0w(lgh_ctx *c) { return c->rho0DetJ0w; }
 double *lgh_mass_D(lgh_ctx *c)
 {
    c->mass_rank1 = -1; // (the caller may write through this pointer: the compact form of the mass data is looked for again)
+   c->mass_gen++;
    return c->massD;
 }
 int lgh_mass_data_form(lgh_ctx *c, int *form)
@@ -632,6 +635,7 @@ int lgh_mass_data_changed(lgh_ctx *c)
 {
    LGH_CHECK_ARG(c);
    c->mass_rank1 = -1;            // the compact form is looked for again at the next mass apply
+   c->mass_gen++;
    return mass_assemble_diag(c);  // operator and Jacobi preconditioner stay consistent (laghos_solver.cpp:266-270)
 }
 double *lgh_mass_diag(lgh_ctx *c) { return c->diagV; }
@@ -670,6 +674,7 @@ int lgh_setup_rho0detj0(lgh_ctx *c, const double *x0, const double *rho0_l2, con
    LGH_CHECK_ARG(c && x0 && rho0_l2 && rho0_q && volume);
    invalidate_fused(c);
    c->mass_rank1 = -1; // (new mass data)
+   c->mass_gen++;
    int rc = setup_rho0detj0(c, x0, rho0_l2, rho0_q, volume);
    if (rc) { return rc; }
    return mass_assemble_diag(c);

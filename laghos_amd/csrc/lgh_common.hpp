@@ -72,6 +72,19 @@ struct KTime
 
 struct Comm; // RCCL state (lgh_comm.hip)
 
+// The library's own order of the zones and numbering of the nodes (lgh_order.hip): found from the element -> node map at
+// lgh_create by face adjacency, nothing about the caller's numbering is assumed.  identity: the caller's order already is
+// that order (or no structured block was found, or LGH_ORDER=0) - nothing is permuted anywhere.
+struct MeshOrder
+{
+   bool structured = false, identity = true;
+   int components = 0, extent[3] = {0, 0, 0};
+   std::vector<int> zorder;   // internal zone i is the caller's zone zorder[i]
+   std::vector<int> nnum;     // the caller's node n is internal node nnum[n]
+   std::vector<int> ncaller;  // internal node m is the caller's node ncaller[m]
+   int *zorder_d = nullptr, *ncaller_d = nullptr, *nnum_d = nullptr; // the same on the device (nullptr when identity)
+};
+
 } // namespace lgh
 
 struct lgh_ctx
@@ -170,6 +183,8 @@ struct lgh_ctx
    lgh::Comm *comm;
    int nranks, rank;
    int multi;            // 1: run the multi-rank code path (nranks > 1, or LGH_FORCE_MULTI=1 for testing on one GPU)
+   void *order;          // lgh::MeshOrder (lgh_order.hip)
+   unsigned long mass_gen; // counts changes of the mass data / Jacobi diagonal (the velocity solve keeps copies in its own numbering)
 };
 
 namespace lgh
@@ -414,6 +429,20 @@ __device__ __forceinline__ int xcd_swizzle(const int b, const int nblocks)
 }
 
 inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---- lgh_order.hip
+int mesh_order_build(lgh_ctx *c, const int *map_host);
+void mesh_order_free(lgh_ctx *c);
+// the internal order when it differs from the caller's, else nullptr
+inline const MeshOrder *mesh_order(const lgh_ctx *c)
+{
+   const MeshOrder *o = (const MeshOrder *)c->order;
+   return (o && !o->identity) ? o : nullptr;
+}
+int order_gather_nodes(lgh_ctx *c, const double *in, double *out, int ncomp);  // out[k N + m] = in[k N + ncaller[m]]
+int order_scatter_nodes(lgh_ctx *c, const double *in, double *out, int ncomp); // out[k N + ncaller[m]] = in[k N + m]
+int order_gather_bytes(lgh_ctx *c, const uint8_t *in, uint8_t *out);
+int order_zone_blocks(lgh_ctx *c, const double *in, double *out, int per, bool to_caller); // blocks of `per` doubles per zone
 
 // ---- cross-TU launch helpers (implemented in the .hip files) ------------------
 int force_mult_E(lgh_ctx *c, const double *sJit, const double *xE, double *yE);

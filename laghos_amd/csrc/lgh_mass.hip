@@ -1037,6 +1037,7 @@ int mass_assemble_diag(lgh_ctx *c)
    hipLaunchKernelGGL(reciprocal_k, dim3(ceil_div(c->N, 256)), dim3(256), 0, c->stream, c->N,
                       c->diagV, c->dinvV);
    LGH_HIP_CHECK(hipGetLastError());
+   c->mass_gen++; // (the velocity solve keeps 1/diag in its own node numbering: lgh_vcg.hip)
    return LGH_OK;
 }
 

@@ -50,6 +50,8 @@ struct QArgs
    double *force_e;  // update mode (3D): F.1 as E-vector (D1D^3, dim, NE), or nullptr (see below)
    double *erhs_q;   // update mode: F^T v of the SAME state (the velocity block of S), L2 vector, or nullptr (see below)
    int q_swz;        // row form of the update (lgh_qrows.hpp): element -> XCD mapping
+   const int *zorder; // row form of the update: workgroup i takes the caller's zone zorder[i] - the library's own zone order (lgh_order.hip:
+                      // neighbours close on one XCD whatever order the caller numbers its zones in); nullptr: zone i
    double tiny_grad; // wave-uniform shortcut of the eigen-decomposition below this |sym grad v| (see qpoint_body); < 0: off
 };
 
@@ -897,6 +899,10 @@ static QArgs q_base(lgh_ctx *c)
    }
    a.erhs_q = c->fused_forces_off ? nullptr : c->erhs_q;
    a.force_e = (c->dim == 3 && !c->fused_forces_off) ? c->force_e_q : nullptr;
+   {
+      const MeshOrder *o = mesh_order(c);
+      a.zorder = o ? o->zorder_d : nullptr;
+   }
    return a;
 }
 

@@ -126,6 +126,8 @@ qrows_kernel(const QArgs a, unsigned long long *trace = nullptr)
       const int R = 1 << a.q_swz, span = 8 * R, b = blockIdx.x;
       if (b < (int)(gridDim.x / span) * span) { e = (b / span) * span + (b & 7) * R + ((b >> 3) & (R - 1)); }
    }
+   // (the zones are walked in the library's own order; every per-zone array is the caller's and is read / written at the caller's place)
+   if (a.zorder) { e = __builtin_amdgcn_readfirstlane(a.zorder[min(e, a.NE - 1)]); }
    const size_t eq = (size_t)e * NQ + lt;
    const size_t plane = (size_t)a.NE * NQ;
 

@@ -956,7 +956,7 @@ vcg_init_k(const VcgArgs a)
       for (int c = 0; c < kVC; c++)
       {
          const size_t i = (size_t)c * a.N + n;
-         const double rv = a.b[i];
+         const double rv = a.b[(size_t)c * a.N + (a.ncaller ? a.ncaller[n] : n)]; // (b is the caller's vector)
          a.r[i] = rv;
          part[c] = ow * __dmul_rn(rv, di) * rv; // z = r/diag is recomputed where it is used
       }
@@ -990,9 +990,11 @@ vcg_init_k(const VcgArgs a)
 // the force E-vector in the reference layout (D1D^3, dim, NE) (laghos_assembly.cpp:312); the sum
 // runs in the order of h1_transpose_gather_k, so b has the bits of the separate
 // gather / negate / EliminateRHS kernels it replaces (four passes over the vectors less).
+// ellc: the transpose of the restriction for the FORCE E-vector (slot j of node n at j * N + n), which is in the caller's zone
+// order whatever order the solve's own E-vector has
 template <int DEG>
 __global__ void __launch_bounds__(256)
-vcg_init_force_k(const VcgArgs a, const double *__restrict__ FE, const int ND, double *__restrict__ bout)
+vcg_init_force_k(const VcgArgs a, const double *__restrict__ FE, const int ND, double *__restrict__ bout, const int *__restrict__ ellc, const int degc)
 {
    __shared__ double red[48];
    const int n = xcd_swizzle(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x; // node ranges of vcg_init_k: same partial sums
@@ -1003,7 +1005,7 @@ vcg_init_force_k(const VcgArgs a, const double *__restrict__ FE, const int ND, d
 #pragma unroll
       for (int j = 0; j < DEG; j++)
       {
-         const int p = (j < a.deg) ? a.ell[(size_t)j * a.N + n] : -1; // e*ND + d
+         const int p = (j < degc) ? ellc[(size_t)j * a.N + n] : -1; // e*ND + d
          const int e = p / ND;
          pos[j] = (p >= 0) ? (long)kVC * ND * e + (p - e * ND) : -1;
       }
@@ -1017,7 +1019,7 @@ vcg_init_force_k(const VcgArgs a, const double *__restrict__ FE, const int ND, d
          double bv = -s;
          if (a.ess[c] && a.ess[c][n]) { bv = 0.0; }
          const size_t i = (size_t)c * a.N + n;
-         bout[i] = bv;
+         bout[(size_t)c * a.N + (a.ncaller ? a.ncaller[n] : n)] = bv; // (the caller's vector)
          a.r[i] = bv;
          a.x[i] = 0.0;
          part[c] = __dmul_rn(bv, di) * bv;
@@ -1090,7 +1092,7 @@ vcg_init_force_z_k(const VcgArgs a, const double *__restrict__ FE, const unsigne
       if (ok)
       {
          const size_t i = (size_t)c * a.N + n;
-         bout[i] = bv;
+         bout[(size_t)c * a.N + (a.ncaller ? a.ncaller[n] : n)] = bv; // (the caller's vector)
          a.r[i] = bv;
          a.x[i] = 0.0;
       }
@@ -1638,6 +1640,23 @@ vcg_xfix_k(const VcgArgs a)
    }
 }
 
+// The solve ran in the library's own node numbering (a.ncaller): its solution goes to the caller's vector, with the pending
+// update of vcg_xfix_k applied on the way (the same fma: the same bits as fix, then copy)
+__global__ void __launch_bounds__(256)
+vcg_xout_k(const VcgArgs a, double *__restrict__ X)
+{
+   const int n = blockIdx.x * blockDim.x + threadIdx.x;
+   if (n >= a.N) { return; }
+   const int nc = a.ncaller[n];
+   for (int k = 0; k < kVC; k++)
+   {
+      const size_t i = (size_t)k * a.N + n;
+      double xv = a.x[i];
+      if (a.s->nupd[k] & 1) { xv = fma(a.s->alpha_last[k], a.d[i], xv); }
+      X[(size_t)k * a.N + nc] = xv;
+   }
+}
+
 // unfused E -> L sum of the kVC planes (multi-GPU path, unusual valence)
 __global__ void __launch_bounds__(256)
 vcg_gather_k(const VcgArgs a)
@@ -1811,13 +1830,18 @@ struct SlabLayout
    std::vector<uint8_t> sec;
    size_t n_merged = 0;
 };
+// (the map of the order the solve runs in: the caller's, or the library's own - vcg_view_map)
+static int vcg_view_map(lgh_ctx *c, std::vector<int> &map);
 static int slab_merge_layout(lgh_ctx *c, SlabLayout &L)
 {
    constexpr int ES = 5, D = 4, ND = 64;
    if (c->D1D != D || c->dim != 3) { set_error("slab_merge_layout: Q3 only"); return LGH_ERR_UNSUPPORTED; }
    const int NE = c->NE, nset = ceil_div(NE, ES);
-   std::vector<int> map((size_t)NE * ND);
-   LGH_HIP_CHECK(hipMemcpy(map.data(), c->h1map, map.size() * sizeof(int), hipMemcpyDeviceToHost));
+   std::vector<int> map;
+   {
+      const int rc = vcg_view_map(c, map);
+      if (rc) { return rc; }
+   }
    L.settab.assign((size_t)nset, 0u);
    L.pos.assign((size_t)NE * ND, 0);
    L.sec.assign((size_t)NE * ND, 0);
@@ -1884,7 +1908,26 @@ struct VcgAux
    int degm = 0;
    unsigned *ellzm = nullptr;
    int *nstartm = nullptr;
+   // The library's own order (lgh_order.hip), when it differs from the caller's: the tables and vectors of the solve in the
+   // internal zone order / node numbering - everything the kernels see comes from here then, the context's own tables (the
+   // caller's numbering) serve every other entry point.  ord == nullptr: the caller's order is the solve's.
+   const MeshOrder *ord = nullptr;
+   int *o_map = nullptr;       // NE*ND: internal node of (internal zone, local dof)
+   int *o_ell = nullptr;       // t_deg*N: transpose of o_map, E-positions of the solve's own E-vector (internal zone order)
+   int *o_ellc = nullptr;      // t_deg*N: per internal node, the positions in an E-vector of the CALLER's zone order (the force E-vector)
+   std::vector<int> o_valence; // contributions per internal node
+   uint8_t *o_ess[kVC] = {nullptr, nullptr, nullptr};
+   double *o_dinv = nullptr, *o_Se = nullptr, *o_massD = nullptr;
+   double *o_x = nullptr;      // kVC*N: the solution in internal numbering (vcg_xout_k hands it to the caller)
+   unsigned long o_mass_gen = ~0ul; // c->mass_gen the copies above were taken at
 };
+static int vcg_view_map(lgh_ctx *c, std::vector<int> &map)
+{
+   map.resize((size_t)c->NE * c->ND);
+   const VcgAux *x = (const VcgAux *)c->vcg_aux;
+   LGH_HIP_CHECK(hipMemcpy(map.data(), (x && x->o_map) ? x->o_map : c->h1map, map.size() * sizeof(int), hipMemcpyDeviceToHost));
+   return LGH_OK;
+}
 void vcg_free(lgh_ctx *c)
 {
    VcgAux *x = (VcgAux *)c->vcg_aux;
@@ -1901,6 +1944,14 @@ void vcg_free(lgh_ctx *c)
    (void)hipFree(x->mapb);
    (void)hipFree(x->limbs);
    (void)hipFree(x->rzl);
+   (void)hipFree(x->o_map);
+   (void)hipFree(x->o_ell);
+   (void)hipFree(x->o_ellc);
+   for (int k = 0; k < kVC; k++) { (void)hipFree(x->o_ess[k]); }
+   (void)hipFree(x->o_dinv);
+   (void)hipFree(x->o_Se);
+   (void)hipFree(x->o_massD);
+   (void)hipFree(x->o_x);
    delete x;
    c->vcg_aux = nullptr;
 }
@@ -2032,7 +2083,7 @@ static int vcg_build_merged_tables(lgh_ctx *c, VcgAux *x)
    const size_t N = (size_t)c->N;
    const int deg = c->t_deg;
    std::vector<int> ell((size_t)deg * N), ellm((size_t)8 * N, -1), val(N, 0);
-   LGH_HIP_CHECK(hipMemcpy(ell.data(), c->t_ell, ell.size() * sizeof(int), hipMemcpyDeviceToHost));
+   LGH_HIP_CHECK(hipMemcpy(ell.data(), x->o_ell ? x->o_ell : c->t_ell, ell.size() * sizeof(int), hipMemcpyDeviceToHost));
    int degm = 0;
    for (size_t n = 0; n < N; n++)
    {
@@ -2055,6 +2106,70 @@ static int vcg_build_merged_tables(lgh_ctx *c, VcgAux *x)
    rc = make_ellz(c, &x->ellzm, x->ellm, 8);
    if (rc) { return rc; }
    return partition_nodes_by_cost(c, x->grid2, &x->nstartm, &val);
+}
+
+// The order the lockstep solve runs in: the library's own (lgh_order.hip) unless it is the caller's anyway.  Several ranks:
+// the exchange tables of lgh_comm.hip (shared-node lists, pack / combine positions) are in the caller's numbering and the
+// solve follows them - the caller's order is kept there.
+static const MeshOrder *vcg_order_for(const lgh_ctx *c)
+{
+   if (c->multi != 0) { return nullptr; }
+   return mesh_order(c);
+}
+// Tables and vectors of the solve in the internal order (VcgAux::o_*): the element -> node map (internal zone i, internal
+// node numbers), its transpose for the solve's own E-vector and for an E-vector in the caller's zone order, essential masks,
+// room for 1/diag, the mass data and the solution.
+static int vcg_build_internal_tables(lgh_ctx *c, VcgAux *x)
+{
+   const MeshOrder *o = x->ord;
+   const size_t N = (size_t)c->N, NE = (size_t)c->NE, ND = (size_t)c->ND, nmap = NE * ND;
+   const int deg = c->t_deg;
+   std::vector<int> hm(nmap), om(nmap);
+   LGH_HIP_CHECK(hipMemcpy(hm.data(), c->h1map, nmap * sizeof(int), hipMemcpyDeviceToHost));
+   for (size_t i = 0; i < NE; i++)
+   {
+      const size_t e = (size_t)o->zorder[i];
+      for (size_t d = 0; d < ND; d++) { om[i * ND + d] = o->nnum[hm[e * ND + d]]; }
+   }
+   LGH_HIP_CHECK(hipMalloc((void **)&x->o_map, nmap * sizeof(int)));
+   LGH_HIP_CHECK(hipMemcpy(x->o_map, om.data(), nmap * sizeof(int), hipMemcpyHostToDevice));
+   // transpose, ascending E-position per node (as lgh_create builds the caller's)
+   std::vector<int> off(N + 1, 0);
+   for (size_t i = 0; i < nmap; i++) { off[(size_t)om[i] + 1]++; }
+   x->o_valence.assign(N, 0);
+   for (size_t n = 0; n < N; n++) { x->o_valence[n] = off[n + 1]; off[n + 1] += off[n]; }
+   std::vector<int> pos(off.begin(), off.end() - 1), ell((size_t)deg * N, -1);
+   for (size_t i = 0; i < nmap; i++)
+   {
+      const size_t n = (size_t)om[i];
+      const int k = pos[n]++ - off[n];
+      if (k >= deg) { set_error("vcg_build_internal_tables: valence above the mesh's"); return LGH_ERR_ARG; }
+      ell[(size_t)k * N + n] = (int)i;
+   }
+   LGH_HIP_CHECK(hipMalloc((void **)&x->o_ell, ell.size() * sizeof(int)));
+   LGH_HIP_CHECK(hipMemcpy(x->o_ell, ell.data(), ell.size() * sizeof(int), hipMemcpyHostToDevice));
+   // the caller's transpose, rows taken in internal node order: positions in an E-vector of the CALLER's zone order, in the
+   // caller's (ascending) order of contributions - the right-hand side has the bits of the unfused E -> L sum
+   std::vector<int> tell((size_t)deg * N);
+   LGH_HIP_CHECK(hipMemcpy(tell.data(), c->t_ell, tell.size() * sizeof(int), hipMemcpyDeviceToHost));
+   for (int k = 0; k < deg; k++)
+      for (size_t m = 0; m < N; m++) { ell[(size_t)k * N + m] = tell[(size_t)k * N + (size_t)o->ncaller[m]]; }
+   LGH_HIP_CHECK(hipMalloc((void **)&x->o_ellc, ell.size() * sizeof(int)));
+   LGH_HIP_CHECK(hipMemcpy(x->o_ellc, ell.data(), ell.size() * sizeof(int), hipMemcpyHostToDevice));
+   for (int k = 0; k < kVC; k++)
+   {
+      if (!c->essmask[k]) { continue; }
+      LGH_HIP_CHECK(hipMalloc((void **)&x->o_ess[k], N));
+      const int rc = order_gather_bytes(c, c->essmask[k], x->o_ess[k]);
+      if (rc) { return rc; }
+   }
+   LGH_HIP_CHECK(hipMalloc((void **)&x->o_dinv, N * sizeof(double)));
+   LGH_HIP_CHECK(hipMalloc((void **)&x->o_Se, NE * sizeof(double)));
+   LGH_HIP_CHECK(hipMalloc((void **)&x->o_x, kVC * N * sizeof(double)));
+   LGH_HIP_CHECK(hipMemset(x->o_x, 0, kVC * N * sizeof(double)));
+   LGH_HIP_CHECK(hipStreamSynchronize(c->stream));
+   x->o_mass_gen = ~0ul;
+   return LGH_OK;
 }
 
 static int vcg_prepare(lgh_ctx *c, double *B, double *X, double rel_tol, VcgPlan &plan)
@@ -2086,6 +2201,16 @@ static int vcg_prepare(lgh_ctx *c, double *B, double *X, double rel_tol, VcgPlan
       const size_t ye_n = (size_t)kVC * ((size_t)c->NE * c->ND + kYePad);
       LGH_HIP_CHECK(hipMalloc((void **)&x->ye, ye_n * sizeof(double)));
       LGH_HIP_CHECK(hipMemset(x->ye, 0, ye_n * sizeof(double)));
+      // The library's own order of zones and nodes (lgh_order.hip), when the caller's is another one: the solve's tables are
+      // built for THAT order.  (Several ranks: the exchange tables of lgh_comm.hip are in the caller's numbering - see
+      // vcg_order_for.)
+      x->ord = vcg_order_for(c);
+      if (x->ord)
+      {
+         rc = vcg_build_internal_tables(c, x);
+         if (rc) { return rc; }
+      }
+      const int *v_map = x->o_map ? x->o_map : c->h1map;
       if (c->t_deg <= 8 && (size_t)c->N * 8 * kVC < 0xffffffffull && ((size_t)c->NE * c->ND + kYePad) * 8 < 0xffffffffull)
       {
          int ncu = 256;
@@ -2098,17 +2223,30 @@ static int vcg_prepare(lgh_ctx *c, double *B, double *X, double rel_tol, VcgPlan
          if (genv && atoi(genv) > 0) { x->grid2 = atoi(genv) * ncu; }
          else { x->grid2 = (int)std::max<long>(4L * ncu, (((long)c->N + 1023) / 1024 + 7) & ~7L); }
          x->grid2 = std::min<long>(x->grid2, (long)c->vcg_stride - (long)kShards); // (one partial per workgroup in a reduction slot)
-         rc = make_ellz(c, &x->ellz, nullptr, 0);
+         rc = make_ellz(c, &x->ellz, x->o_ell, x->o_ell ? c->t_deg : 0);
          if (rc) { return rc; }
          rc = make_essbits(c, &x->essbits);
          if (rc) { return rc; }
-         rc = partition_nodes_by_cost(c, x->grid2, &x->nstart, nullptr);
+         if (x->ord)
+         {
+            // (the flag bytes were built from the caller's masks: into the internal numbering)
+            uint8_t *tmp = nullptr;
+            LGH_HIP_CHECK(hipMalloc((void **)&tmp, (size_t)c->N));
+            LGH_HIP_CHECK(hipStreamSynchronize(nullptr));
+            rc = order_gather_bytes(c, x->essbits, tmp);
+            if (rc) { (void)hipFree(tmp); return rc; }
+            LGH_HIP_CHECK(hipStreamSynchronize(c->stream));
+            (void)hipFree(x->essbits);
+            x->essbits = tmp;
+         }
+         rc = partition_nodes_by_cost(c, x->grid2, &x->nstart, x->ord ? &x->o_valence : nullptr);
          if (rc) { return rc; }
          if ((size_t)kVC * (c->NE + 1) * c->ND * 8 < 0xffffffffull)
          {
+            // (the FORCE E-vector is in the caller's zone order: o_ellc)
             const size_t ell_n = (size_t)8 * c->N;
             LGH_HIP_CHECK(hipMalloc((void **)&x->ellf, ell_n * sizeof(unsigned)));
-            hipLaunchKernelGGL(vcg_ellf_k, dim3((unsigned)((ell_n + 255) / 256)), dim3(256), 0, nullptr, c->t_ell, x->ellf,
+            hipLaunchKernelGGL(vcg_ellf_k, dim3((unsigned)((ell_n + 255) / 256)), dim3(256), 0, nullptr, x->o_ellc ? x->o_ellc : c->t_ell, x->ellf,
                                (size_t)c->t_deg * c->N, ell_n, c->ND, c->NE);
             LGH_HIP_CHECK(hipGetLastError());
          }
@@ -2117,11 +2255,11 @@ static int vcg_prepare(lgh_ctx *c, double *B, double *X, double rel_tol, VcgPlan
       {
          const size_t nm = (size_t)c->NE * c->ND;
          LGH_HIP_CHECK(hipMalloc((void **)&x->mapb, nm * sizeof(unsigned)));
-         hipLaunchKernelGGL(vcg_mapb_k, dim3((unsigned)((nm + 255) / 256)), dim3(256), 0, nullptr, c->h1map, x->mapb, nm);
+         hipLaunchKernelGGL(vcg_mapb_k, dim3((unsigned)((nm + 255) / 256)), dim3(256), 0, nullptr, v_map, x->mapb, nm);
          LGH_HIP_CHECK(hipGetLastError());
          int *flag = (int *)c->scal, h = 1;
          LGH_HIP_CHECK(hipMemset(flag, 0, sizeof(int)));
-         hipLaunchKernelGGL(vcg_map_xrows_k, dim3((unsigned)((nm / c->D1D + 255) / 256)), dim3(256), 0, nullptr, c->h1map, nm / c->D1D, c->D1D, flag);
+         hipLaunchKernelGGL(vcg_map_xrows_k, dim3((unsigned)((nm / c->D1D + 255) / 256)), dim3(256), 0, nullptr, v_map, nm / c->D1D, c->D1D, flag);
          LGH_HIP_CHECK(hipMemcpy(&h, flag, sizeof(int), hipMemcpyDeviceToHost));
          x->map_xrows = (h == 0) ? 1 : 0;
          LGH_HIP_CHECK(hipMalloc((void **)&x->limbs, (2 * kLimbWords + 8 * 16 + 32 * 4096) * sizeof(long long)));
@@ -2195,6 +2333,35 @@ static int vcg_prepare(lgh_ctx *c, double *B, double *X, double rel_tol, VcgPlan
    a.owner = multi ? c->owner : nullptr;
    a.b = B;
    a.x = X;
+   if (aux->ord)
+   {
+      // the library's own order: per-zone and per-node data of the context through the permutation (copies, refreshed when
+      // the mass data or the Jacobi diagonal have changed since they were taken)
+      const bool need_table = a.dqs != 0 || k1form == 0; // (the column form of K1 reads the stored table whatever the compact form says)
+      if (aux->o_mass_gen != c->mass_gen)
+      {
+         rc = order_gather_nodes(c, c->dinvV, aux->o_dinv, 1);
+         if (rc) { return rc; }
+         if (a.dqs == 0) { rc = order_zone_blocks(c, a.Se, aux->o_Se, 1, false); }
+         if (rc) { return rc; }
+         if (need_table)
+         {
+            if (!aux->o_massD) { LGH_HIP_CHECK(hipMalloc((void **)&aux->o_massD, ((size_t)c->NE * c->NQ + 2048) * sizeof(double))); LGH_HIP_CHECK(hipMemset(aux->o_massD, 0, ((size_t)c->NE * c->NQ + 2048) * sizeof(double))); }
+            rc = order_zone_blocks(c, c->massD, aux->o_massD, c->NQ, false);
+            if (rc) { return rc; }
+         }
+         aux->o_mass_gen = c->mass_gen;
+      }
+      if (a.dqs == 0) { a.Se = aux->o_Se; }
+      else { a.Dq = aux->o_massD; } // (a.Se: ones)
+      a.DqFull = need_table ? aux->o_massD : nullptr;
+      a.map = aux->o_map;
+      a.ell = aux->o_ell;
+      for (int k = 0; k < kVC; k++) { a.ess[k] = aux->o_ess[k]; }
+      a.dinv = aux->o_dinv;
+      a.ncaller = aux->ord->ncaller_d;
+      a.x = aux->o_x;
+   }
    a.r = c->vcg_vec;
    a.d = c->vcg_vec + kVC * N;
    a.yL = c->vcg_vec + 2 * kVC * N;
@@ -2346,9 +2513,13 @@ int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
       {
          hipLaunchKernelGGL(vcg_init_force_z_k, dim3(nb), dim3(256), 0, c->stream, a, force_E, 8u * (unsigned)c->ND, aux->ellf, B);
       }
-      else { hipLaunchKernelGGL(vcg_init_force_k<8>, dim3(nb), dim3(256), 0, c->stream, a, force_E, c->ND, B); }
+      else { hipLaunchKernelGGL(vcg_init_force_k<8>, dim3(nb), dim3(256), 0, c->stream, a, force_E, c->ND, B, aux->o_ellc ? aux->o_ellc : c->t_ell, c->t_deg); }
    }
-   else { hipLaunchKernelGGL(vcg_init_k, dim3(nb), dim3(256), 0, c->stream, a); }
+   else
+   {
+      if (aux->ord) { LGH_HIP_CHECK(hipMemsetAsync(a.x, 0, kVC * N * sizeof(double), c->stream)); } // (X = 0 on entry: the solve's own copy as well)
+      hipLaunchKernelGGL(vcg_init_k, dim3(nb), dim3(256), 0, c->stream, a);
+   }
    LGH_HIP_CHECK(hipGetLastError());
    if (multi)
    {
@@ -2456,7 +2627,13 @@ int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
          LGH_HIP_CHECK(hipGetLastError());
       }
    }
-   if (k2p && ((hs->nupd[0] | hs->nupd[1] | hs->nupd[2]) & 1))
+   if (aux->ord)
+   {
+      // the solution, in the caller's numbering, into the caller's vector (with the pending update of vcg_xfix_k)
+      hipLaunchKernelGGL(vcg_xout_k, dim3(nb), dim3(256), 0, c->stream, a, X);
+      LGH_HIP_CHECK(hipGetLastError());
+   }
+   else if (k2p && ((hs->nupd[0] | hs->nupd[1] | hs->nupd[2]) & 1))
    {
       // x lags one update behind for the components that stopped after an odd number of updates
       hipLaunchKernelGGL(vcg_xfix_k, dim3(nb), dim3(256), 0, c->stream, a);
@@ -2555,7 +2732,14 @@ int vcg_test_merged_faces(lgh_ctx *c, unsigned char *mask, long *n_merged)
    SlabLayout L;
    const int rc2 = slab_merge_layout(c, L);
    if (rc2) { return rc2; }
-   memcpy(mask, L.sec.data(), nE);
+   // (the layout is that of the order the solve runs in; the caller's E-vector is in the caller's zone order)
+   const MeshOrder *ord = plan.aux->ord;
+   if (ord)
+   {
+      const size_t ND = (size_t)c->ND;
+      for (size_t i = 0; i < (size_t)c->NE; i++) { memcpy(mask + (size_t)ord->zorder[i] * ND, L.sec.data() + i * ND, ND); }
+   }
+   else { memcpy(mask, L.sec.data(), nE); }
    *n_merged = (long)L.n_merged;
    return LGH_OK;
 }
@@ -2617,8 +2801,11 @@ int vcg_test_k1(lgh_ctx *c, const double *r, const double *d_old, const double r
    VcgArgs &a = plan.a;
    const size_t N = (size_t)c->N, nE = (size_t)c->NE * c->ND;
    VcgScalars *ds = (VcgScalars *)c->vcg_s;
-   LGH_HIP_CHECK(hipMemcpyAsync(a.r, r, kVC * N * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+   const MeshOrder *ord = plan.aux->ord; // (the solve's own order: the caller's vectors and E-vector go through the permutation)
+   if (ord) { rc = order_gather_nodes(c, r, a.r, kVC); if (rc) { return rc; } }
+   else { LGH_HIP_CHECK(hipMemcpyAsync(a.r, r, kVC * N * sizeof(double), hipMemcpyDeviceToDevice, c->stream)); }
    if (first) { LGH_HIP_CHECK(hipMemsetAsync(a.d, 0, kVC * N * sizeof(double), c->stream)); }
+   else if (ord) { rc = order_gather_nodes(c, d_old, a.d, kVC); if (rc) { return rc; } }
    else { LGH_HIP_CHECK(hipMemcpyAsync(a.d, d_old, kVC * N * sizeof(double), hipMemcpyDeviceToDevice, c->stream)); }
    LGH_HIP_CHECK(hipStreamSynchronize(c->stream)); // (vcg_set_tol_k has cleared the accumulators and the set counters)
    VcgScalars h;
@@ -2649,15 +2836,23 @@ int vcg_test_k1(lgh_ctx *c, const double *r, const double *d_old, const double r
    LGH_HIP_CHECK(hipMemcpy(&h, ds, sizeof(h), hipMemcpyDeviceToHost));
    MergedDev md;
    if (a.settab) { rc = merged_to_device(c, md); if (rc) { return rc; } }
+   struct Tmp { double *p = nullptr; ~Tmp() { (void)hipFree(p); } } tmp; // (internal order: a plane in the solve's zone order on its way to the caller's)
+   if (ord) { LGH_HIP_CHECK(hipMalloc((void **)&tmp.p, nE * sizeof(double))); }
    for (int k = 0; k < kVC; k++)
    {
       den_out[k] = h.den[k];
+      double *dst = ord ? tmp.p : YE_out + (size_t)k * nE;
       if (a.settab)
       {
-         hipLaunchKernelGGL(vcg_unpack_merged_k, dim3((unsigned)((nE + 255) / 256)), dim3(256), 0, c->stream, a.YE + (size_t)k * a.ye_stride, md.pos, md.sec, YE_out + (size_t)k * nE, nE);
+         hipLaunchKernelGGL(vcg_unpack_merged_k, dim3((unsigned)((nE + 255) / 256)), dim3(256), 0, c->stream, a.YE + (size_t)k * a.ye_stride, md.pos, md.sec, dst, nE);
          LGH_HIP_CHECK(hipGetLastError());
       }
-      else { LGH_HIP_CHECK(hipMemcpy(YE_out + (size_t)k * nE, a.YE + (size_t)k * a.ye_stride, nE * sizeof(double), hipMemcpyDeviceToDevice)); }
+      else { LGH_HIP_CHECK(hipMemcpyAsync(dst, a.YE + (size_t)k * a.ye_stride, nE * sizeof(double), hipMemcpyDeviceToDevice, c->stream)); }
+      if (ord)
+      {
+         rc = order_zone_blocks(c, tmp.p, YE_out + (size_t)k * nE, c->ND, true);
+         if (rc) { return rc; }
+      }
    }
    LGH_HIP_CHECK(hipStreamSynchronize(c->stream));
    return LGH_OK;
@@ -2681,18 +2876,38 @@ int vcg_test_k2(lgh_ctx *c, int it, const double *YE_in, double *r, double *d, d
    VcgArgs &a = plan.a;
    const size_t N = (size_t)c->N, nE = (size_t)c->NE * c->ND;
    VcgScalars *ds = (VcgScalars *)c->vcg_s;
-   LGH_HIP_CHECK(hipMemcpyAsync(a.r, r, kVC * N * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-   LGH_HIP_CHECK(hipMemcpyAsync(a.d, d, kVC * N * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+   const MeshOrder *ord = plan.aux->ord; // (the solve's own order: the caller's vectors and E-vector go through the permutation)
+   if (ord)
+   {
+      rc = order_gather_nodes(c, r, a.r, kVC);
+      if (rc == LGH_OK) { rc = order_gather_nodes(c, d, a.d, kVC); }
+      if (rc == LGH_OK) { rc = order_gather_nodes(c, x, a.x, kVC); }
+      if (rc) { return rc; }
+   }
+   else
+   {
+      LGH_HIP_CHECK(hipMemcpyAsync(a.r, r, kVC * N * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+      LGH_HIP_CHECK(hipMemcpyAsync(a.d, d, kVC * N * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+   }
    MergedDev md;
    if (a.settab) { rc = merged_to_device(c, md); if (rc) { return rc; } }
+   struct Tmp { double *p = nullptr; ~Tmp() { (void)hipFree(p); } } tmp;
+   if (ord) { LGH_HIP_CHECK(hipMalloc((void **)&tmp.p, nE * sizeof(double))); }
    for (int k = 0; k < kVC; k++)
    {
+      const double *src = YE_in + (size_t)k * nE;
+      if (ord)
+      {
+         rc = order_zone_blocks(c, src, tmp.p, c->ND, false);
+         if (rc) { return rc; }
+         src = tmp.p;
+      }
       if (a.settab)
       {
-         hipLaunchKernelGGL(vcg_pack_merged_k, dim3((unsigned)((nE + 255) / 256)), dim3(256), 0, c->stream, YE_in + (size_t)k * nE, md.pos, md.sec, c->ND, a.YE + (size_t)k * a.ye_stride, nE);
+         hipLaunchKernelGGL(vcg_pack_merged_k, dim3((unsigned)((nE + 255) / 256)), dim3(256), 0, c->stream, src, md.pos, md.sec, c->ND, a.YE + (size_t)k * a.ye_stride, nE);
          LGH_HIP_CHECK(hipGetLastError());
       }
-      else { LGH_HIP_CHECK(hipMemcpyAsync(a.YE + (size_t)k * a.ye_stride, YE_in + (size_t)k * nE, nE * sizeof(double), hipMemcpyDeviceToDevice, c->stream)); }
+      else { LGH_HIP_CHECK(hipMemcpyAsync(a.YE + (size_t)k * a.ye_stride, src, nE * sizeof(double), hipMemcpyDeviceToDevice, c->stream)); }
    }
    LGH_HIP_CHECK(hipStreamSynchronize(c->stream)); // (vcg_set_tol_k has cleared the accumulators)
    VcgScalars h;
@@ -2724,6 +2939,15 @@ int vcg_test_k2(lgh_ctx *c, int it, const double *YE_in, double *r, double *d, d
    LGH_HIP_CHECK(hipStreamSynchronize(c->stream));
    LGH_HIP_CHECK(hipMemcpy(&h, ds, sizeof(h), hipMemcpyDeviceToHost));
    for (int k = 0; k < kVC; k++) { rz_out[k] = (a.rzl && plan.k2p) ? h.rzh[it & 1][k] : h.rz[k]; }
+   if (ord)
+   {
+      rc = order_scatter_nodes(c, a.r, r, kVC);
+      if (rc == LGH_OK) { rc = order_scatter_nodes(c, a.d, d, kVC); }
+      if (rc == LGH_OK) { rc = order_scatter_nodes(c, a.x, x, kVC); }
+      if (rc) { return rc; }
+      LGH_HIP_CHECK(hipStreamSynchronize(c->stream));
+      return LGH_OK;
+   }
    LGH_HIP_CHECK(hipMemcpy(r, a.r, kVC * N * sizeof(double), hipMemcpyDeviceToDevice));
    LGH_HIP_CHECK(hipMemcpy(d, a.d, kVC * N * sizeof(double), hipMemcpyDeviceToDevice));
    return LGH_OK;

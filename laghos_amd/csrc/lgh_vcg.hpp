@@ -205,6 +205,8 @@ struct VcgArgs
    int deg;
    const uint8_t *ess[kVC];
    const double *dinv, *owner;
+   const int *ncaller;    // the solve runs in the library's own node numbering (lgh_order.hip): internal node m is the caller's node ncaller[m] - the
+                          // caller's vectors (b in, the right-hand side and x out) are indexed through it; nullptr: the caller's numbering is the solve's
    const double *b;       // kVC*N right-hand sides (byNODES)
    double *x;             // kVC*N solutions
    double *r, *d;         // kVC*N each (z = r/diag is recomputed where it is used)

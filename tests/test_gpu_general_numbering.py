@@ -1,11 +1,13 @@
 """The operators on a mesh whose numbering has no structure: random renumbering of the H1 nodes, random order of the zones
 (tests/helpers.py::PermutedProblem).  Every mesh of BASELINE.json comes out of this repository's own Cartesian generator -
-lexicographic nodes, zones x-fastest - and the kernels use what they FIND of that (x-chains of zones -> merged E-vector,
-consecutive x-rows of nodes -> row loads, neighbouring zones on one XCD); what the reference hands its operators is
-MFEM's numbering (vertices, then edge / face / interior dofs; `H1.GetElementRestriction`, laghos_assembly.cpp:557-565),
-which has none of it.  These cases run the general path of every kernel of the hot path: against the oracle on the same
-permuted problem (which knows nothing but the element -> node map), and against the un-permuted run - the discrete
-problem is the same, so `|e|`, the time step and the state agree to round-off (sums run in another order)."""
+lexicographic nodes, zones x-fastest; what the reference hands its operators is MFEM's numbering (vertices, then edge /
+face / interior dofs; `H1.GetElementRestriction`, laghos_assembly.cpp:557-565), which has none of that structure.
+Round 6: the library finds the structure of the MESH itself (lgh_order.hip: face adjacency of the element -> node map) and
+runs the velocity solve in its own zone order and node numbering, so the fast paths (x-chains of zones -> merged E-vector,
+consecutive x-rows of nodes -> row loads) are taken on the permuted mesh as well - `order` = "own"; `order` = "callers"
+(LGH_ORDER=0) keeps the caller's numbering: the general path of every kernel, as in rounds 1-5.  Both against the oracle on
+the same permuted problem (which knows nothing but the element -> node map), and against the un-permuted run - the
+discrete problem is the same, so `|e|`, the time step and the state agree to round-off (sums run in another order)."""
 import numpy as np
 import pytest
 
@@ -23,16 +25,20 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("order", ["own", "callers"])
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
-def test_rhs_on_a_permuted_mesh_vs_oracle_and_vs_the_structured_mesh(case, monkeypatch):
+def test_rhs_on_a_permuted_mesh_vs_oracle_and_vs_the_structured_mesh(case, order, monkeypatch):
     """One evaluation of dS/dt (quadrature update, both force products, three H1 solves, the L2 solve; CG to 1e-13) on a
     distorted state: HIP path on the permuted problem against (a) the oracle on the same permuted problem, (b) the HIP path
     on the structured problem, mapped through the permutation."""
     from oracle.fem import Problem
     _, kw, variant = case
     monkeypatch.delenv("LGH_VCG_VARIANT", raising=False)
+    monkeypatch.delenv("LGH_ORDER", raising=False)
     if variant is not None:
         monkeypatch.setenv("LGH_VCG_VARIANT", variant)
+    if order == "callers":
+        monkeypatch.setenv("LGH_ORDER", "0")
     base = Problem(**kw)
     perm = PermutedProblem(base, seed=11)
     S_b = deformed_state(base, seed=23)
@@ -43,6 +49,8 @@ def test_rhs_on_a_permuted_mesh_vs_oracle_and_vs_the_structured_mesh(case, monke
         g = make_gpu(prob, cg_tol=1e-13)
         try:
             form = g.ctx.k1_form()
+            mo = g.ctx.mesh_order()
+            assert mo["identity"] == (prob is base or order == "callers" or prob.dim == 2), mo
             _, n_merged = g.ctx.test_vcg_merged_faces() if prob.dim == 3 else (None, 0)
             Sd, dS = g.ctx.to_dev(S), g.ctx.zeros(S.size)
             g.reset_quadrature_data()
@@ -58,7 +66,9 @@ def test_rhs_on_a_permuted_mesh_vs_oracle_and_vs_the_structured_mesh(case, monke
     dS_b, dt_b, form_b, merged_b = rhs_gpu(base, S_b)
     assert form_p == form_b
     if variant == "4":
-        assert form_p == "slab" and merged_b > 0 and merged_p == 0  # the zones of a set are no neighbours any more: nothing to merge
+        # the library's own zone order finds the same x-chains on the permuted mesh; in the caller's order the zones of a set are
+        # no neighbours: nothing to merge
+        assert form_p == "slab" and merged_b > 0 and merged_p == (merged_b if order == "own" else 0)
     o = make_oracle(perm, cg_tol=1e-13)
     try:
         dS_o = np.empty_like(S_p)
@@ -75,14 +85,20 @@ def test_rhs_on_a_permuted_mesh_vs_oracle_and_vs_the_structured_mesh(case, monke
     assert abs(dt_p - dt_o) <= 1e-12 * dt_o and abs(dt_p - dt_b) <= 1e-12 * dt_b
 
 
-def test_k1_and_mass_operators_on_a_permuted_mesh(monkeypatch):
+@pytest.mark.parametrize("order", ["own", "callers"])
+def test_k1_and_mass_operators_on_a_permuted_mesh(order, monkeypatch):
     """The mass operators alone, kernel by kernel, on the permuted 512-zone Q3Q2 mesh: MassPAOperator::Mult on both spaces
-    and one launch of the slab K1 (node gathers instead of row loads, element-local E-vector in every set) vs the oracle."""
+    and one launch of the slab K1 vs the oracle - in the caller's order (node gathers instead of row loads, element-local
+    E-vector in every set) and in the library's own (row loads, merged sets; the hook speaks the caller's numbering on both
+    sides: vectors and E-vector go through the permutation)."""
     from oracle.driver import _dp
     from oracle.fem import Problem
     base = Problem(mesh="cube01_hex", rs=2, order_v=3, order_e=2, problem=1)
     perm = PermutedProblem(base, seed=13)
     monkeypatch.setenv("LGH_VCG_VARIANT", "4")
+    monkeypatch.delenv("LGH_ORDER", raising=False)
+    if order == "callers":
+        monkeypatch.setenv("LGH_ORDER", "0")
     g, o = make_gpu(perm), make_oracle(perm)
     try:
         N, NE, ND = perm.N, perm.NE, perm.ND
@@ -100,13 +116,29 @@ def test_k1_and_mass_operators_on_a_permuted_mesh(monkeypatch):
         rz_prev = rz * np.array([1.7, 0.6, 1.1])
         yE, den = g.ctx.test_vcg_k1(g.ctx.to_dev(r), g.ctx.to_dev(d_old), rz, rz_prev, False)
         yE = yE.cpu().numpy()
+        mask, n_merged = g.ctx.test_vcg_merged_faces()
+        assert (n_merged > 0) == (order == "own")
+        mask = np.asarray(mask).reshape(NE, ND).astype(bool)
         hmap = np.asarray(perm.h1map).reshape(NE, ND)
+        # zone -> its left x-neighbour (the zone whose dx = 3 face is this zone's dx = 0 face), for the merged pairs
+        left = {tuple(hmap[e].reshape(4, 4, 4)[:, :, 3].ravel()): e for e in range(NE)}
         for c in range(3):
             d = r[c * N:(c + 1) * N] * dinv + (rz[c] / rz_prev[c]) * d_old[c * N:(c + 1) * N]
             xE = np.ascontiguousarray(d[hmap].reshape(-1))
             yE_o = np.empty(NE * ND)
             o.L.lgo_mass_apply_E(o.h, 0, _dp(xE), _dp(yE_o))
-            assert rel_err(yE[c], yE_o) < 2e-12, c
+            exp = yE_o.reshape(NE, 4, 4, 4).copy()   # [e][dz][dy][dx]
+            if n_merged:
+                # K1 reports the sum of a merged pair in the LEFT zone's dx = 3 entry and 0.0 in the right zone's dx = 0 entry
+                m4 = mask.reshape(NE, 4, 4, 4)
+                for e in range(NE):
+                    if not m4[e, :, :, 0].any():
+                        continue
+                    l = left[tuple(hmap[e].reshape(4, 4, 4)[:, :, 0].ravel())]
+                    sel = m4[e, :, :, 0]
+                    exp[l, :, :, 3][sel] += exp[e, :, :, 0][sel]
+                    exp[e, :, :, 0][sel] = 0.0
+            assert rel_err(yE[c], exp.reshape(-1)) < 2e-12, c
             assert abs(den[c] - float(np.dot(xE, yE_o))) <= 2e-12 * abs(den[c]), c
     finally:
         g.close()
@@ -184,3 +216,33 @@ def test_rhs_on_a_curved_initial_mesh_vs_oracle(kw, variant, monkeypatch):
         o.close()
     assert rel_err(dS[H1V:2 * H1V], dS_o[H1V:2 * H1V]) < 1e-9 and rel_err(dS[2 * H1V:], dS_o[2 * H1V:]) < 1e-9
     assert abs(dt - dt_o) <= 1e-12 * dt_o
+
+
+@pytest.mark.parametrize("mode", ["mfem", "random"])
+def test_cpp_driver_on_a_renumbered_mesh_reproduces_the_structured_run(mode):
+    """`laghos -renumber mfem|random` (the legs c2mfem / c2perm of bench.py at a small size): eight RK4 steps of 3D Sedov Q3Q2
+    on 512 zones through the C++ host layer, in an MFEM-like / a random numbering of nodes and zones - same steps, same dt,
+    same |e| and the same state (through the permutation) as in the generator's own numbering."""
+    from laghos_amd import host_lib
+    common = ["-m", "data/cube01_hex.mesh", "-rs", 2, "-p", 1, "-ok", 3, "-ot", 2, "-pa", "-tf", 1e9, "-ms", 8, "-vs", 10 ** 9, "-q"]
+    out = {}
+    for name, extra in (("base", []), (mode, ["-renumber", mode, "-renumber-seed", 9])):
+        sim = host_lib.Sim(common + extra)
+        try:
+            sim.enable_timers(False)
+            while sim.step() == 1:
+                pass
+            sim.sync()
+            out[name] = (sim.t, sim.dt, sim.rk_steps, sim.e_norm(), sim.state())
+        finally:
+            sim.close()
+    d = host_lib.host_disc("cube01_hex", 2, 3, 2, 1, renumber=mode, seed=9)
+    npm, epm = d["node_perm"].astype(np.int64), d["elem_perm"].astype(np.int64)
+    (t_b, dt_b, n_b, e_b, S_b), (t_r, dt_r, n_r, e_r, S_r) = out["base"], out[mode]
+    assert n_b == n_r and abs(t_r - t_b) <= 1e-11 * t_b and abs(dt_r - dt_b) <= 1e-10 * dt_b
+    assert abs(e_r - e_b) <= 1e-9 * e_b
+    N, NE = npm.size, epm.size
+    H1V, NL = 3 * N, 27
+    for b in range(6):
+        assert rel_err(S_r[b * N:(b + 1) * N][npm], S_b[b * N:(b + 1) * N]) < 1e-8, b
+    assert rel_err(S_r[2 * H1V:].reshape(NE, NL), S_b[2 * H1V:].reshape(NE, NL)[epm]) < 1e-8
