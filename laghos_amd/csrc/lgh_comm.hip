@@ -378,10 +378,13 @@ bool halo_can_piggyback(const lgh_ctx *c)
 
 // extra != nullptr (device, nextra <= 3 doubles, requires halo_can_piggyback): replaced
 // by its sum over all ranks, carried by the same messages
-int halo_sum(lgh_ctx *c, double *v, int ncomp, double *extra, int nextra, bool packed)
+// alias (optional): v is numbered otherwise than the caller's vectors (the velocity solve's own node numbering,
+// lgh_order.hip) - the same node lists in THAT numbering; everything else of the exchange does not know about numbers
+int halo_sum(lgh_ctx *c, double *v, int ncomp, double *extra, int nextra, bool packed, const HaloNodeAlias *alias)
 {
    Comm *cm = c->comm;
    if (!cm || cm->n_nbr == 0) { return LGH_OK; }
+   const int *const l_nodes = alias ? alias->nodes : cm->nodes, *const l_sh_node = alias ? alias->sh_node : cm->sh_node;
    if (ncomp > 3 || ncomp < 0 || (ncomp == 0 && !extra)) { set_error("halo_sum: bad ncomp"); return LGH_ERR_ARG; }
    if (extra && (!cm->allpairs || nextra < 1 || nextra > 3)) { set_error("halo_sum: cannot piggy-back"); return LGH_ERR_ARG; }
    const int nx = extra ? nextra : 0;
@@ -399,14 +402,14 @@ int halo_sum(lgh_ctx *c, double *v, int ncomp, double *extra, int nextra, bool p
    if (!packed)
    {
       hipLaunchKernelGGL(halo_pack_k, dim3(ceil_div(npack, 256)), dim3(256), 0, c->stream, tot,
-                         ncomp, c->N, cm->nodes, cm->pos, cm->cnt, v, sbuf, cm->n_nbr, nx, cm->d_base, cm->d_cnt,
+                         ncomp, c->N, l_nodes, cm->pos, cm->cnt, v, sbuf, cm->n_nbr, nx, cm->d_base, cm->d_cnt,
                          extra);
       LGH_HIP_CHECK(hipGetLastError());
    }
    auto combine = [&]() {
       const long ncomb = std::max((long)cm->n_shared * ncomp, (long)nx);
       hipLaunchKernelGGL(halo_combine_k, dim3(ceil_div(ncomb, 256)), dim3(256), 0,
-                         c->stream, cm->n_shared, ncomp, c->N, cm->sh_node, cm->sh_off, cm->sh_src, cm->pos,
+                         c->stream, cm->n_shared, ncomp, c->N, l_sh_node, cm->sh_off, cm->sh_src, cm->pos,
                          cm->cnt, rbuf, v, c->nranks, nx, cm->rank_src, cm->d_base, cm->d_cnt, extra);
    };
    if (cm->local)
@@ -486,6 +489,15 @@ bool comm_pack_tables(const lgh_ctx *c, HaloPackTables *t)
    return true;
 }
 
+// the node lists of the exchanges (device, the caller's numbering): concatenated neighbour lists, unique shared nodes
+void comm_node_lists(const lgh_ctx *c, const int **nodes, int *total, const int **sh_node, int *n_shared)
+{
+   const Comm *cm = c->comm;
+   *nodes = cm ? cm->nodes : nullptr;
+   *total = cm ? cm->total : 0;
+   *sh_node = cm ? cm->sh_node : nullptr;
+   *n_shared = (cm && cm->sh_node) ? cm->n_shared : 0;
+}
 void comm_shared_nodes(const lgh_ctx *c, const uint8_t **hmask, const int **sh_node, int *n_shared)
 {
    const Comm *cm = c->comm;

@@ -499,7 +499,9 @@ int vec_zero_list(lgh_ctx *c, double *y, const int *list, int n);
 int vec_dot(lgh_ctx *c, const double *x, const double *y, const double *w, long n, double *dev_out);
 // packed: the caller's own kernel has already put the node values / scalars into the send buffer of the main channel
 // (HaloPackTables: what it needs for that) - the exchange then starts without a pack kernel
-int halo_sum(lgh_ctx *c, double *v, int ncomp, double *extra = nullptr, int nextra = 0, bool packed = false);
+struct HaloNodeAlias { const int *nodes, *sh_node; }; // the exchange's node lists in another numbering of the SAME nodes (the velocity solve's own)
+int halo_sum(lgh_ctx *c, double *v, int ncomp, double *extra = nullptr, int nextra = 0, bool packed = false, const HaloNodeAlias *alias = nullptr);
+void comm_node_lists(const lgh_ctx *c, const int **nodes, int *total, const int **sh_node, int *n_shared);
 struct HaloPackTables
 {
    const int *sh_off, *sh_src; // CSR over the unique shared nodes: entries of the concatenated neighbour lists (-1: own value)

@@ -1919,6 +1919,11 @@ struct VcgAux
    uint8_t *o_ess[kVC] = {nullptr, nullptr, nullptr};
    double *o_dinv = nullptr, *o_Se = nullptr, *o_massD = nullptr;
    double *o_x = nullptr;      // kVC*N: the solution in internal numbering (vcg_xout_k hands it to the caller)
+   // several ranks: owner weights, shared-node flags and the node lists of the exchanges (lgh_comm.hip) in internal numbering
+   double *o_owner = nullptr;
+   uint8_t *o_hmask = nullptr;
+   int *o_nodes = nullptr, *o_shnode = nullptr;
+   HaloNodeAlias o_alias = {nullptr, nullptr};
    unsigned long o_mass_gen = ~0ul; // c->mass_gen the copies above were taken at
 };
 static int vcg_view_map(lgh_ctx *c, std::vector<int> &map)
@@ -1952,6 +1957,10 @@ void vcg_free(lgh_ctx *c)
    (void)hipFree(x->o_Se);
    (void)hipFree(x->o_massD);
    (void)hipFree(x->o_x);
+   (void)hipFree(x->o_owner);
+   (void)hipFree(x->o_hmask);
+   (void)hipFree(x->o_nodes);
+   (void)hipFree(x->o_shnode);
    delete x;
    c->vcg_aux = nullptr;
 }
@@ -2109,11 +2118,12 @@ static int vcg_build_merged_tables(lgh_ctx *c, VcgAux *x)
 }
 
 // The order the lockstep solve runs in: the library's own (lgh_order.hip) unless it is the caller's anyway.  Several ranks:
-// the exchange tables of lgh_comm.hip (shared-node lists, pack / combine positions) are in the caller's numbering and the
-// solve follows them - the caller's order is kept there.
+// every rank orders its own block; the node lists of the exchanges (lgh_comm.hip: the caller's numbering) are translated
+// once (HaloNodeAlias) - which nodes travel, in which order and how they are summed does not depend on their numbers.
 static const MeshOrder *vcg_order_for(const lgh_ctx *c)
 {
-   if (c->multi != 0) { return nullptr; }
+   const char *env = getenv("LGH_ORDER_MULTI"); // A/B: 0 = several ranks keep the caller's numbering in the solve
+   if (c->multi != 0 && env && env[0] == '0') { return nullptr; }
    return mesh_order(c);
 }
 // Tables and vectors of the solve in the internal order (VcgAux::o_*): the element -> node map (internal zone i, internal
@@ -2162,6 +2172,41 @@ static int vcg_build_internal_tables(lgh_ctx *c, VcgAux *x)
       LGH_HIP_CHECK(hipMalloc((void **)&x->o_ess[k], N));
       const int rc = order_gather_bytes(c, c->essmask[k], x->o_ess[k]);
       if (rc) { return rc; }
+   }
+   if (c->multi != 0)
+   {
+      if (c->owner)
+      {
+         LGH_HIP_CHECK(hipMalloc((void **)&x->o_owner, N * sizeof(double)));
+         const int rc = order_gather_nodes(c, c->owner, x->o_owner, 1);
+         if (rc) { return rc; }
+      }
+      const uint8_t *hmask = nullptr;
+      const int *sh_node = nullptr, *nodes = nullptr;
+      int n_shared = 0, total = 0;
+      comm_shared_nodes(c, &hmask, &sh_node, &n_shared);
+      if (hmask)
+      {
+         LGH_HIP_CHECK(hipMalloc((void **)&x->o_hmask, N));
+         const int rc = order_gather_bytes(c, hmask, x->o_hmask);
+         if (rc) { return rc; }
+      }
+      comm_node_lists(c, &nodes, &total, &sh_node, &n_shared);
+      auto translate = [&](const int *src, const int n, int **dst) -> int {
+         std::vector<int> h((size_t)std::max(n, 1), 0);
+         if (n > 0) { LGH_HIP_CHECK(hipMemcpy(h.data(), src, (size_t)n * sizeof(int), hipMemcpyDeviceToHost)); }
+         for (int i = 0; i < n; i++) { h[i] = o->nnum[h[i]]; }
+         LGH_HIP_CHECK(hipMalloc((void **)dst, h.size() * sizeof(int)));
+         LGH_HIP_CHECK(hipMemcpy(*dst, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice));
+         return LGH_OK;
+      };
+      if (nodes && sh_node)
+      {
+         int rc = translate(nodes, total, &x->o_nodes);
+         if (rc == LGH_OK) { rc = translate(sh_node, n_shared, &x->o_shnode); }
+         if (rc) { return rc; }
+         x->o_alias = {x->o_nodes, x->o_shnode};
+      }
    }
    LGH_HIP_CHECK(hipMalloc((void **)&x->o_dinv, N * sizeof(double)));
    LGH_HIP_CHECK(hipMalloc((void **)&x->o_Se, NE * sizeof(double)));
@@ -2359,6 +2404,7 @@ static int vcg_prepare(lgh_ctx *c, double *B, double *X, double rel_tol, VcgPlan
       a.ell = aux->o_ell;
       for (int k = 0; k < kVC; k++) { a.ess[k] = aux->o_ess[k]; }
       a.dinv = aux->o_dinv;
+      a.owner = multi ? aux->o_owner : nullptr;
       a.ncaller = aux->ord->ncaller_d;
       a.x = aux->o_x;
    }
@@ -2412,7 +2458,11 @@ static int vcg_prepare(lgh_ctx *c, double *B, double *X, double rel_tol, VcgPlan
    if (trace_path && !trace_dev) { (void)hipMalloc((void **)&trace_dev, kTraceRec * 4096 * sizeof(unsigned long long)); (void)hipMemset(trace_dev, 0, kTraceRec * 4096 * sizeof(unsigned long long)); }
    a.trace = trace_dev;
    if (trace_dev) { (void)hipMemsetAsync(trace_dev, 0, kTraceRec * 4096 * sizeof(unsigned long long), c->stream); }
-   if (multi) { comm_shared_nodes(c, &a.hmask, &a.sh_node, &a.n_shared); }
+   if (multi)
+   {
+      comm_shared_nodes(c, &a.hmask, &a.sh_node, &a.n_shared);
+      if (aux->ord && a.n_shared > 0) { a.hmask = aux->o_hmask; a.sh_node = aux->o_shnode; } // (the same nodes by their internal numbers)
+   }
    {
       // several ranks, bounded-grid K2: the shared-node gather fills the send buffer of the halo exchange itself (and
       // the local (d, A d) with it where the sums ride on the messages), the last workgroup of K2 the one of the
@@ -2502,6 +2552,7 @@ int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
    const size_t N = (size_t)c->N;
    VcgScalars *ds = (VcgScalars *)c->vcg_s;
    const int nb = ceil_div((long)N, 256);
+   const HaloNodeAlias *alias = (aux->ord && aux->o_alias.nodes) ? &aux->o_alias : nullptr; // (a.yL is in the solve's own numbering)
 
    // init (vector kernels use reduction slot 0, the element kernel slot 1)
    a.partials = c->vcg_partials;
@@ -2596,12 +2647,12 @@ int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
                // rank is a neighbour of every other, by an all-reduce otherwise
                if (halo_can_piggyback(c))
                {
-                  rc = halo_sum(c, a.yL, kVC, ds->den, kVC, a.pack_halo != 0);
+                  rc = halo_sum(c, a.yL, kVC, ds->den, kVC, a.pack_halo != 0, alias);
                   if (rc) { return rc; }
                }
                else
                {
-                  rc = halo_sum(c, a.yL, kVC, nullptr, 0, a.pack_halo != 0);
+                  rc = halo_sum(c, a.yL, kVC, nullptr, 0, a.pack_halo != 0, alias);
                   if (rc) { return rc; }
                   rc = allreduce_dev(c, ds->den, kVC, 0);
                   if (rc) { return rc; }

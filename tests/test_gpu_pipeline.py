@@ -481,6 +481,14 @@ MULTI_RANK_CASES = [
     (8, (8, 8, 8), 1, 0, (3, 2), {"LGH_HALO_FUSED_PACK": "0"}), (3, (9, 6, 6), 1, 1, (3, 2), {"LGH_HALO_FUSED_PACK": "0"}),
     # the high-order forms of K1 / K2 on several ranks (BASELINE config 5 is an 8-GPU Q5Q4 run)
     (8, (4, 4, 4), 1, 0, (4, 3), {}), (8, (4, 4, 4), 3, 0, (5, 4), {}), (2, (4, 4, 2), 3, 1, (5, 4), {"LGH_COMM2": "0"}),
+    # round 6: every rank is handed its block in an MFEM-like / a random numbering of nodes and zones (LGH_RENUMBER: `-renumber`
+    # for the ranks only; the one-rank reference runs on the generator's numbering) - each rank's velocity solve then runs in
+    # the library's own order, the node lists of the exchanges translated (HaloNodeAlias); LGH_ORDER_MULTI=0: in the caller's
+    (8, (16, 16, 16), 1, 0, (3, 2), {"LGH_VCG_VARIANT": "4", "LGH_RENUMBER": "mfem"}),
+    (2, (16, 8, 8), 1, 0, (3, 2), {"LGH_VCG_VARIANT": "4", "LGH_RENUMBER": "random"}),
+    (3, (9, 6, 6), 1, 1, (3, 2), {"LGH_RENUMBER": "random"}), (8, (8, 8, 8), 1, 0, (3, 2), {"LGH_RENUMBER": "mfem", "LGH_HALO_FUSED_PACK": "0"}),
+    (4, (8, 8, 4), 7, 1, (3, 2), {"LGH_RENUMBER": "mfem"}), (8, (4, 4, 4), 3, 0, (5, 4), {"LGH_RENUMBER": "random"}),
+    (2, (16, 8, 8), 1, 0, (3, 2), {"LGH_VCG_VARIANT": "4", "LGH_RENUMBER": "random", "LGH_ORDER_MULTI": "0"}),
 ]
 
 
@@ -520,7 +528,8 @@ def test_multi_rank_run_on_one_gpu(nranks, nel, problem, timers, order, env, mon
 
     def rank_main(rank):
         try:
-            sim = host_lib.Sim(args, nranks=nranks, rank=rank, nccl_id=cid)
+            rargs = args + (["-renumber", env["LGH_RENUMBER"], "-renumber-seed", 3 + rank] if "LGH_RENUMBER" in env else [])
+            sim = host_lib.Sim(rargs, nranks=nranks, rank=rank, nccl_id=cid)
             sim.enable_timers(timers)
             while sim.step() == 1:
                 pass
