@@ -103,25 +103,21 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(threads):
-    """The oracle (CPU restatement of the reference -pa path) timed on the host
-    cores on a bounded sample of the same 32^3 Q3/Q2 Sedov workload: whole RK4
-    steps from t=0 with the real dt controller inputs (each step = 4 stages of
-    1 QUpdate, 1 Force, 1 ForceT, 3 H1 PCG, 1 L2 CG, + the dt-estimate QUpdate)
-    until ~12 s of CPU work.  Reported next to the GPU number; never shipped."""
+def _time_oracle(threads, native, budget_s, want_ref):
+    """RK4 steps of the bench's own problem from t = 0 with the restated CPU path until `budget_s` of wall time are spent"""
     import numpy as np
     from oracle.driver import Hydro, lib, rk4_step
     from oracle.fem import Problem
-    lib().lgo_set_num_threads(threads)
+    lib(native).lgo_set_num_threads(threads)
     prob = Problem(mesh="cube01_hex", rs=4, order_v=3, order_e=2, problem=1)
-    h = Hydro(prob)
+    h = Hydro(prob, native=native)
     S = h.S0.copy()
     work = (np.empty_like(S), np.empty_like(S), np.empty_like(S))
     h.reset_time_step_estimate()
     dt = h.get_time_step_estimate(S)
     steps, wall, t = 0, 0.0, 0.0
     ref = None
-    while wall < 12.0 and steps < 40:
+    while (wall < budget_s or (want_ref and steps < PARITY_STEPS)) and steps < 40:
         t0 = time.time()
         h.reset_time_step_estimate()
         t = rk4_step(h, S, t, dt, work)
@@ -132,16 +128,36 @@ def cpu_baseline(threads):
             ref = {"error": "the oracle's step %d would be repeated with a smaller dt: no parity sample" % steps}
         if dt_est > 1.25 * dt:
             dt *= 1.02
-        if steps == PARITY_STEPS and ref is None:
+        if want_ref and steps == PARITY_STEPS and ref is None:
             # the checker's state after PARITY_STEPS whole RK4 steps of the bench problem: main() holds the HIP path's against it
             ref = {"steps": steps, "t": t, "dt": dt, "e_norm": h.e_norm(S), "S": S.copy(), "H1V": prob.H1V}
     dofs = prob.dim * prob.N + prob.L2V
     tm = h.timers()
     h.close()
-    return dict(value=1e-6 * dofs * 4 * steps / wall, unit="Mdofs*steps/s", cores=threads, cpu_model=cpu_model(), kind="port",
-                sample="%d RK4 steps from t=0 of the same 3D Sedov Q3Q2 32^3 problem (oracle/ C++ kernels, "
-                       "OpenMP %d threads), %.1f s" % (steps, threads, wall),
-                seconds=wall, rk4_steps=steps, h1_cg_iters=tm["H1iter"]), ref
+    return dict(value=1e-6 * dofs * 4 * steps / wall, seconds=wall, rk4_steps=steps, h1_cg_iters=tm["H1iter"]), ref
+
+
+def cpu_baseline(threads):
+    """The oracle (CPU restatement of the reference -pa path) timed on the host cores on a bounded sample of the same 32^3
+    Q3/Q2 Sedov workload: whole RK4 steps from t = 0 with the real dt controller inputs (each step = 4 stages of 1 QUpdate,
+    1 Force, 1 ForceT, 3 H1 PCG, 1 L2 CG, + the dt-estimate QUpdate).  Two builds of the same source (round-5 verdict, item 6):
+    `value` is the TIMING build SURVEY 8(d) asks for (-O3 -march=native, FMA contraction; compiled on this very host by
+    `make -C oracle native`), `value_parity_build` the checker itself (-march=x86-64-v3 -ffp-contract=off: the build every
+    parity test and the `parity` block of this line are held against).  Reported next to the GPU number; never shipped."""
+    from oracle.driver import NATIVE_FLAGS, PARITY_FLAGS
+    par, ref = _time_oracle(threads, False, 8.0, True)
+    out = dict(unit="Mdofs*steps/s", cores=threads, cpu_model=cpu_model(), kind="port",
+               value_parity_build=par["value"], flags_parity_build=PARITY_FLAGS)
+    try:
+        nat, _ = _time_oracle(threads, True, 8.0, False)
+        out.update(value=nat["value"], flags=NATIVE_FLAGS, seconds=nat["seconds"] + par["seconds"], rk4_steps=nat["rk4_steps"], h1_cg_iters=nat["h1_cg_iters"])
+        note = "%d steps in %.1f s with the -march=native build, %d in %.1f s with the parity build" % (nat["rk4_steps"], nat["seconds"], par["rk4_steps"], par["seconds"])
+    except Exception as e:  # no compiler on this host: the parity build's time stands in, and the line says so
+        out.update(value=par["value"], flags=PARITY_FLAGS, seconds=par["seconds"], rk4_steps=par["rk4_steps"], h1_cg_iters=par["h1_cg_iters"],
+                   native_build_error=repr(e)[:200])
+        note = "%d steps in %.1f s with the parity build (the -march=native build could not be made here)" % (par["rk4_steps"], par["seconds"])
+    out["sample"] = "RK4 steps from t=0 of the same 3D Sedov Q3Q2 32^3 problem (oracle/ C++ kernels, OpenMP %d threads): %s" % (threads, note)
+    return out, ref
 
 
 PARITY_STEPS = 3
@@ -499,18 +515,18 @@ LEGS = {
                workload="3D triple point -p 3 -m box01_hex -rs 4 -ok 5 -ot 4 -pa (65 536 zones, Q5/Q4; BASELINE config 5 on one GPU)"),
     "c2dev": dict(args=WORKLOADS["c2"][0], order=(3, 2), steps=10, warmup=300,
                   workload=WORKLOADS["c2"][1] + ", after 300 time steps (developed flow)"),
-    # configs[1] with the STORED mass table (LGH_MASS_RANK1=0): what a mesh whose initial zones are not affine, or a
-    # density that varies inside a zone, takes - the reference's data makes no such assumption (laghos_assembly.cpp:92-95)
-    "c2stored": dict(args=WORKLOADS["c2"][0], order=(3, 2), steps=10, warmup=3, env={"LGH_MASS_RANK1": "0"},
-                     workload=WORKLOADS["c2"][1] + ", stored mass quadrature table (general-mesh path, LGH_MASS_RANK1=0)"),
+    # configs[1] on the GENERAL-MESH path (round-5 verdict, item 6): the stored mass quadrature table (LGH_MASS_RANK1=0) AND
+    # Jac0inv per quadrature point (LGH_JAC0_COMPACT=0) - what a curved or graded initial mesh, or a density that varies inside
+    # a zone, takes; the reference's data makes neither assumption (laghos_assembly.cpp:92-95, laghos_solver.cpp:1243-1251)
+    "c2general": dict(args=WORKLOADS["c2"][0], order=(3, 2), steps=10, warmup=3, env={"LGH_MASS_RANK1": "0", "LGH_JAC0_COMPACT": "0"},
+                      workload=WORKLOADS["c2"][1] + ", general-mesh path: stored mass table, Jac0inv per point (LGH_MASS_RANK1=0 LGH_JAC0_COMPACT=0)"),
     "c2multi": dict(args=WORKLOADS["c2"][0], order=(3, 2), steps=10, warmup=3, force_multi=True,
                     workload=WORKLOADS["c2"][1] + ", N-rank code path on one rank (LGH_FORCE_MULTI=1, RCCL communicator of size 1)"),
-    # the stored-table twins of the N-rank and the HBM-resident legs (round-4 verdict, item 9): what the general-mesh path
-    # costs beyond configs[1]
-    "c2multistored": dict(args=WORKLOADS["c2"][0], order=(3, 2), steps=10, warmup=3, force_multi=True, env={"LGH_MASS_RANK1": "0"},
-                          workload=WORKLOADS["c2"][1] + ", N-rank code path on one rank, stored mass quadrature table"),
-    "c3stored": dict(args=WORKLOADS["c3"][0], order=(3, 2), steps=4, warmup=2, env={"LGH_MASS_RANK1": "0"},
-                     workload=WORKLOADS["c3"][1] + ", stored mass quadrature table (general-mesh path)"),
+    # the general-mesh twins of the N-rank and the HBM-resident legs
+    "c2multigeneral": dict(args=WORKLOADS["c2"][0], order=(3, 2), steps=10, warmup=3, force_multi=True, env={"LGH_MASS_RANK1": "0", "LGH_JAC0_COMPACT": "0"},
+                           workload=WORKLOADS["c2"][1] + ", N-rank code path on one rank, general-mesh path"),
+    "c3general": dict(args=WORKLOADS["c3"][0], order=(3, 2), steps=4, warmup=2, env={"LGH_MASS_RANK1": "0", "LGH_JAC0_COMPACT": "0"},
+                      workload=WORKLOADS["c3"][1] + ", general-mesh path: stored mass table, Jac0inv per point"),
     # configs[1] in the numbering the reference's operator API would hand over (round-5 verdict, item 1): every other leg runs
     # on this repository's own generator (nodes lexicographic, zones x-fastest).  c2mfem: MFEM's numbering of the same mesh
     # (`-renumber mfem`, laghos_amd/host/fem.cpp::MfemLikeNumbering: vertex / edge / face / interior dofs, zones in
@@ -575,7 +591,8 @@ def compact_line(full, detail_path=None):
         line["comm"] = {k: c[k] for k in c if k in ("halo_exchange", "allreduce", "neighbours", "largest_message_bytes_3_components",
                                                     "all_pairs_partition", "second_channel", "ranks")}
     if "cpu_baseline" in full:
-        line["cpu_baseline"] = _pick(full["cpu_baseline"], ("value", "unit", "cores", "kind", "sample", "cpu_model", "error"))
+        line["cpu_baseline"] = _pick(full["cpu_baseline"], ("value", "unit", "cores", "kind", "sample", "cpu_model", "flags", "value_parity_build", "flags_parity_build",
+                                                           "native_build_error", "error"))
     if "parity" in full:
         line["parity"] = _pick(full["parity"], ("pass", "rk4_steps", "e_norm_rel_diff", "dt_rel_diff", "state_x_max_rel_diff",
                                                 "state_v_max_rel_diff", "state_e_max_rel_diff", "tolerances", "error"))
@@ -633,7 +650,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="skip the extra legs (64^3 Sedov / Taylor-Green, Q5Q4, developed flow, N-rank path)")
-    ap.add_argument("--legs", default="c2mfem,c2perm,c3,tg,c5,c2dev,c2stored,c2multi,c2multistored,c3stored", help="comma-separated extra legs of a single-GPU run")
+    ap.add_argument("--legs", default="c2mfem,c2perm,c3,tg,c5,c2dev,c2general,c2multi,c2multigeneral,c3general", help="comma-separated extra legs of a single-GPU run")
     ap.add_argument("--transport", choices=("rccl", "shm"), default="rccl",
                     help="several ranks: rccl = the product transport (one GPU per rank, RCCL over xGMI); shm = the cross-process loopback "
                          "transport of lgh_comm.hip (ranks may share one GPU: the torchrun / id broadcast / N-rank code path on a one-GPU box)")

@@ -214,7 +214,9 @@ int lgh_vec_set(lgh_ctx *ctx, double *y, double a, long n);              /* y = 
 int lgh_vec_copy(lgh_ctx *ctx, double *y, const double *x, long n);      /* y = x */
 /* z1 = a1 x1 + b1 y and z2 = a2 x2 + b2 y in one pass over y: the two combinations an explicit RK stage forms from the same
  * increment k (upstream RK4Solver::Step: the next stage state and the running sum of the solution).  The same expressions
- * as lgh_vec_axpby - the same bits as two calls.  z2 may be x2; z1 and z2 must differ. */
+ * as lgh_vec_axpby - the same bits as two calls.  z1 may be x1 and z2 may be x2 (the very same vector); any other overlap
+ * between a result and an operand of the OTHER combination (z1 with z2, x2 or y; z2 with x1 or y) is refused with
+ * LGH_ERR_ARG: two sequential calls would see the first result, the fused pass would not. */
 int lgh_vec_axpby_pair(lgh_ctx *ctx, double *z1, double a1, const double *x1, double b1, double *z2, double a2, const double *x2, double b2,
                        const double *y, long n);
 int lgh_vec_axpby(lgh_ctx *ctx, double *z, double a, const double *x, double b,
@@ -407,6 +409,10 @@ int lgh_test_vcg_k2(lgh_ctx *ctx, int it, const double *y_E, double *r, double *
 int lgh_test_set_rank(lgh_ctx *ctx, int nranks, int rank);
 int lgh_test_halo_pack(lgh_ctx *ctx, const double *v_h1, int ncomp, double *sendbuf_out);
 int lgh_test_halo_combine(lgh_ctx *ctx, const double *recvbuf_in, double *v_h1, int ncomp);
+/* the peer buffer of the exact word exchange (the (r, z) accumulator words of the velocity CG on all-pairs partitions) as
+ * the solve would size it for `nwords` words per peer: *capacity_words = peers x nwords.  A second
+ * lgh_comm_set_neighbors with more neighbours must grow it (round-5 advisor). */
+int lgh_test_word_peers(lgh_ctx *ctx, int nwords, long *capacity_words);
 /* grouped ncclSend / ncclRecv of n doubles from this rank to itself on the RCCL communicator (what
  * halo_sum does with its neighbours); *max_abs_diff = max |received - sent| */
 int lgh_test_rccl_self_sendrecv(lgh_ctx *ctx, int n, double *max_abs_diff);

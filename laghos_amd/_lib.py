@@ -120,6 +120,7 @@ SYMBOLS = {
     "lgh_test_vcg_merged_faces": (_I, [_P, _P, ctypes.POINTER(ctypes.c_long)]),
     "lgh_test_vcg_k2": (_I, [_P, _I, _P, _P, _P, _P, c_dbl_p, c_dbl_p, c_dbl_p, c_dbl_p, c_dbl_p, ctypes.POINTER(ctypes.c_int)]),
     "lgh_test_set_rank": (_I, [_P, _I, _I]),
+    "lgh_test_word_peers": (_I, [_P, _I, ctypes.POINTER(ctypes.c_long)]),
     "lgh_test_halo_pack": (_I, [_P, _P, _I, _P]),
     "lgh_test_halo_combine": (_I, [_P, _P, _P, _I]),
     "lgh_test_rccl_self_sendrecv": (_I, [_P, _I, c_dbl_p]),

@@ -437,6 +437,11 @@ class Context:
         arr = (ip * max(n, 1))(*[l.ctypes.data_as(ip) for l in lists])
         check(self.lib.lgh_comm_set_neighbors(self.h, n, ranks.ctypes.data_as(ip), counts.ctypes.data_as(ip), arr))
 
+    def test_word_peers(self, nwords):
+        cap = ctypes.c_long(-1)
+        check(self.lib.lgh_test_word_peers(self.h, nwords, ctypes.byref(cap)))
+        return cap.value
+
     def test_set_rank(self, nranks, rank):
         check(self.lib.lgh_test_set_rank(self.h, nranks, rank))
 

@@ -8,6 +8,8 @@
 
 #include "lgh_common.hpp"
 
+#include <dlfcn.h>
+
 namespace lgh
 {
 
@@ -100,7 +102,9 @@ __global__ void __launch_bounds__(256) dt_est_set_k(double *p, double v)
 }
 // ... and the fold in front of every read: estimate = min(estimate, partial minima) in a fixed tree (a minimum does not
 // depend on the order anyway); the slots go back to +inf
-__global__ void __launch_bounds__(256) dt_est_fold_k(double *p)
+// host_out (pinned host memory as the device sees it): [0] the estimate, [1] the error word `err` - the host reads them
+// after the stream synchronisation it needs anyway, without two copy kernels in front of it
+__global__ void __launch_bounds__(256) dt_est_fold_k(double *p, const int *err, double *host_out, const unsigned long long token)
 {
    __shared__ double red[16];
    double m = __builtin_inf();
@@ -110,7 +114,15 @@ __global__ void __launch_bounds__(256) dt_est_fold_k(double *p)
       p[kDtSlotStride * (1 + s)] = __builtin_inf();
    }
    m = block_min(m, red);
-   if (threadIdx.x == 0) { p[0] = fmin(p[0], m); }
+   if (threadIdx.x == 0)
+   {
+      const double est = fmin(p[0], m);
+      p[0] = est;
+      host_out[0] = est;
+      ((int *)(host_out + 1))[0] = *err;
+      __threadfence_system();
+      __hip_atomic_store((unsigned long long *)(host_out + 2), token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); // (host_wait_token)
+   }
 }
 
 static int grid_for(long n) { return (int)std::min<long>(std::max<long>((n + 255) / 256, 1), 2048); }
@@ -196,6 +208,44 @@ void timer_stop(lgh_ctx *c, int which)
    c->timers.t[which] += 1e-3 * ms;
 }
 
+// ---- roctx ranges (LGH_ROCTX=1) ----------------------------------------------------------------
+namespace
+{
+struct Roctx
+{
+   int (*push)(const char *) = nullptr;
+   int (*pop)() = nullptr;
+   Roctx()
+   {
+      const char *env = getenv("LGH_ROCTX");
+      if (!(env && env[0] == '1')) { return; }
+      void *h = nullptr;
+      for (const char *n : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"})
+      {
+         h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+         if (h) { break; }
+      }
+      if (!h) { return; }
+      push = (int (*)(const char *))dlsym(h, "roctxRangePushA");
+      pop = (int (*)())dlsym(h, "roctxRangePop");
+      if (!push || !pop) { push = nullptr; pop = nullptr; }
+   }
+};
+const Roctx &roctx()
+{
+   static const Roctx r;
+   return r;
+}
+} // namespace
+RoctxRange::RoctxRange(const char *name) : on(roctx().push != nullptr)
+{
+   if (on) { (void)roctx().push(name); }
+}
+RoctxRange::~RoctxRange()
+{
+   if (on) { (void)roctx().pop(); }
+}
+
 template <typename T> static int dev_alloc_copy(T **dst, const T *src, size_t n)
 {
    LGH_HIP_CHECK(hipMalloc((void **)dst, std::max<size_t>(n, 1) * sizeof(T)));
@@ -221,6 +271,43 @@ static bool kernel_id_supported(int id)
          return true;
    }
    return false;
+}
+
+} // namespace lgh
+
+namespace lgh
+{
+int host_wait_token(lgh_ctx *c, volatile unsigned long long *word, const unsigned long long token)
+{
+   static const bool spin = !(getenv("LGH_SPIN") && getenv("LGH_SPIN")[0] == '0');
+   if (spin)
+   {
+      // ~2 ms of polling at most: a look normally returns within the tail of the last enqueued kernels
+      for (long i = 0; i < 4000000L; i++)
+      {
+         if (__atomic_load_n((const unsigned long long *)word, __ATOMIC_ACQUIRE) == token) { return LGH_OK; }
+         __builtin_ia32_pause();
+      }
+   }
+   LGH_HIP_CHECK(hipStreamSynchronize(c->stream));
+   if (__atomic_load_n((const unsigned long long *)word, __ATOMIC_ACQUIRE) != token) { set_error("host look: the finishing kernel did not report"); return LGH_ERR_HIP; }
+   return LGH_OK;
+}
+
+int energy_overlap_poll(lgh_ctx *c)
+{
+   if (c->e_async != 1 || c->e_polled) { return LGH_OK; }
+   int it = 0;
+   std::swap(c->stream, c->stream2);
+   c->on_stream2 = 1;
+   int rc = cg_l2_end(c, &it);
+   if (rc == LGH_OK) { rc = (hipEventRecord(c->ev_join, c->stream) == hipSuccess) ? LGH_OK : LGH_ERR_HIP; }
+   std::swap(c->stream, c->stream2);
+   c->on_stream2 = 0;
+   if (rc) { return rc; }
+   c->e_polled = 1;
+   c->e_iters = it;
+   return LGH_OK;
 }
 
 } // namespace lgh
@@ -261,6 +348,7 @@ int lgh_create(const lgh_config *cfg, lgh_ctx **out)
    }
    LGH_HIP_CHECK(hipSetDevice(cfg->device));
    // argument errors a caller can trigger are found before anything is allocated
+   LGH_CHECK_ARG(cfg->cfl > 0.0); // (the time-step estimate is a minimum over cfl / inv_dt >= 0, folded as such: lgh_qrows.hpp)
    for (size_t i = 0, n = (size_t)cfg->NE * (cfg->dim == 2 ? cfg->D1D * cfg->D1D : cfg->D1D * cfg->D1D * cfg->D1D); i < n; i++)
    {
       if (cfg->h1_map[i] < 0 || cfg->h1_map[i] >= cfg->N) { set_error("h1_map entry out of range"); return LGH_ERR_ARG; }
@@ -477,7 +565,9 @@ static int create_impl(const lgh_config *cfg, lgh_ctx *c, const int kid)
    LGH_TRY(dev_alloc_zero(&c->tickets, 4 * (size_t)kTicketSlot));
    LGH_TRY(dev_alloc_zero(&c->cgs, 1));
    LGH_TRY(dev_alloc_zero(&c->scal, 16));
-   LGH_HIP_CHECK(hipHostMalloc((void **)&c->host_pinned, 96 * sizeof(double), hipHostMallocDefault));
+   LGH_HIP_CHECK(hipHostMalloc((void **)&c->host_pinned, 96 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
+   memset(c->host_pinned, 0, 96 * sizeof(double));
+   LGH_HIP_CHECK(hipHostGetDevicePointer((void **)&c->host_pinned_dev, c->host_pinned, 0)); // (the one-thread kernels in front of a host look write there)
    LGH_HIP_CHECK(hipEventCreate(&c->timers.ev[0]));
    LGH_HIP_CHECK(hipEventCreate(&c->timers.ev[1]));
    {
@@ -652,11 +742,13 @@ int lgh_set_dt_est(lgh_ctx *c, double v)
 int lgh_get_dt_est(lgh_ctx *c, double *v)
 {
    LGH_CHECK_ARG(c && v);
-   hipLaunchKernelGGL(dt_est_fold_k, dim3(1), dim3(256), 0, c->stream, c->dt_est_dev);
+   const unsigned long long token = ++c->look_token;
+   hipLaunchKernelGGL(dt_est_fold_k, dim3(1), dim3(256), 0, c->stream, c->dt_est_dev, c->dev_flags + 4, c->host_pinned_dev + 8, token);
    LGH_HIP_CHECK(hipGetLastError());
-   LGH_HIP_CHECK(hipMemcpyAsync(c->host_pinned + 8, c->dt_est_dev, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-   LGH_HIP_CHECK(hipMemcpyAsync(c->host_pinned + 9, c->dev_flags + 4, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-   LGH_HIP_CHECK(hipStreamSynchronize(c->stream));
+   {
+      const int rc = host_wait_token(c, (volatile unsigned long long *)(c->host_pinned + 10), token);
+      if (rc) { return rc; }
+   }
    *v = c->host_pinned[8];
    if (*(const int *)(c->host_pinned + 9) != 0)
    {
@@ -739,6 +831,7 @@ int lgh_cg_solve(lgh_ctx *c, int space, const double *b, double *x, double rel_t
 int lgh_qupdate(lgh_ctx *c, const double *S)
 {
    LGH_CHECK_ARG(c && S);
+   RoctxRange range("QUpdate-UpdateQuadratureData"); // laghos_solver.cpp:1358
    timer_start(c);
    kt_begin(c, LGH_KERNEL_QUPDATE);
    int rc = qupdate(c, S);
@@ -812,6 +905,7 @@ int lgh_solve_velocity(lgh_ctx *c, const double *S, double *dS_dt, const double 
          if (rc) { return rc; }
       }
       int its[3] = {0, 0, 0};
+      RoctxRange range("SolveVelocity-CGVMass"); // laghos_solver.cpp:387-390 (here: with the E->L sum of F.1 and EliminateRHS in its first kernel)
       rc = vcg_solve(c, rhs_h1, dv, rel_tol, max_iter, its, force_E); // :358-388
       if (rc) { return rc; }
       for (int cc = 0; cc < dim; cc++)
@@ -824,6 +918,8 @@ int lgh_solve_velocity(lgh_ctx *c, const double *S, double *dS_dt, const double 
    }
    rc = vec_set(c, dv, 0.0, c->H1V); // dv = 0.0 (:338)
    if (rc) { return rc; }
+   {
+   RoctxRange range("SolveVelocity-ForcePA"); // laghos_solver.cpp:353-356
    timer_start(c);
    if (c->force_e_q && c->fused_f1_valid && is_the_one_vector(c, one_l2))
    {
@@ -839,6 +935,7 @@ int lgh_solve_velocity(lgh_ctx *c, const double *S, double *dS_dt, const double 
       if (rc == LGH_OK) { rc = lgh_force_mult(c, ones, rhs_h1); } // :354
    }
    timer_stop(c, 2);
+   }
    if (rc) { return rc; }
    rc = vec_neg_inplace(c, rhs_h1, c->H1V); // :358
    if (rc) { return rc; }
@@ -861,6 +958,7 @@ int lgh_solve_velocity(lgh_ctx *c, const double *S, double *dS_dt, const double 
          if (rc) { return rc; }
       }
       int its[3] = {0, 0, 0};
+      RoctxRange range("SolveVelocity-CGVMass"); // laghos_solver.cpp:387-390
       timer_start(c);
       rc = vcg_solve(c, rhs_h1, dv, rel_tol, max_iter, its); // :388 for all components
       if (rc == LGH_OK)
@@ -945,6 +1043,7 @@ __global__ void __launch_bounds__(256) copy_unless_k(double *__restrict__ y, con
 }
 static int energy_rhs(lgh_ctx *c, const double *v_h1, double *e_rhs)
 {
+   RoctxRange range("SolveEnergy-ForcePA"); // laghos_solver.cpp:472-475
    if (c->erhs_q && c->fused_ftv_valid)
    {
       int *flag = c->dev_flags + (c->on_stream2 ? 2 : 0);
@@ -986,6 +1085,7 @@ int lgh_solve_energy(lgh_ctx *c, const double *S, const double *v_h1, double *dS
       if (rc) { return rc; }
    }
    int it = 0;
+   RoctxRange range("SolveEnergy-CGEMass"); // laghos_solver.cpp:480-483
    timer_start(c);
    rc = cg_solve(c, LGH_SPACE_L2, e_rhs, de, rel_tol, max_iter, &it, true); // :481
    timer_stop(c, 1);
@@ -1032,11 +1132,16 @@ int lgh_solve_energy_begin(lgh_ctx *c, const double *S, const double *v_h1, doub
    c->on_stream2 = 1;
    int rc = energy_rhs(c, v_h1, e_rhs); // :473
    if (rc == LGH_OK && e_source) { rc = vec_axpby(c, e_rhs, 1.0, e_rhs, 1.0, e_source, c->L2V); } // :477
-   if (rc == LGH_OK) { rc = cg_l2_begin(c, e_rhs, dS_dt + 2 * (size_t)c->H1V, rel_tol, max_iter); } // :481
+   if (rc == LGH_OK)
+   {
+      RoctxRange range("SolveEnergy-CGEMass"); // laghos_solver.cpp:480-483 (first chunk, second stream)
+      rc = cg_l2_begin(c, e_rhs, dS_dt + 2 * (size_t)c->H1V, rel_tol, max_iter); // :481
+   }
    std::swap(c->stream, c->stream2);
    c->on_stream2 = 0;
    if (rc) { return rc; }
    c->e_async = 1;
+   c->e_polled = 0;
    return LGH_OK;
 }
 int lgh_solve_energy_end(lgh_ctx *c, int *l2_iters)
@@ -1044,6 +1149,16 @@ int lgh_solve_energy_end(lgh_ctx *c, int *l2_iters)
    LGH_CHECK_ARG(c && (c->e_async == 1 || c->e_async == 2));
    const int mode = c->e_async;
    c->e_async = 0;
+   if (mode == 1 && c->e_polled)
+   {
+      // completed from inside the velocity solve (energy_overlap_poll): only the join is left
+      c->e_polled = 0;
+      LGH_HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+      const int counted = (c->e_iters == 0) ? 1 : c->e_iters; // :486
+      c->timers.c[1] += counted;
+      if (l2_iters) { *l2_iters += counted; }
+      return LGH_OK;
+   }
    if (mode == 2)
    {
       return lgh_solve_energy(c, c->e_args.S, c->e_args.v, c->e_args.dS, c->e_args.e_rhs, c->e_args.src,
@@ -1079,7 +1194,14 @@ int lgh_vec_axpby(lgh_ctx *c, double *z, double a, const double *x, double b, co
 int lgh_vec_axpby_pair(lgh_ctx *c, double *z1, double a1, const double *x1, double b1, double *z2, double a2, const double *x2, double b2,
                        const double *y, long n)
 {
-   LGH_CHECK_ARG(c && z1 && x1 && z2 && x2 && y && z1 != z2);
+   LGH_CHECK_ARG(c && z1 && x1 && z2 && x2 && y && n >= 0);
+   // "the same bits as two lgh_vec_axpby calls" only holds when the first result is not an operand of the second: z1 must not
+   // overlap z2, x2 or y (round-5 advisor; z1 may be x1, z2 may be x2 - exact aliases, element i is read before it is written)
+   {
+      auto overlap = [n](const double *p, const double *q) { return p < q + n && q < p + n; };
+      LGH_CHECK_ARG(!overlap(z1, z2) && !overlap(z1, x2) && !overlap(z1, y));
+      LGH_CHECK_ARG(!overlap(z2, y) && !overlap(z2, x1) && (z2 == x2 || !overlap(z2, x2)) && (z1 == x1 || !overlap(z1, x1)));
+   }
    return vec_axpby_pair(c, z1, a1, x1, b1, z2, a2, x2, b2, y, n);
 }
 int lgh_vec_dot(lgh_ctx *c, const double *x, const double *y, long n, double *result)

@@ -302,7 +302,7 @@ struct Comm
    // exchange_words: the peers' accumulator words (n_nbr blocks of wordcap words), and where this rank's own words are
    // (the in-process transport copies device to device out of the peer's accumulators)
    long long *wordbuf = nullptr;
-   int wordcap = 0;
+   int wordcap = 0, wordnbr = 0; // words per peer and peers the buffer was allocated for
    const long long *word_src = nullptr;
    std::vector<long long> wstage;
 };
@@ -513,12 +513,14 @@ int comm_word_peers(lgh_ctx *c, int nwords, const long long **peers, int *n_peer
    *n_peers = 0;
    if (!cm || cm->n_nbr == 0) { return LGH_OK; } // (a communicator of size 1: nobody to hear from)
    if (!cm->allpairs) { set_error("comm_word_peers: all-pairs partitions only"); return LGH_ERR_ARG; }
-   if (cm->wordcap < nwords)
+   if (cm->wordcap != nwords || cm->wordnbr != cm->n_nbr) // (sized by BOTH factors)
    {
       if (cm->wordbuf) { (void)hipFree(cm->wordbuf); cm->wordbuf = nullptr; }
+      cm->wordcap = 0;
       LGH_HIP_CHECK(hipMalloc((void **)&cm->wordbuf, (size_t)cm->n_nbr * nwords * sizeof(long long)));
       LGH_HIP_CHECK(hipMemset(cm->wordbuf, 0, (size_t)cm->n_nbr * nwords * sizeof(long long)));
       cm->wordcap = nwords;
+      cm->wordnbr = cm->n_nbr;
    }
    *peers = cm->wordbuf;
    *n_peers = cm->n_nbr;
@@ -529,7 +531,7 @@ int exchange_words(lgh_ctx *c, const long long *src, int nwords)
 {
    Comm *cm = c->comm;
    if (!cm || cm->n_nbr == 0) { return LGH_OK; }
-   if (!cm->allpairs || !cm->wordbuf || cm->wordcap != nwords || c->on_stream2) { set_error("exchange_words: all-pairs partition, main channel, peer buffer of %d words", nwords); return LGH_ERR_ARG; }
+   if (!cm->allpairs || !cm->wordbuf || cm->wordcap != nwords || cm->wordnbr != cm->n_nbr || c->on_stream2) { set_error("exchange_words: all-pairs partition, main channel, peer buffer of %d words", nwords); return LGH_ERR_ARG; }
    KtScope sample(c, LGH_KERNEL_ALLREDUCE); // (counted with the small sums it replaces)
    const size_t bytes = (size_t)nwords * sizeof(long long);
    if (cm->local)
@@ -834,6 +836,11 @@ int lgh_comm_set_neighbors(lgh_ctx *c, int n_nbr, const int *nbr_rank, const int
          if (nbr_nodes[k][i] < 0 || nbr_nodes[k][i] >= c->N) { set_error("neighbour node out of range"); return LGH_ERR_ARG; }
       }
    }
+   // (the peer buffer of exchange_words is sized by the neighbour count: round-5 advisor - a second call with more
+   //  neighbours would otherwise leave the exchange writing behind a buffer of the old size)
+   if (cm->wordbuf) { (void)hipFree(cm->wordbuf); cm->wordbuf = nullptr; }
+   cm->wordcap = 0;
+   cm->word_src = nullptr;
    cm->n_nbr = n_nbr;
    cm->nbr_rank.assign(nbr_rank, nbr_rank + n_nbr);
    cm->nbr_count.assign(nbr_count, nbr_count + n_nbr);
@@ -985,6 +992,18 @@ int lgh_test_set_rank(lgh_ctx *c, int nranks, int rank)
    c->nranks = nranks;
    c->rank = rank;
    return LGH_OK;
+}
+int lgh_test_word_peers(lgh_ctx *c, int nwords, long *capacity_words)
+{
+   LGH_CHECK_ARG(c && nwords > 0 && capacity_words);
+   const long long *peers = nullptr;
+   int n_peers = 0;
+   const int rc = comm_word_peers(c, nwords, &peers, &n_peers);
+   if (rc) { return rc; }
+   const Comm *cm = c->comm;
+   *capacity_words = (cm && cm->wordbuf) ? (long)cm->wordnbr * cm->wordcap : 0;
+   if (peers) { LGH_HIP_CHECK(hipMemset((void *)peers, 0, (size_t)n_peers * nwords * sizeof(long long))); } // (writes the whole buffer: a short one faults here)
+   return (cm && cm->wordbuf && cm->wordnbr == n_peers && cm->wordcap == nwords) || n_peers == 0 ? LGH_OK : LGH_ERR_COMM;
 }
 int lgh_test_halo_pack(lgh_ctx *c, const double *v, int ncomp, double *out)
 {

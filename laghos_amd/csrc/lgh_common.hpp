@@ -103,6 +103,7 @@ struct lgh_ctx
    void *l2run;          // state of a split L2 solve (lgh_mass.hip)
    const double *accel_src; // dim*N acceleration source of SolveVelocity (source_type 2) or nullptr
    int e_async;          // 1: lgh_solve_energy_begin enqueued the solve, 2: deferred to _end
+   int e_polled, e_iters; // the enqueued solve has already been completed (energy_overlap_poll, from inside the velocity solve): its iteration count
    struct { const double *S, *v; double *dS, *e_rhs; const double *src; double tol; int maxit; } e_args;
    bool own_stream;
 
@@ -163,6 +164,9 @@ struct lgh_ctx
    lgh::CgScalars *cgs;  // device
    double *scal;         // small device scalar pool (16 doubles)
    double *host_pinned;  // pinned host staging, 64 doubles: [0..7] scalar CG / misc, [8] dt, [32..] lockstep CG scalars
+   unsigned long long look_token; // counts the host looks that wait for a token in pinned memory (host_wait_token)
+   double *host_pinned_dev; // the same memory as the device addresses it: scalars a host look needs are written there by the kernel that
+                            // finishes them (no copy kernel between it and the stream synchronisation)
 
    // lockstep velocity CG (lgh_vcg.hip), allocated on first use
    void *vcg_s;
@@ -477,6 +481,15 @@ int vcg_test_k2(lgh_ctx *c, int it, const double *YE_in, double *r, double *d, d
 int vcg_k1_form(lgh_ctx *c); // 0 column, 2 plane, 3 matrix cores, 4 slab, -1 none
 // multi-rank: flags / list of the nodes shared with other ranks (nullptr / 0 without neighbours)
 void comm_shared_nodes(const lgh_ctx *c, const uint8_t **hmask, const int **sh_node, int *n_shared);
+// Completes the energy solve that lgh_solve_energy_begin enqueued on the second stream - its host looks and, if it has not
+// converged, its further iterations - from INSIDE the velocity solve, while the main stream still has the velocity
+// solve's first chunk of iterations in front of it: lgh_solve_energy_end then only joins the streams (round 6: the looks of
+// the energy solve used to sit between the end of the velocity solve and the RK combination, with the GPU idle).
+int energy_overlap_poll(lgh_ctx *c);
+// Host look without a copy kernel and without the wake-up latency of a blocking stream synchronisation: the one-thread
+// kernel that finishes the scalars writes them, then `token`, into pinned host memory (a.k.a. host_pinned_dev); the host
+// spins on the token word (falls back to hipStreamSynchronize after a while; LGH_SPIN=0: always synchronise).
+int host_wait_token(lgh_ctx *c, volatile unsigned long long *word, unsigned long long token);
 int cg_l2_begin(lgh_ctx *c, const double *b, double *x, double rel_tol, int max_iter);
 int cg_l2_end(lgh_ctx *c, int *iters);
 void cg_l2_free(lgh_ctx *c);
@@ -546,5 +559,18 @@ struct KtScope
 
 void timer_start(lgh_ctx *c);
 void timer_stop(lgh_ctx *c, int which);
+// roctx range around a region of the host timeline, named after the reference's Caliper regions
+// (/root/reference/laghos_solver.cpp:353-356 "SolveVelocity-ForcePA", :387-390 "SolveVelocity-CGVMass", :472-475
+// "SolveEnergy-ForcePA", :480-483 "SolveEnergy-CGEMass", :1358 "QUpdate-UpdateQuadratureData"): a `rocprofv3 --marker-trace
+// --kernel-trace` run then attributes the kernels the way the reference's own profile does.  LGH_ROCTX=1 switches them on
+// (librocprofiler-sdk-roctx / libroctx64 resolved with dlopen: no link dependency, nothing happens without the variable).
+struct RoctxRange
+{
+   bool on;
+   explicit RoctxRange(const char *name);
+   ~RoctxRange();
+   RoctxRange(const RoctxRange &) = delete;
+   RoctxRange &operator=(const RoctxRange &) = delete;
+};
 
 } // namespace lgh

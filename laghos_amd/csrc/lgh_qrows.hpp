@@ -393,8 +393,11 @@ qrows_kernel(const QArgs a, unsigned long long *trace = nullptr)
       const double wmin = wave_min(cand, lane, nact);
       if (lane == 0 && wmin < __builtin_inf())
       {
+         // (unsigned order = numeric order only from +0.0 up: lgh_create refuses cfl <= 0, so a candidate is cfl / inv_dt >= 0 or
+         //  the 0 of an inverted zone; a -0.0 goes in as +0.0 - round-5 advisor)
+         const double w0 = (wmin > 0.0) ? wmin : 0.0;
          unsigned long long *slot = (unsigned long long *)(a.result + kDtSlotStride * (1 + (blockIdx.x % kDtSlots)));
-         (void)__hip_atomic_fetch_min(slot, (unsigned long long)__double_as_longlong(wmin), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+         (void)__hip_atomic_fetch_min(slot, (unsigned long long)__double_as_longlong(w0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
    }
    if (TRACE && lt == 0 && trace)

@@ -53,7 +53,8 @@ int setup_rho0detj0(lgh_ctx *c, const double *x0, const double *rho0_l2, const d
       int *flag = c->dev_flags + 5, h = 1;
       LGH_HIP_CHECK(hipMemsetAsync(flag, 0, sizeof(int), c->stream));
       hipLaunchKernelGGL(jac0_compact_k, dim3(ceil_div(c->NE, 64)), dim3(64), 0, c->stream, c->NE, c->NQ, c->dim * c->dim, c->Jac0inv_soa,
-                         tenv ? atof(tenv) : kJac0Tol, c->Jac0inv_e, flag);
+                         // (a tolerance above 1e-10 would turn curved zones into affine ones: clamped - round-5 advisor)
+                         tenv ? std::min(std::max(atof(tenv), 0.0), 1e-10) : kJac0Tol, c->Jac0inv_e, flag);
       LGH_HIP_CHECK(hipGetLastError());
       LGH_HIP_CHECK(hipMemcpyAsync(&h, flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
       LGH_HIP_CHECK(hipStreamSynchronize(c->stream));

@@ -941,10 +941,30 @@ vcg_apply_kron(const VcgArgs a)
 __device__ __forceinline__ double vcg_ld(const double *base, const unsigned off) { return *(const double *)((const char *)base + off); }
 __device__ __forceinline__ double *vcg_ptr(double *base, const unsigned off) { return (double *)((char *)base + off); }
 
+// a.reset: the first kernel of a solve does what vcg_set_tol_k did in a launch of its own in front of it (round 6: one
+// kernel boundary and a serial one-thread loop over ~400 words less per solve).  Workgroup 0 clears the exact accumulators
+// and the set counters (nobody touches them before K1 of the first iteration); the thread that writes the scalars of the
+// solve resets them first.
+__device__ __forceinline__ void vcg_reset_accumulators(const VcgArgs &a)
+{
+   if (!a.reset || blockIdx.x != 0) { return; }
+   if (a.limbs) { for (int i = threadIdx.x; i < 2 * kLimbWords + 8 * 16; i += blockDim.x) { a.limbs[i] = 0; } }
+   if (a.rzl) { for (int i = threadIdx.x; i < 3 * kLimbWords; i += blockDim.x) { a.rzl[i] = 0; } }
+}
+__device__ __forceinline__ void vcg_reset_scalars(const VcgArgs &a, VcgScalars *s)
+{
+   if (!a.reset) { return; }
+   s->rel_tol2 = a.reset_tol2;
+   s->all_done = 0;
+   s->first = 1;
+   for (int c = 0; c < kVC; c++) { s->done[c] = 0; s->iters[c] = 0; s->nupd[c] = 0; s->alpha_last[c] = 0.0; s->alpha_hist[0][c] = s->alpha_hist[1][c] = 0.0; s->rzh[0][c] = s->rzh[1][c] = 0.0; }
+}
+
 // ---- init: r = b (x = 0), z = r/diag, nom_c = (z_c, r_c)
 __global__ void __launch_bounds__(256)
 vcg_init_k(const VcgArgs a)
 {
+   vcg_reset_accumulators(a);
    __shared__ double red[48];
    const int n = xcd_swizzle(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x; // as K2 and vcg_init_force_k
    double part[kVC] = {0.0, 0.0, 0.0};
@@ -969,6 +989,7 @@ vcg_init_k(const VcgArgs a)
       {
          VcgScalars *s = a.s;
          int all = 1;
+         vcg_reset_scalars(a, s);
          for (int c = 0; c < kVC; c++)
          {
             s->rz[c] = s->rz_prev[c] = total[c];
@@ -996,6 +1017,7 @@ template <int DEG>
 __global__ void __launch_bounds__(256)
 vcg_init_force_k(const VcgArgs a, const double *__restrict__ FE, const int ND, double *__restrict__ bout, const int *__restrict__ ellc, const int degc)
 {
+   vcg_reset_accumulators(a);
    __shared__ double red[48];
    const int n = xcd_swizzle(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x; // node ranges of vcg_init_k: same partial sums
    double part[kVC] = {0.0, 0.0, 0.0};
@@ -1033,6 +1055,7 @@ vcg_init_force_k(const VcgArgs a, const double *__restrict__ FE, const int ND, d
       {
          VcgScalars *s = a.s;
          int all = 1;
+         vcg_reset_scalars(a, s);
          for (int c = 0; c < kVC; c++)
          {
             s->rz[c] = s->rz_prev[c] = total[c];
@@ -1053,6 +1076,7 @@ __global__ void __launch_bounds__(256)
 vcg_init_force_z_k(const VcgArgs a, const double *__restrict__ FE, const unsigned compb_fe, const unsigned *__restrict__ ellf,
                    double *__restrict__ bout)
 {
+   vcg_reset_accumulators(a);
    __shared__ double red[48];
    const int n = xcd_swizzle(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
    const bool ok = n < a.N;
@@ -1105,6 +1129,7 @@ vcg_init_force_z_k(const VcgArgs a, const double *__restrict__ FE, const unsigne
       {
          VcgScalars *s = a.s;
          int all = 1;
+         vcg_reset_scalars(a, s);
          for (int c = 0; c < kVC; c++)
          {
             s->rz[c] = s->rz_prev[c] = total[c];
@@ -1172,7 +1197,7 @@ __global__ void vcg_set_tol_k(VcgScalars *s, double rel_tol2, long long *limbs, 
 // component done (vcg_pending_update / vcg_pending_den inside the kernels, this kernel before the host
 // looks) therefore zeroes its scalars: sums of zeros stay zero.  den[c] and rz[c] are undefined (0) once
 // done[c] is set; nothing reads them after that.
-__global__ void vcg_update_finish_k(VcgScalars *s, int iter)
+__global__ void vcg_update_finish_k(VcgScalars *s, int iter, VcgScalars *host_out, unsigned long long *host_token, const unsigned long long token)
 {
    int all = 1;
    for (int c = 0; c < kVC; c++)
@@ -1186,11 +1211,18 @@ __global__ void vcg_update_finish_k(VcgScalars *s, int iter)
       all = all && s->done[c];
    }
    s->all_done = all;
+   if (host_out) // (the host looks next: straight into its pinned memory, the token last)
+   {
+      *host_out = *s;
+      __threadfence_system();
+      __hip_atomic_store(host_token, token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+   }
 }
 
 // rz_limbs mode: the outcome of the last enqueued iteration `last`, committed for the host (what workgroup 0 of
-// K1(last + 1) would write)
-__global__ void vcg_rz_finish_k(VcgScalars *s, const long long *rzl, const int last, const long long *peers, const int n_peers)
+// K1(last + 1) would write); host_out: pinned host memory the host reads after its stream synchronisation (nullptr: test hook)
+__global__ void vcg_rz_finish_k(VcgScalars *s, const long long *rzl, const int last, const long long *peers, const int n_peers, VcgScalars *host_out,
+                                unsigned long long *host_token, const unsigned long long token)
 {
    // several ranks: own words + the peers' (exchange_words) = the sum over the ranks; folded into a scratch set - the
    // flag word rides along (any rank's overflow turns the sum into NaN on every rank)
@@ -1210,6 +1242,12 @@ __global__ void vcg_rz_finish_k(VcgScalars *s, const long long *rzl, const int l
       dn[k] = s->done[k] != 0 || vcg_rz_converged(last + 1, cur[k], s->r0[k]);
    }
    vcg_rz_commit(s, last + 1, cur, dn);
+   if (host_out)
+   {
+      *host_out = *s;
+      __threadfence_system();
+      __hip_atomic_store(host_token, token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+   }
 }
 
 // ---- K2: per node and component: A d = sum of element contributions, ess rows,
@@ -1903,6 +1941,7 @@ struct VcgAux
    int grid2 = 0;
    // merged E-vector layout of the slab K1 (slab_merge_layout): its set table and the tables of K2 for that layout
    int rz_words_all = -1;      // several ranks: every rank can exchange (r, z) as accumulator words (-1: not asked yet)
+   int rz_words_key = -1;      // ... and the local inputs of that question at the time it was asked
    unsigned *settab = nullptr;
    int *ellm = nullptr;
    int degm = 0;
@@ -2217,7 +2256,9 @@ static int vcg_build_internal_tables(lgh_ctx *c, VcgAux *x)
    return LGH_OK;
 }
 
-static int vcg_prepare(lgh_ctx *c, double *B, double *X, double rel_tol, VcgPlan &plan)
+// in_solve: the call comes from vcg_solve, which every rank enters together - only there may a collective run (the decision
+// below); the statistics and test entry points take the conservative answer until a solve has decided (round-5 advisor)
+static int vcg_prepare(lgh_ctx *c, double *B, double *X, double rel_tol, VcgPlan &plan, const bool in_solve = false)
 {
    const bool multi = c->multi != 0;
    const size_t N = (size_t)c->N;
@@ -2339,8 +2380,13 @@ static int vcg_prepare(lgh_ctx *c, double *B, double *X, double rel_tol, VcgPlan
       // Which exchange follows K2 - accumulator words or three doubles - must be the same on every rank, and whether a rank
       // CAN use the words depends on its own kernels (the slab K1 is dispatched by the rank's zone count): decided
       // collectively, once per set of tables (a MIN over the ranks; every rank builds its tables in its first solve)
-      if (aux->rz_words_all < 0)
+      // (what this rank can do depends on switches that may be flipped between solves: the answer is cached with them)
+      const int key = (rz_words ? 1 : 0) | (c->slab_exact ? 2 : 0) | ((c->vcg_variant & 0xff) << 2) | (k1form << 10);
+      if (aux->rz_words_key != key) { aux->rz_words_all = -1; }
+      if (aux->rz_words_all < 0 && !in_solve) { rz_words = false; }
+      else if (aux->rz_words_all < 0)
       {
+         aux->rz_words_key = key;
          const double mine = rz_words ? 1.0 : 0.0;
          LGH_HIP_CHECK(hipStreamSynchronize(c->stream));
          LGH_HIP_CHECK(hipMemcpy(c->scal + 12, &mine, sizeof(double), hipMemcpyHostToDevice)); // (pageable host memory: synchronous copies)
@@ -2358,7 +2404,9 @@ static int vcg_prepare(lgh_ctx *c, double *B, double *X, double rel_tol, VcgPlan
       const char *e0 = getenv("LGH_SLAB_DEFER");
       if (e0 && e0[0] == '0') { rzl = nullptr; } // (needs the deferred fold of (d, A d) as well)
    }
-   hipLaunchKernelGGL(vcg_set_tol_k, dim3(1), dim3(1), 0, c->stream, ds, rel_tol * rel_tol, limbs, rzl);
+   // (a solve resets its scalars and accumulators in its first kernel: a.reset below; the hooks and statistics entry points,
+   //  which launch single kernels on state of their own, keep the separate launch)
+   if (!in_solve) { hipLaunchKernelGGL(vcg_set_tol_k, dim3(1), dim3(1), 0, c->stream, ds, rel_tol * rel_tol, limbs, rzl); }
 
    VcgArgs a;
    memset(&a, 0, sizeof(a));
@@ -2433,6 +2481,8 @@ static int vcg_prepare(lgh_ctx *c, double *B, double *X, double rel_tol, VcgPlan
    }
    a.limbs = limbs;
    a.rzl = rzl;
+   a.reset = in_solve ? 1 : 0;
+   a.reset_tol2 = rel_tol * rel_tol;
    if (rzl && multi)
    {
       rc = comm_word_peers(c, kLimbWords, &a.rzl_peers, &a.n_rz_peers);
@@ -2543,7 +2593,7 @@ int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
 {
    if (!vcg_supported(c)) { return LGH_ERR_UNSUPPORTED; }
    VcgPlan plan;
-   int rc = vcg_prepare(c, B, X, rel_tol, plan);
+   int rc = vcg_prepare(c, B, X, rel_tol, plan, true);
    if (rc) { return rc; }
    VcgArgs &a = plan.a;
    VcgAux *aux = plan.aux;
@@ -2582,6 +2632,7 @@ int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
    VcgScalars *hs = (VcgScalars *)(c->host_pinned + 32);
    static_assert(sizeof(VcgScalars) <= 64 * sizeof(double), "pinned staging too small");
    int it = 0;
+   bool energy_polled = false;
    // first chunk = iteration count of the previous velocity solve (see cg_solve)
    int chunk = c->vcg_last > 0 ? c->vcg_last : 8;
    bool first_look = true;
@@ -2593,10 +2644,30 @@ int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
       if (!first_look || max_iter <= 0)
       {
          // several ranks: the outcome of the last enqueued update is still pending (vcg_pending_update) - commit it
-         if (multi && !a.rzl && it > 0) { hipLaunchKernelGGL(vcg_update_finish_k, dim3(1), dim3(1), 0, c->stream, ds, it); }
-         if (a.rzl && it > 0) { hipLaunchKernelGGL(vcg_rz_finish_k, dim3(1), dim3(1), 0, c->stream, ds, a.rzl, it, a.rzl_peers, a.n_rz_peers); }
-         LGH_HIP_CHECK(hipMemcpyAsync(hs, ds, sizeof(VcgScalars), hipMemcpyDeviceToHost, c->stream));
-         LGH_HIP_CHECK(hipStreamSynchronize(c->stream));
+         // (the one-thread kernel that commits the outcome also puts the scalars into the host's pinned memory: no copy
+         //  kernel between it and the synchronisation)
+         VcgScalars *hs_dev = (VcgScalars *)(c->host_pinned_dev + 32);
+         unsigned long long *tok_dev = (unsigned long long *)(c->host_pinned_dev + 80);
+         volatile unsigned long long *tok = (volatile unsigned long long *)(c->host_pinned + 80);
+         const unsigned long long token = ++c->look_token;
+         bool copied = false;
+         // the first look of a solve comes after a whole chunk of iterations: the energy solve on the second stream is
+         // brought to its end meanwhile (its looks used to wait behind the velocity solve, with the GPU idle)
+         if (!energy_polled) { rc = energy_overlap_poll(c); energy_polled = true; if (rc) { return rc; } }
+         if (multi && !a.rzl && it > 0) { hipLaunchKernelGGL(vcg_update_finish_k, dim3(1), dim3(1), 0, c->stream, ds, it, hs_dev, tok_dev, token); copied = true; }
+         if (a.rzl && it > 0) { hipLaunchKernelGGL(vcg_rz_finish_k, dim3(1), dim3(1), 0, c->stream, ds, a.rzl, it, a.rzl_peers, a.n_rz_peers, hs_dev, tok_dev, token); copied = true; }
+         if (copied)
+         {
+            // (on several ranks the exchanges that follow are host-synchronous on the loopback transports and enqueue-only over
+            //  RCCL: either way nothing of this rank is in flight behind the finishing kernel)
+            rc = host_wait_token(c, tok, token);
+            if (rc) { return rc; }
+         }
+         else
+         {
+            LGH_HIP_CHECK(hipMemcpyAsync(hs, ds, sizeof(VcgScalars), hipMemcpyDeviceToHost, c->stream));
+            LGH_HIP_CHECK(hipStreamSynchronize(c->stream));
+         }
          if (hs->all_done || it >= max_iter) { break; }
          chunk = 2;
       }
@@ -2985,7 +3056,7 @@ int vcg_test_k2(lgh_ctx *c, int it, const double *YE_in, double *r, double *d, d
    else if (c->t_deg <= 8) { hipLaunchKernelGGL((vcg_update_k<true, 8>), dim3(ceil_div((long)N, 256)), dim3(256), 0, c->stream, a); }
    else { set_error("lgh_test_vcg_k2: unusual valence (the unfused gather runs in the solve)"); return LGH_ERR_UNSUPPORTED; }
    LGH_HIP_CHECK(hipGetLastError());
-   if (a.rzl && plan.k2p) { hipLaunchKernelGGL(vcg_rz_finish_k, dim3(1), dim3(1), 0, c->stream, ds, a.rzl, it, (const long long *)nullptr, 0); }
+   if (a.rzl && plan.k2p) { hipLaunchKernelGGL(vcg_rz_finish_k, dim3(1), dim3(1), 0, c->stream, ds, a.rzl, it, (const long long *)nullptr, 0, (VcgScalars *)nullptr, (unsigned long long *)nullptr, 0ull); }
    LGH_HIP_CHECK(hipGetLastError());
    LGH_HIP_CHECK(hipStreamSynchronize(c->stream));
    LGH_HIP_CHECK(hipMemcpy(&h, ds, sizeof(h), hipMemcpyDeviceToHost));

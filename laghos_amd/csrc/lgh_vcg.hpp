@@ -205,6 +205,8 @@ struct VcgArgs
    int deg;
    const uint8_t *ess[kVC];
    const double *dinv, *owner;
+   int reset;             // the first kernel of a solve (vcg_init_*) also does what vcg_set_tol_k did in front of it: clears the exact accumulators
+   double reset_tol2;     // and the set counters (workgroup 0) and resets the scalars of the solve with rel_tol^2 = reset_tol2 (the thread that writes them)
    const int *ncaller;    // the solve runs in the library's own node numbering (lgh_order.hip): internal node m is the caller's node ncaller[m] - the
                           // caller's vectors (b in, the right-hand side and x out) are indexed through it; nullptr: the caller's numbering is the solve's
    const double *b;       // kVC*N right-hand sides (byNODES)

@@ -33,28 +33,48 @@ def build(force=False):
     return so
 
 
-def lib():
-    global _LIB
+_LIB_NATIVE = None
+PARITY_FLAGS = "-O3 -march=x86-64-v3 -fopenmp -fno-fast-math -ffp-contract=off"   # oracle/Makefile CXXFLAGS: the checker
+NATIVE_FLAGS = "-O3 -march=native -fopenmp -fno-fast-math -ffp-contract=fast"     # oracle/Makefile NATIVEFLAGS: timing only
+
+
+def build_native():
+    """The timing build of the same source (`make native`: -march=native, FMA contraction), compiled on the machine that
+    runs it - bench.py's cpu_baseline only; never the checker."""
+    so = os.path.join(_HERE, "_build", "liblaghos_oracle_native.so")
+    subprocess.check_call(["make", "-C", _HERE, "native"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib(native=False):
+    global _LIB, _LIB_NATIVE
+    if native:
+        if _LIB_NATIVE is None:
+            _LIB_NATIVE = _bind(ctypes.CDLL(build_native()))
+        return _LIB_NATIVE
     if _LIB is None:
-        _LIB = ctypes.CDLL(build())
-        L = _LIB
-        L.lgo_create.restype = ctypes.c_void_p
-        for name in ("lgo_stressJinvT", "lgo_Jac0inv", "lgo_rho0DetJ0w", "lgo_massD", "lgo_diagV",
-                     "lgo_q_dx", "lgo_q_dv", "lgo_q_e"):
-            getattr(L, name).restype = c_dp
-            getattr(L, name).argtypes = [ctypes.c_void_p]
-        for name in ("lgo_get_h0", "lgo_get_dt_est"):
-            getattr(L, name).restype = ctypes.c_double
-            getattr(L, name).argtypes = [ctypes.c_void_p]
-        L.lgo_set_h0.argtypes = [ctypes.c_void_p, ctypes.c_double]
-        L.lgo_set_dt_est.argtypes = [ctypes.c_void_p, ctypes.c_double]
-        L.lgo_setup_rho0detj0.restype = ctypes.c_double
-        L.lgo_internal_energy.restype = ctypes.c_double
-        L.lgo_kinetic_energy.restype = ctypes.c_double
-        L.lgo_sv3.restype = ctypes.c_double
-        L.lgo_sv2.restype = ctypes.c_double
-        L.lgo_cg.restype = ctypes.c_int
+        _LIB = _bind(ctypes.CDLL(build()))
     return _LIB
+
+
+def _bind(L):
+    L.lgo_create.restype = ctypes.c_void_p
+    for name in ("lgo_stressJinvT", "lgo_Jac0inv", "lgo_rho0DetJ0w", "lgo_massD", "lgo_diagV",
+                 "lgo_q_dx", "lgo_q_dv", "lgo_q_e"):
+        getattr(L, name).restype = c_dp
+        getattr(L, name).argtypes = [ctypes.c_void_p]
+    for name in ("lgo_get_h0", "lgo_get_dt_est"):
+        getattr(L, name).restype = ctypes.c_double
+        getattr(L, name).argtypes = [ctypes.c_void_p]
+    L.lgo_set_h0.argtypes = [ctypes.c_void_p, ctypes.c_double]
+    L.lgo_set_dt_est.argtypes = [ctypes.c_void_p, ctypes.c_double]
+    L.lgo_setup_rho0detj0.restype = ctypes.c_double
+    L.lgo_internal_energy.restype = ctypes.c_double
+    L.lgo_kinetic_energy.restype = ctypes.c_double
+    L.lgo_sv3.restype = ctypes.c_double
+    L.lgo_sv2.restype = ctypes.c_double
+    L.lgo_cg.restype = ctypes.c_int
+    return L
 
 
 def _dp(a):
@@ -74,9 +94,9 @@ ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_double, ctypes.c_double, ctypes.c_int, 
 class Hydro:
     """The oracle's LagrangianHydroOperator (PA branch, dim >= 2)."""
 
-    def __init__(self, prob: Problem, cfl=0.5, cg_tol=1e-8, cg_max_iter=300, comm=None):
+    def __init__(self, prob: Problem, cfl=0.5, cg_tol=1e-8, cg_max_iter=300, comm=None, native=False):
         self.p = prob
-        self.L = L = lib()
+        self.L = L = lib(native)  # native: the timing build (bench.py's cpu_baseline), never the checker
         self.cg_tol, self.cg_max_iter = cg_tol, cg_max_iter
         self.comm = comm
         S, rho_l2, gamma, rho0_q = prob.initial_state()

@@ -457,6 +457,30 @@ def test_halo_logic_emulated_ranks(pgrid):
         c.close()
 
 
+def test_word_exchange_buffer_follows_the_neighbour_count():
+    """lgh_comm_set_neighbors called again with MORE neighbours on the same context (a re-partition): the peer buffer of the
+    exact word exchange (n_nbr x nwords) must grow with it (round-5 advisor: it was only re-allocated when nwords grew, and the
+    exchange then wrote behind it)."""
+    from laghos_amd.context import Context
+    from oracle.fem import Problem
+    p = Problem(mesh="cube01_hex", rs=1, order_v=2, order_e=1, problem=1)
+    _, _, gamma, _ = p.initial_state()
+    c = Context(p.dim, p.NE, p.D1D, p.Q1D, p.L1D, p.N, p.h1map, p.B, p.G, p.Bl, p.W, gamma, p.ess, order_v=p.order_v)
+    try:
+        c.test_set_rank(2, 0)
+        c.comm_set_neighbors([1], [np.arange(5, dtype=np.int32)])
+        assert c.test_word_peers(56) == 56
+        c.test_set_rank(8, 0)
+        c.comm_set_neighbors(list(range(1, 8)), [np.arange(3, dtype=np.int32)] * 7)
+        assert c.test_word_peers(56) == 7 * 56
+        assert c.test_word_peers(60) == 7 * 60
+        c.test_set_rank(2, 0)
+        c.comm_set_neighbors([1], [np.arange(5, dtype=np.int32)])
+        assert c.test_word_peers(60) == 60
+    finally:
+        c.close()
+
+
 MULTI_RANK_CASES = [
     # (ranks, zones, problem, region timers, (ok, ot), environment)
     (2, (8, 8, 8), 1, 1, (3, 2), {}), (8, (8, 8, 8), 1, 1, (3, 2), {}), (3, (9, 6, 6), 1, 1, (3, 2), {}),
