@@ -1313,6 +1313,7 @@ int cg_solve(lgh_ctx *c, int space, const double *b, double *x, double rel_tol, 
    int chunk = last > 0 ? last : 8;
    bool done = false;
    bool first_look = true;
+   int looks = 0;
    while (!done)
    {
       // several ranks: the outcome of the last enqueued update is still pending (cg_pending_update) - commit it
@@ -1320,7 +1321,10 @@ int cg_solve(lgh_ctx *c, int space, const double *b, double *x, double rel_tol, 
       LGH_HIP_CHECK(hipMemcpyAsync(hs, c->cgs, sizeof(CgScalars), hipMemcpyDeviceToHost, c->stream));
       LGH_HIP_CHECK(hipStreamSynchronize(c->stream));
       if (hs->done || it >= max_iter) { break; }
-      if (!first_look) { chunk = 2; }
+      // after the first chunk (the previous solve's count): two more iterations per look while the count only creeps, then
+      // doubling - a solve whose count jumps (the unpreconditioned L2 CG of the first steps at order 4: 225 -> 300) must not pay
+      // a host look every two iterations (round 6: 149 looks per RK step at config 5); launches past convergence return at once
+      if (!first_look) { chunk = (++looks <= 2) ? 2 : std::min(64, 2 * chunk); }
       first_look = false;
       const int upto = std::min(max_iter, it + chunk);
       for (; it < upto;)
@@ -1472,13 +1476,15 @@ int cg_l2_end(lgh_ctx *c, int *iters)
    L2Run *r = (L2Run *)c->l2run;
    if (!r || !r->active) { return LGH_ERR_ARG; }
    CgScalars *hs = (CgScalars *)c->host_pinned;
+   int looks = 0, chunk = 2;
    while (true)
    {
       if (r->m.multi && r->it > 0) { hipLaunchKernelGGL(cg_update_finish_k, dim3(1), dim3(1), 0, c->stream, c->cgs, r->it); } // as cg_solve
       LGH_HIP_CHECK(hipMemcpyAsync(hs, c->cgs, sizeof(CgScalars), hipMemcpyDeviceToHost, c->stream));
       LGH_HIP_CHECK(hipStreamSynchronize(c->stream));
       if (hs->done || r->it >= r->max_iter) { break; }
-      const int rc = l2_enqueue(c, r, std::min(r->max_iter, r->it + 2));
+      chunk = (++looks <= 2) ? 2 : std::min(64, 2 * chunk); // (as cg_solve: a count that jumps is not chased two iterations at a time)
+      const int rc = l2_enqueue(c, r, std::min(r->max_iter, r->it + chunk));
       if (rc) { return rc; }
    }
    int fin = hs->iters;

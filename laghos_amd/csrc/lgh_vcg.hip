@@ -2631,7 +2631,7 @@ int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
 
    VcgScalars *hs = (VcgScalars *)(c->host_pinned + 32);
    static_assert(sizeof(VcgScalars) <= 64 * sizeof(double), "pinned staging too small");
-   int it = 0;
+   int it = 0, looks = 0;
    bool energy_polled = false;
    // first chunk = iteration count of the previous velocity solve (see cg_solve)
    int chunk = c->vcg_last > 0 ? c->vcg_last : 8;
@@ -2669,7 +2669,7 @@ int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
             LGH_HIP_CHECK(hipStreamSynchronize(c->stream));
          }
          if (hs->all_done || it >= max_iter) { break; }
-         chunk = 2;
+         chunk = (++looks <= 2) ? 2 : std::min(64, 2 * chunk); // (as cg_solve, lgh_mass.hip)
       }
       first_look = false;
       const int upto = std::min(max_iter, it + chunk);

@@ -8,7 +8,7 @@ f = glob.glob(os.path.join(sys.argv[1], "**", "*kernel_trace.csv"), recursive=Tr
 rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "").replace("lgh::", "")[:34]) for r in csv.DictReader(open(f))]
 rows.sort()
 # steady state: between the 2nd and the last qrows update of the final third
-q = [i for i, r in enumerate(rows) if r[2].startswith("qrows_kernel")]
+q = [i for i, r in enumerate(rows) if r[2].startswith(("qrows_kernel", "qpoint_kernel<3, 6, 10, 5, 1, 6, 0"))]
 q = q[len(q) * 2 // 3:]
 q = q[: (len(q) // 4) * 4 + 1]           # whole RK4 steps (4 updates each; the dt estimate comes out of the 4th stage's data)
 a, b = q[0], q[-1]
