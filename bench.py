@@ -373,7 +373,7 @@ def kernel_sources_sha():
     return h.hexdigest()[:16]
 
 
-PMC_FILE = "r5_pmc_traffic.json"
+PMC_FILE = "r6_pmc_traffic.json"
 
 
 def pmc_traffic(workload, kernel):

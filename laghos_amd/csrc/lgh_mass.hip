@@ -53,6 +53,11 @@ struct MassArgs
    unsigned int *ticket;
    int multi; // multi-GPU: den is all-reduced before any decision is taken on it
    int iter;  // CG iteration this launch belongs to (several ranks: see cg_pending_update)
+   // mass_apply_l2_kron, fused update of the energy CG (round 6): MODE 3 with no_y does not store M d - MODE 4, the update of the
+   // same iteration, forms it again from d (the L2 mass matrix is block diagonal: M d of a zone needs that zone's d only) and
+   // updates ux (x) and ur (r) with it: ten vector passes per iteration become eight
+   int no_y;
+   double *ux, *ur;
 };
 
 // Several ranks: the sums of den and (r, z) over the ranks complete outside the kernels that produce the
@@ -622,7 +627,10 @@ static int unknown_kernel(int id)
 // element's L^3 dofs - 3 L^4 FMAs instead of ~2 (L^3 Q + L^2 Q^2 + L Q^3) + Q^3 through the quadrature points (L = 5,
 // Q = 10: 1 875 against 18 500) and no quadrature-point values at all: the kernel moves its vectors and nothing else.
 // Same operator in exact arithmetic (the compact form itself is accepted to 1e-12, mass_data); rounding differs.
-// MODE 0: y = M x.  MODE 3: CG K1 of the L2 solve (d = r + beta d stored in place, den = (d, M d)), as the plane form.
+// MODE 0: y = M x.  MODE 3: CG K1 of the L2 solve (d = r + beta d stored in place, den = (d, M d)), as the plane form; with
+// a.no_y the product itself is not stored.  MODE 4 (round 6): the UPDATE of the same iteration, for the launch after it -
+// M d is formed again from the stored d (same code, same bits) and x += alpha d, r -= alpha M d, (r, r) follow with the
+// expressions, the scalars and the convergence logic of cg_update_k: the product never travels through memory.
 // One workgroup of 256 threads takes NEB consecutive elements (their dofs are one contiguous run of the L2 vector);
 // a thread owns one row of L values per stage: x rows (e, lz, ly), y rows (e, lz, lx), z rows (e, ly, lx).
 template <int L, int NEB, int MODE>
@@ -635,7 +643,7 @@ mass_apply_l2_kron(const MassArgs a)
    const int tid = threadIdx.x;
    const int e0 = blockIdx.x * NEB;
    const int nel = min(NEB, a.NE - e0);
-   double beta = 0.0;
+   double beta = 0.0, alpha = 0.0;
    bool first = false;
    if (MODE == 3)
    {
@@ -644,13 +652,39 @@ mass_apply_l2_kron(const MassArgs a)
       if (a.multi && !first && cg_pending_update(a.cgs, a.iter, blockIdx.x == 0 && threadIdx.x == 0)) { return; }
       beta = first ? 0.0 : a.cgs->rz / a.cgs->rz_prev;
    }
+   if (MODE == 4)
+   {
+      if (a.cgs->done) { return; }
+      if (a.multi && cg_pending_den(a.cgs, blockIdx.x == 0 && threadIdx.x == 0)) { return; } // (as cg_update_k)
+      alpha = a.cgs->rz / a.cgs->den;
+   }
    double M[LL]; // M[i + L j], symmetric, in scalar registers
 #pragma unroll
    for (int i = 0; i < LL; i++) { M[i] = uniform_f64(a.M1[i]); }
+   // MODE 4: the r and x values of the places this thread updates in the last stage, asked for now
+   constexpr int ZR = (NEB * LL + NT - 1) / NT; // rows (e, ly, lx) per thread in the z stage
+   double ro[MODE == 4 ? ZR : 1][L], xo[MODE == 4 ? ZR : 1][L];
+   if (MODE == 4)
+   {
+#pragma unroll
+      for (int k = 0; k < ZR; k++)
+      {
+         const int r = tid + k * NT;
+         const int yx = r % LL, el = r / LL;
+         const bool ok = r < nel * LL;
+#pragma unroll
+         for (int i = 0; i < L; i++)
+         {
+            const size_t p = (size_t)e0 * NL + (ok ? el * NL + yx + LL * i : 0);
+            ro[k][i] = a.ur[p];
+            xo[k][i] = a.ux[p];
+         }
+      }
+   }
    for (int i = tid; i < nel * NL; i += NT)
    {
       const size_t p = (size_t)e0 * NL + i;
-      double val = a.x[p];
+      double val = (MODE == 4) ? a.d[p] : a.x[p];
       if (MODE == 3)
       {
          if (!first) { val += beta * a.d[p]; }
@@ -695,8 +729,11 @@ mass_apply_l2_kron(const MassArgs a)
    __syncthreads();
    // z: rows (e, ly, lx), stride L^2; the element factor; out (and the partial of (d, M d))
    double dot = 0.0;
-   for (int r = tid; r < nel * LL; r += NT)
+#pragma unroll
+   for (int k = 0; k < ZR; k++)
    {
+      const int r = tid + k * NT;
+      if (r >= nel * LL) { break; }
       const int yx = r % LL, el = r / LL;
       const int base = el * NL + yx;
       const double se = a.Se[e0 + el];
@@ -710,8 +747,38 @@ mass_apply_l2_kron(const MassArgs a)
 #pragma unroll
          for (int j = 1; j < L; j++) { s = fma(M[i + L * j], u[j], s); }
          s *= se;
-         a.y[(size_t)e0 * NL + base + LL * i] = s;
+         if (MODE == 4)
+         {
+            // cg_update_k's expressions: x += alpha d, r -= alpha (M d), (r, r)
+            const double dv = sIn[base + LL * i];
+            const double xv = xo[MODE == 4 ? k : 0][i] + alpha * dv;
+            const double rv = ro[MODE == 4 ? k : 0][i] - alpha * s;
+            a.ux[(size_t)e0 * NL + base + LL * i] = xv;
+            a.ur[(size_t)e0 * NL + base + LL * i] = rv;
+            dot += rv * rv;
+            continue;
+         }
+         if (!(MODE == 3 && a.no_y)) { a.y[(size_t)e0 * NL + base + LL * i] = s; }
          if (MODE == 3) { dot = fma(sIn[base + LL * i], s, dot); }
+      }
+   }
+   if (MODE == 4)
+   {
+      const double bsum = block_sum(dot, red);
+      double total;
+      if (grid_sum_last_block(bsum, a.partials, a.ticket, red, total))
+      {
+         if (tid == 0)
+         {
+            CgScalars *sc = a.cgs;
+            sc->rz_prev = sc->rz;
+            sc->rz = total; // betanom
+            if (!a.multi)
+            {
+               sc->iters = a.iter;
+               if (total < 0.0 || total <= sc->r0) { sc->done = 1; }
+            }
+         }
       }
    }
    if (MODE == 3)
@@ -844,6 +911,14 @@ template <int MODE> static int launch_mass(lgh_ctx *c, int space, const MassArgs
    return LGH_OK;
 }
 
+// The energy CG's update as a second launch of the Kronecker kernel (MODE 4) instead of cg_update_k: when the L2 apply runs in
+// its Kronecker form.  LGH_L2_FUSED=0: cg_update_k reads the stored product (rounds 1-5).
+static bool l2_fused_update(lgh_ctx *c)
+{
+   static const bool on = !(getenv("LGH_L2_FUSED") && getenv("LGH_L2_FUSED")[0] == '0');
+   int form = 0, compact = 0;
+   return on && l2_mass_kernel(c, &form, &compact) == LGH_OK && form == 2;
+}
 // D[q, e] = W[q] s_e ?  In exact arithmetic the data of laghos_assembly.cpp:92-95, w_q detJ0(x_q) rho0(x_q), has this
 // form whenever the initial element is affine and rho0 constant in it; the stored entries carry the rounding of the
 // Jacobian and density evaluation at each point (measured: 220 ulp at Q3Q2 on the 8^3 box mesh, it grows like 1 / h).
@@ -1246,6 +1321,31 @@ __global__ void cg_set_tol_k(CgScalars *s, double rel_tol2)
    s->iters = 0;
 }
 
+static int launch_l2_update(lgh_ctx *c, const MassArgs &m, const CgVecArgs &v)
+{
+   MassArgs a = m;
+   const int rc = mass_data(c, &a.Dq, &a.dqs, &a.Se);
+   if (rc) { return rc; }
+   a.M1 = c->M1l;
+   a.ux = v.x;
+   a.ur = v.r;
+   a.partials = v.partials;
+   a.ticket = v.ticket;
+   a.iter = v.iter;
+#define LGH_L2U(L_, NEB_) hipLaunchKernelGGL((mass_apply_l2_kron<L_, NEB_, 4>), dim3(ceil_div(c->NE, NEB_)), dim3(256), 0, c->stream, a)
+   switch (c->L1D)
+   {
+      case 1: LGH_L2U(1, 256); break;
+      case 2: LGH_L2U(2, 128); break;
+      case 3: LGH_L2U(3, 64); break;
+      case 4: LGH_L2U(4, 32); break;
+      default: LGH_L2U(5, 16); break;
+   }
+#undef LGH_L2U
+   LGH_HIP_CHECK(hipGetLastError());
+   return LGH_OK;
+}
+
 int cg_solve(lgh_ctx *c, int space, const double *b, double *x, double rel_tol, int max_iter,
              int *iters, bool x_is_zero)
 {
@@ -1302,6 +1402,7 @@ int cg_solve(lgh_ctx *c, int space, const double *b, double *x, double rel_tol, 
    m.d = c->cg_d0;
    v.d = c->cg_d0;
    v.d_in_place = h1 ? 0 : 1;
+   m.no_y = (!h1 && l2_fused_update(c)) ? 1 : 0;
    int it = 0;
    CgScalars *hs = (CgScalars *)c->host_pinned;
    // chunk = iterations enqueued between two looks at the convergence flag.  The
@@ -1371,7 +1472,8 @@ int cg_solve(lgh_ctx *c, int space, const double *b, double *x, double rel_tol, 
                if (rc) { return rc; }
             }
             v.yL = c->cg_y;
-            hipLaunchKernelGGL((cg_update_k<false, 0>), dim3(nbu), dim3(256), 0, c->stream, v);
+            if (!h1 && m.no_y) { rc = launch_l2_update(c, m, v); if (rc) { return rc; } } // (the update forms M d of its zones itself)
+            else { hipLaunchKernelGGL((cg_update_k<false, 0>), dim3(nbu), dim3(256), 0, c->stream, v); }
             if (multi)
             {
                rc = allreduce_dev(c, &c->cgs->rz, 1, 0); // convergence is looked at by the next K1 (cg_pending_update)
@@ -1415,7 +1517,8 @@ static int l2_enqueue(lgh_ctx *c, L2Run *r, int upto)
       if (rc) { return rc; }
       if (r->m.multi) { rc = allreduce_dev(c, &c->cgs->den, 1, 0); if (rc) { return rc; } } // as cg_solve
       r->v.iter = r->it;
-      hipLaunchKernelGGL((cg_update_k<false, 0>), dim3(r->nbu), dim3(256), 0, c->stream, r->v);
+      if (r->m.no_y) { rc = launch_l2_update(c, r->m, r->v); if (rc) { return rc; } }
+      else { hipLaunchKernelGGL((cg_update_k<false, 0>), dim3(r->nbu), dim3(256), 0, c->stream, r->v); }
       LGH_HIP_CHECK(hipGetLastError());
       if (r->m.multi) { rc = allreduce_dev(c, &c->cgs->rz, 1, 0); if (rc) { return rc; } }
    }
@@ -1463,6 +1566,7 @@ int cg_l2_begin(lgh_ctx *c, const double *b, double *x, double rel_tol, int max_
    v.d = c->cg_d0;
    v.d_in_place = 1;
    v.yL = c->cg_y;
+   m.no_y = l2_fused_update(c) ? 1 : 0;
    r->it = 0;
    r->max_iter = max_iter;
    r->nbu = ceil_div(n, 256 * kUpdU);

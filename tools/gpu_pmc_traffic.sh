@@ -16,5 +16,5 @@ run c2 "-p 1 -m data/cube01_hex.mesh -rs 4"
 run c3 "-p 1 -m data/cube01_hex.mesh -rs 5"
 run tg "-p 0 -m data/cube01_hex.mesh -rs 5"
 python tools/update_pmc_traffic.py c2=$O/c2_FETCH_SIZE.txt,$O/c2_WRITE_SIZE.txt c3=$O/c3_FETCH_SIZE.txt,$O/c3_WRITE_SIZE.txt tg=$O/tg_FETCH_SIZE.txt,$O/tg_WRITE_SIZE.txt
-cp profiles/r5_pmc_traffic.json $O/
+cp profiles/r6_pmc_traffic.json $O/
 head -30 $O/c3_FETCH_SIZE.txt
