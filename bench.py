@@ -149,7 +149,16 @@ def cpu_baseline(threads):
     out = dict(unit="Mdofs*steps/s", cores=threads, cpu_model=cpu_model(), kind="port",
                value_parity_build=par["value"], flags_parity_build=PARITY_FLAGS)
     try:
-        nat, _ = _time_oracle(threads, True, 8.0, False)
+        # (in a process of its own: a timing build that dies on this host - illegal instruction, a compiler's bad day - must not
+        #  take the bench line with it; round 6 met exactly that with 512-bit auto-vectorisation, oracle/Makefile)
+        import subprocess
+        code = ("import json, sys; sys.path.insert(0, %r); import bench; r, _ = bench._time_oracle(%d, True, 8.0, False); "
+                "print('NATIVE ' + json.dumps(r))" % (ROOT, threads))
+        pr = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=240)
+        lines = [l for l in pr.stdout.splitlines() if l.startswith("NATIVE ")]
+        if pr.returncode != 0 or not lines:
+            raise RuntimeError("timing build exited with %d: %s" % (pr.returncode, (pr.stderr or "").strip()[-120:]))
+        nat = json.loads(lines[-1][len("NATIVE "):])
         out.update(value=nat["value"], flags=NATIVE_FLAGS, seconds=nat["seconds"] + par["seconds"], rk4_steps=nat["rk4_steps"], h1_cg_iters=nat["h1_cg_iters"])
         note = "%d steps in %.1f s with the -march=native build, %d in %.1f s with the parity build" % (nat["rk4_steps"], nat["seconds"], par["rk4_steps"], par["seconds"])
     except Exception as e:  # no compiler on this host: the parity build's time stands in, and the line says so
@@ -226,6 +235,18 @@ def mass_data_note(sim):
     return {1: "compact W[q]*s_e (device check of every stored entry, rel 1e-12; affine zones, zone-constant rho0)",
             0: "stored table D[q,e] (the reference's form)"}.get(form.value, "not decided yet (no mass apply ran)") + \
         ("; Jac0inv one per zone (zone-constant, device check, 1e-12)" if j0.value == 1 else "; Jac0inv per point")
+
+
+def mesh_order_note(sim):
+    """What the library found of the mesh (lgh_mesh_order): it orders zones and nodes itself from the element -> node map; on
+    the generator's own numbering that order is the caller's and nothing is permuted (the legs c2mfem / c2perm measure the rest)."""
+    from laghos_amd import _lib
+    o = (ctypes.c_long * 8)()
+    _lib.check(_lib.load().lgh_mesh_order(sim.L.laghos_sim_context(sim.h), o))
+    if not o[0]:
+        return "no structured block found (or LGH_ORDER=0): the caller's zone order and node numbering are kept"
+    return "structured block %dx%dx%d found by face adjacency; internal zone order / node numbering %s" % (
+        o[3], o[4], o[5], "= the caller's (nothing permuted)" if o[1] else "differ from the caller's (velocity solve and zone walk run in the library's own)")
 
 
 def algorithmic_bytes(sz):
@@ -573,7 +594,7 @@ def compact_line(full, detail_path=None):
                         "vs_baseline", "dtype", "data"))
     line["config"] = _pick(full.get("config", {}), ("workload", "transport", "elements", "h1_dofs", "l2_dofs", "quad_points_per_element",
                                                    "rk_stages_executed", "ode", "cg_rel_tol", "parallelism", "zones_per_gpu",
-                                                   "qupdate_division", "mass_data", "e_norm", "t", "dt"))
+                                                   "qupdate_division", "mass_data", "mesh_order", "e_norm", "t", "dt"))
     r = full.get("roofline")
     if r:
         rl = _pick(r, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "mean_launch_us", "launches_sampled",
@@ -780,6 +801,7 @@ def main():
                    # 2 Newton steps + residual correction (<= 2 ulp) instead of the IEEE divide sequence
                    "qupdate_division": "fp64 reciprocal + 2 Newton steps + correction, <= 2 ulp (-freciprocal-math -fapprox-func)",
                    "mass_data": mass_data_note(sim),
+                   "mesh_order": mesh_order_note(sim),
                    "e_norm": sim.e_norm(), "t": sim.t, "dt": sim.dt},
     }
 

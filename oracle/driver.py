@@ -35,14 +35,15 @@ def build(force=False):
 
 _LIB_NATIVE = None
 PARITY_FLAGS = "-O3 -march=x86-64-v3 -fopenmp -fno-fast-math -ffp-contract=off"   # oracle/Makefile CXXFLAGS: the checker
-NATIVE_FLAGS = "-O3 -march=native -fopenmp -fno-fast-math -ffp-contract=fast"     # oracle/Makefile NATIVEFLAGS: timing only
+NATIVE_FLAGS = "-O3 -march=native -mprefer-vector-width=256 -fopenmp -fno-fast-math -ffp-contract=fast"     # oracle/Makefile NATIVEFLAGS: timing only
 
 
 def build_native():
     """The timing build of the same source (`make native`: -march=native, FMA contraction), compiled on the machine that
     runs it - bench.py's cpu_baseline only; never the checker."""
     so = os.path.join(_HERE, "_build", "liblaghos_oracle_native.so")
-    subprocess.check_call(["make", "-C", _HERE, "native"], stdout=subprocess.DEVNULL)
+    # (-B: always for THIS host - a copy that travelled with the tree was built for another machine's -march=native)
+    subprocess.check_call(["make", "-B", "-C", _HERE, "native"], stdout=subprocess.DEVNULL)
     return so
 
 

@@ -246,3 +246,44 @@ def test_cpp_driver_on_a_renumbered_mesh_reproduces_the_structured_run(mode):
     for b in range(6):
         assert rel_err(S_r[b * N:(b + 1) * N][npm], S_b[b * N:(b + 1) * N]) < 1e-8, b
     assert rel_err(S_r[2 * H1V:].reshape(NE, NL), S_b[2 * H1V:].reshape(NE, NL)[epm]) < 1e-8
+
+
+@pytest.mark.parametrize("mode", ["mfem", "random"])
+def test_config2_full_size_on_a_renumbered_mesh(mode):
+    """BASELINE configs[1] at FULL size (32^3 zones: the slab K1 by default dispatch, the bounded-grid K2, the row-form update)
+    in an MFEM-like / a random numbering against the same run in the generator's numbering - which
+    tests/test_gpu_pipeline.py::test_config2_full_size_vs_oracle holds to the oracle: three RK4 steps from t = 0, same step
+    count and dt, |e| to 1e-9, the state through the permutation to 1e-8; the library must have found the block (lgh_mesh_order:
+    structured, not the identity, 32 x 32 x 32) and merged the same x-faces."""
+    import ctypes
+    from laghos_amd import _lib, host_lib
+    common = ["-m", "data/cube01_hex.mesh", "-rs", 4, "-p", 1, "-ok", 3, "-ot", 2, "-pa", "-tf", 1e9, "-ms", 3, "-vs", 10 ** 9, "-q"]
+    out = {}
+    for name, extra in (("base", []), (mode, ["-renumber", mode, "-renumber-seed", 4])):
+        sim = host_lib.Sim(common + extra)
+        try:
+            sim.enable_timers(False)
+            while sim.step() == 1:
+                pass
+            sim.sync()
+            L, ctx = _lib.load(), sim.L.laghos_sim_context(sim.h)
+            o, st = (ctypes.c_long * 8)(), (ctypes.c_long * 4)()
+            _lib.check(L.lgh_mesh_order(ctx, o))
+            _lib.check(L.lgh_vcg_layout_stats(ctx, st))
+            form = ctypes.c_int(-9)
+            _lib.check(L.lgh_k1_form(ctx, ctypes.byref(form)))
+            out[name] = (sim.t, sim.dt, sim.rk_steps, sim.e_norm(), sim.state(), tuple(o[:6]), int(st[3]), form.value)
+        finally:
+            sim.close()
+    (t_b, dt_b, n_b, e_b, S_b, o_b, merged_b, form_b), (t_r, dt_r, n_r, e_r, S_r, o_r, merged_r, form_r) = out["base"], out[mode]
+    assert o_b == (1, 1, 1, 32, 32, 32) and o_r == (1, 0, 1, 32, 32, 32)
+    assert form_b == form_r == 4 and merged_r == merged_b > 0
+    assert n_b == n_r and abs(t_r - t_b) <= 1e-11 * t_b and abs(dt_r - dt_b) <= 1e-9 * dt_b
+    assert abs(e_r - e_b) <= 1e-9 * e_b
+    d = host_lib.host_disc("cube01_hex", 4, 3, 2, 1, renumber=mode, seed=4)
+    npm, epm = d["node_perm"].astype(np.int64), d["elem_perm"].astype(np.int64)
+    N, NE = npm.size, epm.size
+    H1V, NL = 3 * N, 27
+    for b in range(6):
+        assert rel_err(S_r[b * N:(b + 1) * N][npm], S_b[b * N:(b + 1) * N]) < 1e-8, b
+    assert rel_err(S_r[2 * H1V:].reshape(NE, NL), S_b[2 * H1V:].reshape(NE, NL)[epm]) < 1e-8

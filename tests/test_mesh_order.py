@@ -90,3 +90,27 @@ def test_two_dimensions_keep_the_callers_order():
     NE, N = d["gamma"].size, d["owner"].size
     z, n, st = order_of(d["h1map"], NE, N, 3, dim=2)
     assert st["identity"] and np.array_equal(z, np.arange(NE))
+
+
+def test_an_l_shaped_block_with_a_hole_is_still_one_structured_component():
+    """Not a box: an L-shaped domain (a quarter of the 4 x 4 x 4 mesh removed).  The flood fill still gives consistent integer
+    coordinates; zones come out row by row (rows of different length), nodes along those rows - every x-row of every zone is
+    consecutive in the internal numbering, and zones that follow each other inside a row are x-neighbours."""
+    base = host_lib.host_disc("cube01_hex", 1, 3, 2, 1)      # 4 x 4 x 4 zones, Q3
+    NE0, ND, n = 64, 64, 4
+    hm0 = base["h1map"].reshape(NE0, ND).astype(np.int64)
+    e = np.arange(NE0)
+    keep = ~((e % n >= 2) & ((e // n) % n >= 2))              # drop i >= 2 and j >= 2
+    hm = hm0[keep]
+    used = np.unique(hm)
+    renum = np.full(hm0.max() + 1, -1)
+    renum[used] = np.arange(used.size)
+    rng = np.random.default_rng(9)
+    zp, npm = rng.permutation(hm.shape[0]), rng.permutation(used.size)
+    given = npm[renum[hm]][zp]
+    z, nn, st = order_of(given, hm.shape[0], used.size, 4)
+    assert st["structured"] and st["components"] == 1 and not st["identity"]
+    im = internal_map(given, z, nn, hm.shape[0], ND).reshape(-1, 4, 4, 4)      # [zone][dz][dy][dx]
+    assert np.all(np.diff(im, axis=3) == 1)                                     # x-rows of nodes are consecutive numbers
+    chains = np.all(im[:-1, :, :, 3] == im[1:, :, :, 0], axis=(1, 2))           # zone i + 1 is the x-neighbour of zone i
+    assert chains.sum() == (3 * 2 + 1 * 2) * 4                                  # rows of 4 zones (j < 2) and of 2 zones (j >= 2), per k
