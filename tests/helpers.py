@@ -111,3 +111,38 @@ class CurvedInitialMesh:
         # (rho0 at the quadrature points of the moved mesh would be rho0(x_q); problems with constant rho0 - Sedov, Taylor-Green -
         #  keep their values)
         return self._S.copy(), self._rho_l2, self._gamma, self._rho0_q
+
+
+class TwoBlocks:
+    """Two copies of `base` side by side that share no node (the second one shifted along x): a mesh of two structured blocks.
+    Zones and nodes of the first block first; PermutedProblem on top scrambles both numberings."""
+
+    def __init__(self, base, shift=10.0):
+        self.base, self.shift = base, shift
+        self.N, self.NE = 2 * base.N, 2 * base.NE
+        self.H1V, self.L2V = base.dim * self.N, 2 * base.L2V
+        hm = np.asarray(base.h1map).reshape(base.NE, base.ND)
+        self.h1map = np.ascontiguousarray(np.concatenate([hm, hm + base.N]).astype(np.int32))
+        self.ess = [np.concatenate([np.asarray(e), np.asarray(e) + base.N]).astype(np.int32) for e in base.ess]
+        self.owner = np.ones(self.N)
+
+    def __getattr__(self, name):
+        return getattr(self.base, name)
+
+    def state(self, Sa, Sb):
+        """[x | v | e] of the two-block mesh from a state of each block"""
+        b, N0 = self.base, self.base.N
+        out = []
+        for blk in range(2 * b.dim):   # x components, then v components
+            a_, b_ = Sa[blk * N0:(blk + 1) * N0], Sb[blk * N0:(blk + 1) * N0]
+            out += [a_, b_ + (self.shift if blk == 0 else 0.0)]
+        out += [Sa[2 * b.H1V:], Sb[2 * b.H1V:]]
+        return np.concatenate(out)
+
+    def initial_state(self):
+        S, rho_l2, gamma, rho0_q = self.base.initial_state()
+        return self.state(S, S), np.concatenate([rho_l2, rho_l2]), np.concatenate([np.asarray(gamma)] * 2), np.concatenate([rho0_q, rho0_q])
+
+    def accel_source(self):
+        a, N0 = self.base.accel_source(), self.base.N
+        return np.concatenate([np.concatenate([a[c * N0:(c + 1) * N0]] * 2) for c in range(self.base.dim)])

@@ -316,3 +316,46 @@ def test_published_3d_runs_in_mfem_numbering(name, args, golden):
     assert ti == g["step"]
     assert f"{dt:.6f}" == g["dt"]
     assert abs(e - g["e_norm"]) / g["e_norm"] < 1e-9, (e, g["e_norm"])
+
+
+@pytest.mark.parametrize("variant", ["4", None], ids=["slab", "default"])
+def test_rhs_on_two_blocks_that_share_no_node(variant, monkeypatch):
+    """A mesh of two structured blocks (tests/helpers.py::TwoBlocks: two copies of the 512-zone Q3Q2 cube side by side, no
+    common node), nodes and zones randomly renumbered across BOTH: the library must find two components (lgh_mesh_order), put
+    them one after the other in its own order - sets of five zones that straddle the two are no x-chains and keep the
+    element-local layout - and the right-hand side of a differently distorted state on each block must be the oracle's."""
+    from helpers import TwoBlocks
+    from oracle.fem import Problem
+    monkeypatch.delenv("LGH_VCG_VARIANT", raising=False)
+    monkeypatch.delenv("LGH_ORDER", raising=False)
+    if variant is not None:
+        monkeypatch.setenv("LGH_VCG_VARIANT", variant)
+    base = Problem(mesh="cube01_hex", rs=2, order_v=3, order_e=2, problem=1)
+    two = TwoBlocks(base)
+    perm = PermutedProblem(two, seed=21)
+    S = perm.state(two.state(deformed_state(base, seed=5), deformed_state(base, seed=6)))
+    H1V = two.H1V
+    g, o = make_gpu(perm, cg_tol=1e-13), make_oracle(perm, cg_tol=1e-13)
+    try:
+        mo = g.ctx.mesh_order()
+        assert mo["structured"] and not mo["identity"] and mo["components"] == 2 and mo["extent"] == (8, 8, 8)
+        if variant == "4":
+            _, n_merged = g.ctx.test_vcg_merged_faces()
+            assert g.ctx.k1_form() == "slab" and n_merged > 0
+        Sd, dS = g.ctx.to_dev(S), g.ctx.zeros(S.size)
+        g.reset_quadrature_data()
+        g.reset_time_step_estimate()
+        g.mult(Sd, dS)
+        dt = g.get_time_step_estimate(Sd)
+        g.ctx.sync()
+        dS = dS.cpu().numpy()
+        dS_o = np.empty_like(S)
+        o.qdata_is_current = False
+        o.reset_time_step_estimate()
+        o.mult(S, dS_o)
+        dt_o = o.get_time_step_estimate(S)
+    finally:
+        g.close()
+        o.close()
+    assert rel_err(dS[H1V:2 * H1V], dS_o[H1V:2 * H1V]) < 1e-9 and rel_err(dS[2 * H1V:], dS_o[2 * H1V:]) < 1e-9
+    assert abs(dt - dt_o) <= 1e-12 * dt_o
