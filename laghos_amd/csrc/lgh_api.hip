@@ -8,6 +8,7 @@
 
 #include "lgh_common.hpp"
 
+#include <chrono>
 #include <dlfcn.h>
 
 namespace lgh
@@ -282,11 +283,14 @@ int host_wait_token(lgh_ctx *c, volatile unsigned long long *word, const unsigne
    static const bool spin = !(getenv("LGH_SPIN") && getenv("LGH_SPIN")[0] == '0');
    if (spin)
    {
-      // ~2 ms of polling at most: a look normally returns within the tail of the last enqueued kernels
-      for (long i = 0; i < 4000000L; i++)
+      // polling for at most ~50 ms (a look normally returns within the tail of the last enqueued kernels: a chunk of
+      // iterations, 1-20 ms); a host that would wait longer than that sleeps in the stream synchronisation below instead
+      const auto t0 = std::chrono::steady_clock::now();
+      for (long i = 0;; i++)
       {
          if (__atomic_load_n((const unsigned long long *)word, __ATOMIC_ACQUIRE) == token) { return LGH_OK; }
          __builtin_ia32_pause();
+         if ((i & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50)) { break; }
       }
    }
    LGH_HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -601,6 +605,7 @@ int lgh_destroy(lgh_ctx *c)
    cg_l2_free(c);
    vcg_free(c);
    mesh_order_free(c);
+   if (c->q_trace_dev) { (void)hipFree(c->q_trace_dev); }
    if (c->stream2)
    {
       (void)hipStreamSynchronize(c->stream2);

@@ -187,6 +187,8 @@ struct lgh_ctx
    lgh::Comm *comm;
    int nranks, rank;
    int multi;            // 1: run the multi-rank code path (nranks > 1, or LGH_FORCE_MULTI=1 for testing on one GPU)
+   unsigned long long *q_trace_dev; // debug (LGH_Q_TRACE): stage stamps of the quadrature update's workgroups, NE records
+   int q_trace_n, q_trace_calls;
    void *order;          // lgh::MeshOrder (lgh_order.hip)
    unsigned long mass_gen; // counts changes of the mass data / Jacobi diagonal (the velocity solve keeps copies in its own numbering)
 };

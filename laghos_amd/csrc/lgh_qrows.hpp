@@ -427,18 +427,17 @@ static bool qrows_available(const lgh_ctx *c)
 }
 // debug: LGH_Q_TRACE=<file>: the Q3Q2 update through the traced instantiation; the stamps of call number LGH_Q_TRACE_CALL
 // (default 40: inside the timed window of a bench run) are written to the file (qrows_trace_dump)
-static unsigned long long *q_trace_dev = nullptr;
-static int q_trace_n = 0;
+// (the buffer and the call counter live in the context - round-5 advisor: file-scope statics were shared by every context)
 static void qrows_trace_dump(lgh_ctx *c)
 {
    const char *path = getenv("LGH_Q_TRACE");
-   if (!path || !q_trace_dev || q_trace_n <= 0) { return; }
+   if (!path || !c->q_trace_dev || c->q_trace_n <= 0) { return; }
    (void)hipStreamSynchronize(c->stream);
-   std::vector<unsigned long long> h((size_t)kQTraceRec * q_trace_n);
-   if (hipMemcpy(h.data(), q_trace_dev, h.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) { return; }
+   std::vector<unsigned long long> h((size_t)kQTraceRec * c->q_trace_n);
+   if (hipMemcpy(h.data(), c->q_trace_dev, h.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) { return; }
    FILE *f = fopen(path, "w");
    if (!f) { return; }
-   for (int i = 0; i < q_trace_n; i++)
+   for (int i = 0; i < c->q_trace_n; i++)
    {
       fprintf(f, "%d", i);
       for (int k = 0; k < 14; k++) { fprintf(f, " %llu", h[(size_t)kQTraceRec * i + k]); }
@@ -450,18 +449,17 @@ template <int MINW6> static int launch_qrows_w(lgh_ctx *c, const QArgs &a)
 {
    if (c->kid == 0x346 && getenv("LGH_Q_TRACE"))
    {
-      if (q_trace_n != c->NE)
+      if (c->q_trace_n != c->NE)
       {
-         if (q_trace_dev) { (void)hipFree(q_trace_dev); q_trace_dev = nullptr; }
-         LGH_HIP_CHECK(hipMalloc((void **)&q_trace_dev, (size_t)kQTraceRec * c->NE * 8));
-         q_trace_n = c->NE;
+         if (c->q_trace_dev) { (void)hipFree(c->q_trace_dev); c->q_trace_dev = nullptr; }
+         LGH_HIP_CHECK(hipMalloc((void **)&c->q_trace_dev, (size_t)kQTraceRec * c->NE * 8));
+         c->q_trace_n = c->NE;
       }
-      if (a.Jac0inv_e) { hipLaunchKernelGGL((qrows_kernel<4, 6, 3, MINW6, true, true>), dim3(c->NE), dim3(216), 0, c->stream, a, q_trace_dev); }
-      else { hipLaunchKernelGGL((qrows_kernel<4, 6, 3, MINW6, true, false>), dim3(c->NE), dim3(216), 0, c->stream, a, q_trace_dev); }
+      if (a.Jac0inv_e) { hipLaunchKernelGGL((qrows_kernel<4, 6, 3, MINW6, true, true>), dim3(c->NE), dim3(216), 0, c->stream, a, c->q_trace_dev); }
+      else { hipLaunchKernelGGL((qrows_kernel<4, 6, 3, MINW6, true, false>), dim3(c->NE), dim3(216), 0, c->stream, a, c->q_trace_dev); }
       LGH_HIP_CHECK(hipGetLastError());
-      static int calls = 0;
       const char *nenv = getenv("LGH_Q_TRACE_CALL"); // which call to dump (default 40: a developed bench window)
-      if (++calls == (nenv ? atoi(nenv) : 40)) { qrows_trace_dump(c); }
+      if (++c->q_trace_calls == (nenv ? atoi(nenv) : 40)) { qrows_trace_dump(c); }
       return LGH_OK;
    }
 #define LGH_QROWS(D_, Q_, L_, W_, NT_) do { if (a.Jac0inv_e) { hipLaunchKernelGGL((qrows_kernel<D_, Q_, L_, W_, false, true>), dim3(c->NE), dim3(NT_), 0, c->stream, a, (unsigned long long *)nullptr); } \
