@@ -20,7 +20,10 @@ timeout 1200 python bench.py --detail $O/bench_detail.json > $O/bench.json 2> $O
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- python bench.py --no-legs --no-cpu-baseline --detail $O/bench_under_rocprof_detail.json > $O/bench_under_rocprof.json 2> $O/bench_under_rocprof.err
 f=$(find $O/stats -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/bench_kernel_stats.csv
 python tools/gap_summary.py $O/stats > $O/gaps.txt 2>&1
-python tools/step_timeline.py $O/stats > $O/step_timeline.txt 2>&1
+# (the per-step timeline wants a trace of timed steps only: a run of its own without the per-kernel sampling steps behind them)
+timeout 900 rocprofv3 --kernel-trace --output-format csv -d $O/stats2 -o steps -- python bench.py --no-legs --no-cpu-baseline --no-roofline --steps 30 --warmup 5 --detail $O/steps_detail.json > $O/steps.json 2> $O/steps.err
+python tools/step_timeline.py $O/stats2 > $O/step_timeline.txt 2>&1
+rm -rf $O/stats2
 find $O -name "*kernel_trace.csv" -delete
 rm -rf $O/stats
 python - <<PY
