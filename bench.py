@@ -370,6 +370,10 @@ def measure_comm(sim, world):
     L = _lib.load()
     ctx = sim.L.laghos_sim_context(sim.h)
     out = {}
+    # (first: the sampled steps below run the energy solve after the velocity solve - kernel timing has sequential semantics)
+    ls = (ctypes.c_long * 4)()
+    _lib.check(L.lgh_energy_lockstep_stats(ctx, ls))
+    out["energy_lockstep"] = {"solves": int(ls[0]), "iterations_inside_velocity_solves": int(ls[1]), "iterations_after": int(ls[2])}
     for kid, key in ((6, "halo_exchange"), (7, "allreduce")):
         _lib.check(L.lgh_ktime_begin(ctx, kid, 8192))
         sim.step()
@@ -499,6 +503,7 @@ def _run_leg(host_lib, args, steps, warmup, dev, force_multi, pmc_key):
                                                "sec8d_frac", "time_share_us_per_rk_step")}
     if force_multi:
         out["comm"] = measure_comm(sim, 1)
+        out["energy_lockstep"] = out["comm"]["energy_lockstep"]
     # K1 / K2 / update microseconds per launch and what the velocity solve found of the mesh's structure (lgh_vcg_layout_stats)
     out["k_us"] = {key: 1e6 * raw[k][1] for k, key in ((0, "k1"), (1, "k2"), (2, "q")) if k in raw}
     try:
@@ -543,6 +548,12 @@ LEGS = {
                       workload=WORKLOADS["c2"][1] + ", general-mesh path: stored mass table, Jac0inv per point (LGH_MASS_RANK1=0 LGH_JAC0_COMPACT=0)"),
     "c2multi": dict(args=WORKLOADS["c2"][0], order=(3, 2), steps=10, warmup=3, force_multi=True,
                     workload=WORKLOADS["c2"][1] + ", N-rank code path on one rank (LGH_FORCE_MULTI=1, RCCL communicator of size 1)"),
+    # ... on ONE communicator (LGH_COMM2=0: what N ranks over RCCL run by default - no second channel): the energy CG in lockstep
+    # with the velocity CG (lgh_energy_lockstep_stats), and, for the A/B, after it (LGH_ENERGY_LOCKSTEP=0)
+    "c2multi1c": dict(args=WORKLOADS["c2"][0], order=(3, 2), steps=10, warmup=3, force_multi=True, env={"LGH_COMM2": "0"},
+                      workload=WORKLOADS["c2"][1] + ", N-rank code path on one rank, one communicator: energy CG in lockstep with the velocity CG"),
+    "c2multi1cseq": dict(args=WORKLOADS["c2"][0], order=(3, 2), steps=10, warmup=3, force_multi=True, env={"LGH_COMM2": "0", "LGH_ENERGY_LOCKSTEP": "0"},
+                         workload=WORKLOADS["c2"][1] + ", N-rank code path on one rank, one communicator: energy CG after the velocity CG"),
     # the general-mesh twins of the N-rank and the HBM-resident legs
     "c2multigeneral": dict(args=WORKLOADS["c2"][0], order=(3, 2), steps=10, warmup=3, force_multi=True, env={"LGH_MASS_RANK1": "0", "LGH_JAC0_COMPACT": "0"},
                            workload=WORKLOADS["c2"][1] + ", N-rank code path on one rank, general-mesh path"),
@@ -610,7 +621,7 @@ def compact_line(full, detail_path=None):
     if "comm" in full:
         c = full["comm"]
         line["comm"] = {k: c[k] for k in c if k in ("halo_exchange", "allreduce", "neighbours", "largest_message_bytes_3_components",
-                                                    "all_pairs_partition", "second_channel", "ranks")}
+                                                    "all_pairs_partition", "second_channel", "ranks", "energy_lockstep")}
     if "cpu_baseline" in full:
         line["cpu_baseline"] = _pick(full["cpu_baseline"], ("value", "unit", "cores", "kind", "sample", "cpu_model", "flags", "value_parity_build", "flags_parity_build",
                                                            "native_build_error", "error"))
@@ -631,6 +642,8 @@ def compact_line(full, detail_path=None):
                 e["force_mass_frac"] = g["force_mass_aggregate"].get("frac")
             if isinstance(g.get("k_us"), dict):
                 e["k_us"] = g["k_us"]
+            if isinstance(g.get("energy_lockstep"), dict) and g["energy_lockstep"].get("solves"):
+                e["lockstep_solves"] = g["energy_lockstep"]["solves"]
             if name in ("c2mfem", "c2perm") and isinstance(g.get("vcg_layout"), dict):
                 e["merged_entries"] = g["vcg_layout"].get("merged_entries")
             legs[name] = e
@@ -671,7 +684,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="skip the extra legs (64^3 Sedov / Taylor-Green, Q5Q4, developed flow, N-rank path)")
-    ap.add_argument("--legs", default="c2mfem,c2perm,c3,tg,c5,c2dev,c2general,c2multi,c2multigeneral,c3general", help="comma-separated extra legs of a single-GPU run")
+    ap.add_argument("--legs", default="c2mfem,c2perm,c3,tg,c5,c2dev,c2general,c2multi,c2multi1c,c2multi1cseq,c2multigeneral,c3general", help="comma-separated extra legs of a single-GPU run")
     ap.add_argument("--transport", choices=("rccl", "shm"), default="rccl",
                     help="several ranks: rccl = the product transport (one GPU per rank, RCCL over xGMI); shm = the cross-process loopback "
                          "transport of lgh_comm.hip (ranks may share one GPU: the torchrun / id broadcast / N-rank code path on a one-GPU box)")
@@ -853,8 +866,9 @@ def main():
                 legs[name]["workload"] = leg["workload"]
             except Exception as e:  # an extra leg must not cost the headline number
                 legs[name] = {"error": repr(e)}
-        if "c2multi" in legs and "value" in legs["c2multi"]:
-            legs["c2multi"]["ms_per_step_minus_single_rank_path"] = legs["c2multi"]["ms_per_step"] - out["ms_per_step"]
+        for name in ("c2multi", "c2multi1c", "c2multi1cseq"):
+            if name in legs and "value" in legs[name]:
+                legs[name]["ms_per_step_minus_single_rank_path"] = legs[name]["ms_per_step"] - out["ms_per_step"]
         out["legs"] = legs
 
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

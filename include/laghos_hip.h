@@ -208,6 +208,18 @@ int lgh_solve_energy(lgh_ctx *ctx, const double *S, const double *v_h1, double *
 int lgh_solve_energy_begin(lgh_ctx *ctx, const double *S, const double *v_h1, double *dS_dt,
                            double *e_rhs, const double *e_source, double rel_tol, int max_iter);
 int lgh_solve_energy_end(lgh_ctx *ctx, int *l2_iters);
+/* Several ranks on ONE communicator (no second channel: the default over RCCL): _begin sets the energy CG up on the main stream
+ * and lgh_solve_velocity enqueues one of its iterations behind each of its own - the mass apply behind K1, the update behind K2 -
+ * with (d, M d) as a fourth scalar on the halo messages and (r, r) in a spare word of the accumulator-word exchange: the energy
+ * solve costs no exchange and no host look of its own, as SolveEnergy costs none beside SolveVelocity on one rank.  _end runs
+ * what is left (an energy solve that needs more iterations than the velocity solve took).  The iterates are those of
+ * lgh_solve_energy up to the order in which the ranks' (r, r) and (d, M d) are added (rank order instead of RCCL's).
+ * LGH_ENERGY_LOCKSTEP=0: the energy solve after the velocity solve.  Needs what the velocity solve's word exchange needs (every
+ * rank a neighbour of every other, the slab form of K1) and region timers off.
+ *   out[0] = energy solves run this way, out[1] = their iterations enqueued inside velocity solves, out[2] = ... after them,
+ *   out[3] = 1: the next lgh_solve_energy_begin would take this path.
+ * Replaces nothing in the reference (laghos_solver.cpp:400-493 runs the two solves one after the other). */
+int lgh_energy_lockstep_stats(lgh_ctx *ctx, long out[4]);
 
 /* ---- vector helpers on the context stream (device pointers) */
 int lgh_vec_set(lgh_ctx *ctx, double *y, double a, long n);              /* y = a */

@@ -89,6 +89,7 @@ SYMBOLS = {
     "lgh_k1_form": (_I, [_P, c_int_p]),
     "lgh_l2_mass_form": (_I, [_P, c_int_p, c_int_p]),
     "lgh_vcg_layout_stats": (_I, [_P, ctypes.POINTER(ctypes.c_long)]),
+    "lgh_energy_lockstep_stats": (_I, [_P, ctypes.POINTER(ctypes.c_long)]),
     "lgh_mesh_order": (_I, [_P, ctypes.POINTER(ctypes.c_long)]),
     "lgh_mesh_order_host": (_I, [_I, _I, _I, _I, c_int_p, c_int_p, c_int_p, ctypes.POINTER(ctypes.c_long)]),
     "lgh_mass_data_form": (_I, [_P, c_int_p]),

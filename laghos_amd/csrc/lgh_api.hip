@@ -280,7 +280,7 @@ namespace lgh
 {
 int host_wait_token(lgh_ctx *c, volatile unsigned long long *word, const unsigned long long token)
 {
-   static const bool spin = !(getenv("LGH_SPIN") && getenv("LGH_SPIN")[0] == '0');
+   const bool spin = !(getenv("LGH_SPIN") && getenv("LGH_SPIN")[0] == '0'); // (per call: the switch tests flip it inside one process)
    if (spin)
    {
       // polling for at most ~50 ms (a look normally returns within the tail of the last enqueued kernels: a chunk of
@@ -1120,8 +1120,26 @@ int lgh_solve_energy_begin(lgh_ctx *c, const double *S, const double *v_h1, doub
 {
    LGH_CHECK_ARG(c && S && v_h1 && dS_dt && e_rhs);
    c->e_args = {S, v_h1, dS_dt, e_rhs, e_source, rel_tol, max_iter};
+   c->e_lockstep = 0;
    if (!energy_overlap_ok(c))
    {
+      // Several ranks without a second channel (the default over real RCCL): the energy CG runs in LOCKSTEP with the velocity
+      // CG on this one stream and communicator instead of after it - its two dot products per iteration ride on exchanges the
+      // velocity iteration makes anyway.  Right-hand side and initial residual here, the iterations inside
+      // lgh_solve_velocity, what is left of them in _end.  LGH_ENERGY_LOCKSTEP=0: the solve after the velocity solve.
+      const bool ls_on = !(getenv("LGH_ENERGY_LOCKSTEP") && getenv("LGH_ENERGY_LOCKSTEP")[0] == '0');
+      const bool overlap_wanted = !(getenv("LGH_OVERLAP") && getenv("LGH_OVERLAP")[0] == '0');
+      if (ls_on && overlap_wanted && c->multi != 0 && !comm_second_channel(c) && !c->timers.enabled && !(c->ktime && c->ktime->which >= 0) && vcg_available(c) &&
+          l2_lockstep_possible(c) && vcg_lockstep_ready(c))
+      {
+         int rc = energy_rhs(c, v_h1, e_rhs); // :473
+         if (rc == LGH_OK && e_source) { rc = vec_axpby(c, e_rhs, 1.0, e_rhs, 1.0, e_source, c->L2V); } // :477
+         if (rc == LGH_OK) { rc = cg_l2_begin_lockstep(c, e_rhs, dS_dt + 2 * (size_t)c->H1V, rel_tol, max_iter); }
+         if (rc) { return rc; }
+         c->e_async = 3;
+         c->e_lockstep = 1;
+         return LGH_OK;
+      }
       c->e_async = 2;
       return LGH_OK;
    }
@@ -1149,11 +1167,31 @@ int lgh_solve_energy_begin(lgh_ctx *c, const double *S, const double *v_h1, doub
    c->e_polled = 0;
    return LGH_OK;
 }
+int lgh_energy_lockstep_stats(lgh_ctx *c, long out[4])
+{
+   LGH_CHECK_ARG(c && out);
+   out[0] = c->ls_stats[0]; out[1] = c->ls_stats[1]; out[2] = c->ls_stats[2];
+   out[3] = (c->multi != 0 && !comm_second_channel(c) && vcg_available(c) && l2_lockstep_possible(c) && vcg_lockstep_ready(c)) ? 1 : 0;
+   return LGH_OK;
+}
 int lgh_solve_energy_end(lgh_ctx *c, int *l2_iters)
 {
-   LGH_CHECK_ARG(c && (c->e_async == 1 || c->e_async == 2));
+   LGH_CHECK_ARG(c && (c->e_async == 1 || c->e_async == 2 || c->e_async == 3));
    const int mode = c->e_async;
    c->e_async = 0;
+   if (mode == 3)
+   {
+      // lockstep: whatever the velocity solve did not interleave (a solve that needs more iterations than last time, or than the
+      // velocity solve took) runs now, reducing its scalars itself; then the look
+      c->e_lockstep = 0;
+      int it = 0;
+      const int rc = cg_l2_end_lockstep(c, &it);
+      if (rc) { return rc; }
+      const int counted = (it == 0) ? 1 : it; // :486
+      c->timers.c[1] += counted;
+      if (l2_iters) { *l2_iters += counted; }
+      return LGH_OK;
+   }
    if (mode == 1 && c->e_polled)
    {
       // completed from inside the velocity solve (energy_overlap_poll): only the join is left

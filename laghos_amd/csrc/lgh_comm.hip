@@ -306,7 +306,7 @@ struct Comm
    const long long *word_src = nullptr;
    std::vector<long long> wstage;
 };
-constexpr int kHaloSlack = 4; // doubles of room behind every neighbour's block (<= 3 scalars used)
+constexpr int kHaloSlack = 4; // doubles of room behind every neighbour's block (<= 4 scalars: (d, A d) of the three velocity components and, in lockstep, of the energy CG)
 
 // Buffers: neighbour k owns the contiguous block starting at base_k = 3*off_k +
 // kHaloSlack*k: ncomp*cnt_k node values, component-major, then (optionally) nextra
@@ -386,7 +386,7 @@ int halo_sum(lgh_ctx *c, double *v, int ncomp, double *extra, int nextra, bool p
    if (!cm || cm->n_nbr == 0) { return LGH_OK; }
    const int *const l_nodes = alias ? alias->nodes : cm->nodes, *const l_sh_node = alias ? alias->sh_node : cm->sh_node;
    if (ncomp > 3 || ncomp < 0 || (ncomp == 0 && !extra)) { set_error("halo_sum: bad ncomp"); return LGH_ERR_ARG; }
-   if (extra && (!cm->allpairs || nextra < 1 || nextra > 3)) { set_error("halo_sum: cannot piggy-back"); return LGH_ERR_ARG; }
+   if (extra && (!cm->allpairs || nextra < 1 || nextra > kHaloSlack)) { set_error("halo_sum: cannot piggy-back"); return LGH_ERR_ARG; }
    const int nx = extra ? nextra : 0;
    const int tot = cm->total;
    const bool ch2 = c->on_stream2 != 0;
@@ -497,6 +497,22 @@ void comm_node_lists(const lgh_ctx *c, const int **nodes, int *total, const int 
    *total = cm ? cm->total : 0;
    *sh_node = cm ? cm->sh_node : nullptr;
    *n_shared = (cm && cm->sh_node) ? cm->n_shared : 0;
+}
+// neighbours of lower rank, or -1 when the neighbour list is not in ascending rank order (a sum "own value between the
+// lower and the higher peers' blocks" is then not the rank-ordered sum every rank must form alike)
+int comm_ranks_before(const lgh_ctx *c)
+{
+   const Comm *cm = c->comm;
+   int n = 0;
+   if (cm)
+   {
+      for (int k = 0; k < cm->n_nbr; k++)
+      {
+         if (k > 0 && cm->nbr_rank[k] <= cm->nbr_rank[k - 1]) { return -1; }
+         n += (cm->nbr_rank[k] < c->rank) ? 1 : 0;
+      }
+   }
+   return n;
 }
 void comm_shared_nodes(const lgh_ctx *c, const uint8_t **hmask, const int **sh_node, int *n_shared)
 {

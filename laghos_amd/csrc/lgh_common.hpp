@@ -103,6 +103,9 @@ struct lgh_ctx
    void *l2run;          // state of a split L2 solve (lgh_mass.hip)
    const double *accel_src; // dim*N acceleration source of SolveVelocity (source_type 2) or nullptr
    int e_async;          // 1: lgh_solve_energy_begin enqueued the solve, 2: deferred to _end
+   int e_lockstep;       // lgh_solve_energy_begin has set the energy CG up for LOCKSTEP with the velocity CG on the one stream and communicator
+   long ls_stats[3] = {0, 0, 0}; // lockstep energy solves; their iterations enqueued inside the velocity solve; ... and after it (lgh_energy_lockstep_stats)
+                         // (several ranks without a second channel; lgh_mass.hip "lockstep"): lgh_solve_velocity interleaves its iterations
    int e_polled, e_iters; // the enqueued solve has already been completed (energy_overlap_poll, from inside the velocity solve): its iteration count
    struct { const double *S, *v; double *dS, *e_rhs; const double *src; double tol; int maxit; } e_args;
    bool own_stream;
@@ -492,6 +495,21 @@ int energy_overlap_poll(lgh_ctx *c);
 // kernel that finishes the scalars writes them, then `token`, into pinned host memory (a.k.a. host_pinned_dev); the host
 // spins on the token word (falls back to hipStreamSynchronize after a while; LGH_SPIN=0: always synchronise).
 int host_wait_token(lgh_ctx *c, volatile unsigned long long *word, unsigned long long token);
+// ---- energy CG in lockstep with the velocity CG (several ranks, one stream, one communicator; round 6).  Its two dot products
+// per iteration ride on exchanges the velocity iteration makes anyway: (d, M d) as a fourth scalar behind the halo messages
+// (VcgScalars::den_e), (r, r) as a double in word kLsWord of the accumulator-word exchange.  No exchange of its own.
+constexpr int kLsWord = 50;             // (a padding word of an accumulator set: lgh_vcg.hpp checks it is one)
+constexpr int kLsWordsPerSet = 56;      // = kLimbWords (checked there): stride of the peers' sets
+struct LockstepWords { const long long *own; const long long *peers; int n_peers, before; }; // before: peers of lower rank
+bool l2_lockstep_possible(lgh_ctx *c);  // the L2 apply runs as the Kronecker kernel with the fused update (lgh_mass.hip)
+int cg_l2_begin_lockstep(lgh_ctx *c, const double *b, double *x, double rel_tol, int max_iter); // set-up + initial residual, no iteration
+int l2_lockstep_limit(lgh_ctx *c);      // iterations worth interleaving: the previous solve's count
+int l2_lockstep_apply(lgh_ctx *c, int it, const LockstepWords &prev, double *den_mirror);
+int l2_lockstep_update(lgh_ctx *c, int it, const double *den_src, long long *word_out);
+int l2_lockstep_fold(lgh_ctx *c, int it, const LockstepWords &last); // commits the outcome of iteration it (what the next apply would)
+int cg_l2_end_lockstep(lgh_ctx *c, int *iters); // the rest of the solve on its own (exchanges of its own), the host look
+int comm_ranks_before(const lgh_ctx *c); // neighbours whose rank is lower than this rank's
+bool vcg_lockstep_ready(const lgh_ctx *c); // the velocity solve of this context exchanges accumulator words and packs its halo itself
 int cg_l2_begin(lgh_ctx *c, const double *b, double *x, double rel_tol, int max_iter);
 int cg_l2_end(lgh_ctx *c, int *iters);
 void cg_l2_free(lgh_ctx *c);

@@ -58,7 +58,45 @@ struct MassArgs
    // updates ux (x) and ur (r) with it: ten vector passes per iteration become eight
    int no_y;
    double *ux, *ur;
+   // lockstep with the velocity CG on several ranks (lgh_common.hpp): the rank sums of this solve's two dot products travel with
+   // the velocity iteration's exchanges instead of in exchanges of their own
+   LockstepWords ls;        // MODE 3: the accumulator-word sets of the iteration before, own and peers': word kLsWord = that rank's (r, r)
+   int ls_on;               // 1: MODE 3 takes (r, r) from ls instead of cgs->rz; MODE 4 takes (d, M d) from ls_den_src
+   double *ls_den_mirror;   // MODE 3: the local (d, M d) also goes here (VcgScalars::den_e: behind the halo messages)
+   const double *ls_den_src;// MODE 4: the rank-summed (d, M d)
+   long long *ls_word_out;  // MODE 4: the local (r, r), as bits, into word kLsWord of the set the exchange after K2 sends
 };
+
+// lockstep: (r, r) of the iteration before = the ranks' values in rank order (own value between the lower and the higher peers)
+__device__ __forceinline__ double lockstep_rz(const LockstepWords &w)
+{
+   double rz = 0.0;
+   for (int p = 0; p < w.before; p++) { const double v = __longlong_as_double(w.peers[(size_t)p * kLsWordsPerSet + kLsWord]); rz = (p == 0) ? v : rz + v; }
+   {
+      const double v = __longlong_as_double(w.own[kLsWord]);
+      rz = (w.before == 0) ? v : rz + v;
+   }
+   for (int p = w.before; p < w.n_peers; p++) { rz += __longlong_as_double(w.peers[(size_t)p * kLsWordsPerSet + kLsWord]); }
+   return rz;
+}
+// ... and what the next kernel of the sequence does with it (cg_pending_update with the sum formed here): convergence looked at,
+// the outcome committed by one thread; returns true when the solve has converged
+__device__ __forceinline__ bool lockstep_pending_update(CgScalars *s, const int iter, const double rz, const bool commit)
+{
+   const bool conv = rz < 0.0 || rz <= s->r0;
+   if (commit)
+   {
+      __hip_atomic_store(&s->iters, iter - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (conv)
+      {
+         __hip_atomic_store(&s->done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+         __hip_atomic_store(&s->rz, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+         __hip_atomic_store(&s->den, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      else { __hip_atomic_store(&s->rz, rz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } // (the update of this iteration divides it by (d, M d))
+   }
+   return conv;
+}
 
 // Several ranks: the sums of den and (r, z) over the ranks complete outside the kernels that produce the
 // local parts, so the decisions they feed (breakdown, convergence, iteration count) are taken by the NEXT
@@ -649,14 +687,40 @@ mass_apply_l2_kron(const MassArgs a)
    {
       if (a.cgs->done) { return; }
       first = a.cgs->first != 0;
-      if (a.multi && !first && cg_pending_update(a.cgs, a.iter, blockIdx.x == 0 && threadIdx.x == 0)) { return; }
-      beta = first ? 0.0 : a.cgs->rz / a.cgs->rz_prev;
+      if (a.ls_on && !first)
+      {
+         const double rz = lockstep_rz(a.ls);
+         if (lockstep_pending_update(a.cgs, a.iter, rz, blockIdx.x == 0 && threadIdx.x == 0)) { return; }
+         beta = rz / a.cgs->rz_prev;
+      }
+      else
+      {
+         if (a.multi && !first && cg_pending_update(a.cgs, a.iter, blockIdx.x == 0 && threadIdx.x == 0)) { return; }
+         beta = first ? 0.0 : a.cgs->rz / a.cgs->rz_prev;
+      }
    }
    if (MODE == 4)
    {
       if (a.cgs->done) { return; }
-      if (a.multi && cg_pending_den(a.cgs, blockIdx.x == 0 && threadIdx.x == 0)) { return; } // (as cg_update_k)
-      alpha = a.cgs->rz / a.cgs->den;
+      if (a.ls_on)
+      {
+         const double den = *a.ls_den_src; // (summed over the ranks by the halo exchange of this iteration)
+         if (den == 0.0) // breakdown, as cg_pending_den
+         {
+            if (blockIdx.x == 0 && threadIdx.x == 0)
+            {
+               __hip_atomic_store(&a.cgs->done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+               __hip_atomic_store(&a.cgs->rz, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            return;
+         }
+         alpha = a.cgs->rz / den;
+      }
+      else
+      {
+         if (a.multi && cg_pending_den(a.cgs, blockIdx.x == 0 && threadIdx.x == 0)) { return; } // (as cg_update_k)
+         alpha = a.cgs->rz / a.cgs->den;
+      }
    }
    double M[LL]; // M[i + L j], symmetric, in scalar registers
 #pragma unroll
@@ -773,6 +837,7 @@ mass_apply_l2_kron(const MassArgs a)
             CgScalars *sc = a.cgs;
             sc->rz_prev = sc->rz;
             sc->rz = total; // betanom
+            if (a.ls_on) { a.ls_word_out[kLsWord] = __double_as_longlong(total); } // (its sum over the ranks: the next apply, or l2_lockstep_fold)
             if (!a.multi)
             {
                sc->iters = a.iter;
@@ -790,6 +855,7 @@ mass_apply_l2_kron(const MassArgs a)
          if (tid == 0)
          {
             a.cgs->den = total;
+            if (a.ls_on && a.ls_den_mirror) { *a.ls_den_mirror = total; } // (lockstep: behind the halo messages of the velocity iteration)
             if (a.cgs->first) { a.cgs->first = 0; }
             if (total == 0.0 && !a.multi) { a.cgs->done = 1; } // breakdown (den == 0): stop, as upstream
          }
@@ -915,7 +981,7 @@ template <int MODE> static int launch_mass(lgh_ctx *c, int space, const MassArgs
 // its Kronecker form.  LGH_L2_FUSED=0: cg_update_k reads the stored product (rounds 1-5).
 static bool l2_fused_update(lgh_ctx *c)
 {
-   static const bool on = !(getenv("LGH_L2_FUSED") && getenv("LGH_L2_FUSED")[0] == '0');
+   const bool on = !(getenv("LGH_L2_FUSED") && getenv("LGH_L2_FUSED")[0] == '0'); // (looked up per call: the switch tests flip it inside one process)
    int form = 0, compact = 0;
    return on && l2_mass_kernel(c, &form, &compact) == LGH_OK && form == 2;
 }
@@ -1525,7 +1591,7 @@ static int l2_enqueue(lgh_ctx *c, L2Run *r, int upto)
    return LGH_OK;
 }
 
-int cg_l2_begin(lgh_ctx *c, const double *b, double *x, double rel_tol, int max_iter)
+static int cg_l2_begin_impl(lgh_ctx *c, const double *b, double *x, double rel_tol, int max_iter, const bool enqueue)
 {
    const bool multi = c->multi != 0; // several ranks: the caller has checked that the second stream has a communicator
    if (!c->l2run) { c->l2run = new L2Run(); }
@@ -1572,7 +1638,68 @@ int cg_l2_begin(lgh_ctx *c, const double *b, double *x, double rel_tol, int max_
    r->nbu = ceil_div(n, 256 * kUpdU);
    r->active = true;
    const int last = c->cg_last_iters[1][0];
+   if (!enqueue) { return LGH_OK; } // (lockstep: the velocity solve interleaves the iterations)
    return l2_enqueue(c, r, std::min(max_iter, last > 0 ? last : 8));
+}
+int cg_l2_begin(lgh_ctx *c, const double *b, double *x, double rel_tol, int max_iter) { return cg_l2_begin_impl(c, b, x, rel_tol, max_iter, true); }
+
+// ---- lockstep with the velocity CG (lgh_common.hpp): set-up and initial residual here, one iteration per velocity
+// iteration from inside vcg_solve (apply behind K1, update behind K2), the rest - if any - by cg_l2_end as before
+bool l2_lockstep_possible(lgh_ctx *c) { return l2_fused_update(c); }
+int l2_lockstep_limit(lgh_ctx *c)
+{
+   const int last = c->cg_last_iters[1][0];
+   return last > 0 ? last : 8;
+}
+int cg_l2_begin_lockstep(lgh_ctx *c, const double *b, double *x, double rel_tol, int max_iter) { return cg_l2_begin_impl(c, b, x, rel_tol, max_iter, false); }
+int l2_lockstep_apply(lgh_ctx *c, int it, const LockstepWords &prev, double *den_mirror)
+{
+   L2Run *r = (L2Run *)c->l2run;
+   if (!r || !r->active || !r->m.no_y || it != r->it + 1 || it > r->max_iter) { set_error("l2_lockstep_apply: no energy solve set up for iteration %d", it); return LGH_ERR_ARG; }
+   ++r->it;
+   r->m.iter = r->it;
+   r->m.ls = prev;
+   r->m.ls_on = 1;
+   r->m.ls_den_mirror = den_mirror;
+   return launch_mass<3>(c, LGH_SPACE_L2, r->m);
+}
+int l2_lockstep_update(lgh_ctx *c, int it, const double *den_src, long long *word_out)
+{
+   L2Run *r = (L2Run *)c->l2run;
+   if (!r || !r->active || it != r->it) { set_error("l2_lockstep_update: iteration %d has no apply", it); return LGH_ERR_ARG; }
+   r->v.iter = r->it;
+   MassArgs m = r->m;
+   m.ls_on = 1;
+   m.ls_den_src = den_src;
+   m.ls_word_out = word_out;
+   return launch_l2_update(c, m, r->v);
+}
+__global__ void l2_lockstep_fold_k(CgScalars *s, const int it, const LockstepWords w)
+{
+   if (s->done) { return; }
+   (void)lockstep_pending_update(s, it + 1, lockstep_rz(w), true); // what the apply of iteration it + 1 would commit
+}
+int l2_lockstep_fold(lgh_ctx *c, int it, const LockstepWords &last)
+{
+   L2Run *r = (L2Run *)c->l2run;
+   if (!r || !r->active || it != r->it) { set_error("l2_lockstep_fold: iteration %d is not the last one enqueued", it); return LGH_ERR_ARG; }
+   hipLaunchKernelGGL(l2_lockstep_fold_k, dim3(1), dim3(1), 0, c->stream, c->cgs, it, last);
+   LGH_HIP_CHECK(hipGetLastError());
+   return LGH_OK;
+}
+int cg_l2_end(lgh_ctx *c, int *iters);
+int cg_l2_end_lockstep(lgh_ctx *c, int *iters)
+{
+   L2Run *r = (L2Run *)c->l2run;
+   if (!r || !r->active) { return LGH_ERR_ARG; }
+   r->m.ls_on = 0; // (from here on the solve reduces its scalars itself: the sequence of cg_solve)
+   r->m.ls_den_mirror = nullptr;
+   const int inside = r->it;
+   const int rc = cg_l2_end(c, iters);
+   c->ls_stats[0] += 1;
+   c->ls_stats[1] += inside;
+   c->ls_stats[2] += r->it - inside;
+   return rc;
 }
 
 int cg_l2_end(lgh_ctx *c, int *iters)

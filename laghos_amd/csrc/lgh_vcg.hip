@@ -1748,7 +1748,7 @@ vcg_gather_list_k(const VcgArgs a)
       if (t < a.hp.n_nbr * a.nx_den)
       {
          const int k = t / a.nx_den, e = t - k * a.nx_den;
-         a.hp.sbuf[(size_t)a.hp.base[k] + (size_t)kVC * a.hp.ncnt[k] + e] = __hip_atomic_load(&a.s->den[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+         a.hp.sbuf[(size_t)a.hp.base[k] + (size_t)kVC * a.hp.ncnt[k] + e] = __hip_atomic_load(e < kVC ? &a.s->den[e] : &a.s->den_e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
    }
    const int u = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1942,6 +1942,9 @@ struct VcgAux
    // merged E-vector layout of the slab K1 (slab_merge_layout): its set table and the tables of K2 for that layout
    int rz_words_all = -1;      // several ranks: every rank can exchange (r, z) as accumulator words (-1: not asked yet)
    int rz_words_key = -1;      // ... and the local inputs of that question at the time it was asked
+   int ls_all = 0;             // ... every rank could also run the energy CG in lockstep with this solve (asked in the same exchange)
+   int ls_ready = 0;           // the last solve exchanged (r, z) as accumulator words and packed its halo itself (or had no neighbour), here
+                               // and on every other rank: the energy CG may run in lockstep with the next one (vcg_lockstep_ready)
    unsigned *settab = nullptr;
    int *ellm = nullptr;
    int degm = 0;
@@ -2375,6 +2378,19 @@ static int vcg_prepare(lgh_ctx *c, double *B, double *X, double rel_tol, VcgPlan
    // (several ranks, round 5: all-pairs partitions, where the words of every rank reach every other in one exchange)
    // (a communicator of size 1 - LGH_FORCE_MULTI - has nobody to exchange with: the words are complete as they are)
    bool rz_words = limbs && (!multi || ((halo_can_piggyback(c) || c->nranks == 1) && c->t_deg <= 8)) && !(rzenv && rzenv[0] == '0');
+   // ... and whether the energy CG can ride on this solve's exchanges (lockstep): a fourth scalar on the halo
+   // messages - their LENGTH, which both ends of a message must agree on - so this too is every rank's answer or nobody's
+   bool ls_mine = false;
+   if (multi && rz_words)
+   {
+      const char *e0 = getenv("LGH_HALO_FUSED_PACK");
+      HaloPackTables hp0;
+      const uint8_t *hm0 = nullptr; const int *sn0 = nullptr; int nsh0 = 0;
+      comm_shared_nodes(c, &hm0, &sn0, &nsh0);
+      ls_mine = k2p && c->t_deg <= 8 && l2_lockstep_possible(c) && comm_ranks_before(c) >= 0 &&
+                (nsh0 == 0 || (!(e0 && e0[0] == '0') && halo_can_piggyback(c) && comm_pack_tables(c, &hp0)));
+   }
+   if (multi && c->nranks == 1) { aux->ls_all = ls_mine ? 1 : 0; }
    if (multi && c->nranks > 1)
    {
       // Which exchange follows K2 - accumulator words or three doubles - must be the same on every rank, and whether a rank
@@ -2387,15 +2403,16 @@ static int vcg_prepare(lgh_ctx *c, double *B, double *X, double rel_tol, VcgPlan
       else if (aux->rz_words_all < 0)
       {
          aux->rz_words_key = key;
-         const double mine = rz_words ? 1.0 : 0.0;
+         const double mine[2] = {rz_words ? 1.0 : 0.0, ls_mine ? 1.0 : 0.0};
          LGH_HIP_CHECK(hipStreamSynchronize(c->stream));
-         LGH_HIP_CHECK(hipMemcpy(c->scal + 12, &mine, sizeof(double), hipMemcpyHostToDevice)); // (pageable host memory: synchronous copies)
-         rc = allreduce_dev(c, c->scal + 12, 1, 1);
+         LGH_HIP_CHECK(hipMemcpy(c->scal + 12, mine, sizeof(mine), hipMemcpyHostToDevice)); // (pageable host memory: synchronous copies)
+         rc = allreduce_dev(c, c->scal + 12, 2, 1);
          if (rc) { return rc; }
-         double all = 0.0;
+         double all[2] = {0.0, 0.0};
          LGH_HIP_CHECK(hipStreamSynchronize(c->stream));
-         LGH_HIP_CHECK(hipMemcpy(&all, c->scal + 12, sizeof(double), hipMemcpyDeviceToHost));
-         aux->rz_words_all = (all > 0.5) ? 1 : 0;
+         LGH_HIP_CHECK(hipMemcpy(all, c->scal + 12, sizeof(all), hipMemcpyDeviceToHost));
+         aux->rz_words_all = (all[0] > 0.5) ? 1 : 0;
+         aux->ls_all = (all[0] > 0.5 && all[1] > 0.5) ? 1 : 0;
       }
       rz_words = rz_words && aux->rz_words_all == 1;
    }
@@ -2523,15 +2540,25 @@ static int vcg_prepare(lgh_ctx *c, double *B, double *X, double rel_tol, VcgPlan
       if (want && mixed0 && k2p && a.n_shared > 0 && comm_pack_tables(c, &a.hp))
       {
          a.pack_halo = 1;
-         a.nx_den = halo_can_piggyback(c) ? kVC : 0;
+         a.nx_den = halo_can_piggyback(c) ? (c->e_lockstep ? kVC + 1 : kVC) : 0; // (lockstep energy CG: its (d, M d) rides along, VcgScalars::den_e)
          a.pack_rz = (halo_can_piggyback(c) && !rzl) ? 1 : 0; // (rz_limbs mode: (r, z) travels as accumulator words, exchange_words)
       }
+   }
+   if (in_solve)
+   {
+      // (the collective answer, and nothing of this rank's own has changed since it was given)
+      aux->ls_ready = (multi && aux->ls_all == 1 && ls_mine && a.rzl && (a.n_shared == 0 || (a.pack_halo && halo_can_piggyback(c)))) ? 1 : 0;
    }
    plan.a = a;
    plan.aux = aux;
    plan.k1form = k1form;
    plan.k2p = k2p;
    return LGH_OK;
+}
+bool vcg_lockstep_ready(const lgh_ctx *c)
+{
+   const VcgAux *x = (const VcgAux *)c->vcg_aux;
+   return x && x->ls_ready != 0;
 }
 
 // one launch of K1 in the form vcg_k1_form() names (a.iter, a.partials, a.ticket set by the caller)
@@ -2580,7 +2607,8 @@ static void vcg_launch_k2p(lgh_ctx *c, const VcgPlan &plan, const VcgArgs &a, co
    const int u2 = (uenv && uenv[0] == '2') ? 1 : 0;
    // LGH_K2_OCC (A/B): 4 = the register budget of rounds 2-4 for both launches, 6 = at most 80 registers for both (the launch
    // that updates x then spills 7), default: 80 for the launch without x, the old budget for the one with it
-   static const int occ = [] { const char *e = getenv("LGH_K2_OCC"); return (e && e[0] == '4') ? 0 : (e && e[0] == '6') ? 2 : 1; }();
+   const char *oenv = getenv("LGH_K2_OCC"); // (per launch, like LGH_K2_U: the switch tests flip it inside one process)
+   const int occ = (oenv && oenv[0] == '4') ? 0 : (oenv && oenv[0] == '6') ? 2 : 1;
    const int occ3 = (it & 1) ? (occ >= 1) : (occ == 2);
 #define LGH_K2P_LAUNCH(XU_, U_, MINW_) hipLaunchKernelGGL((vcg_update_p_k<XU_, U_, MINW_>), dim3(plan.aux->grid2), dim3(512), 0, c->stream, a)
    if (it & 1) { if (u2) { LGH_K2P_LAUNCH(false, 2, 2); } else if (occ3) { LGH_K2P_LAUNCH(false, 1, 6); } else { LGH_K2P_LAUNCH(false, 1, 4); } }
@@ -2633,6 +2661,13 @@ int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
    static_assert(sizeof(VcgScalars) <= 64 * sizeof(double), "pinned staging too small");
    int it = 0, looks = 0;
    bool energy_polled = false;
+   // The energy CG in lockstep (lgh_solve_energy_begin set it up on this stream; lgh_mass.hip): one of its iterations per
+   // velocity iteration - apply behind K1, update behind K2 - while it has some left of the count it needed last time; its
+   // (d, M d) rides on the halo messages (den_e, the fourth scalar), its (r, r) in a word of the accumulator-word exchange.
+   const bool ls = c->e_lockstep == 1 && multi && a.rzl && aux->ls_ready && (a.n_shared == 0 || a.nx_den == kVC + 1);
+   const int ls_limit = ls ? std::min(l2_lockstep_limit(c), max_iter) : 0;
+   const int ls_before = ls ? comm_ranks_before(c) : 0;
+   auto ls_words = [&](const int set_it) { return LockstepWords{a.rzl + (set_it % 3) * kLimbWords, a.rzl_peers, a.n_rz_peers, ls_before}; };
    // first chunk = iteration count of the previous velocity solve (see cg_solve)
    int chunk = c->vcg_last > 0 ? c->vcg_last : 8;
    bool first_look = true;
@@ -2683,6 +2718,12 @@ int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
          vcg_launch_k1(c, plan, a);
          kt_end(c, LGH_KERNEL_MASS_CG_H1);
          LGH_HIP_CHECK(hipGetLastError());
+         const bool ls_it = ls && it <= ls_limit;
+         if (ls_it)
+         {
+            rc = l2_lockstep_apply(c, it, ls_words(it - 1), &ds->den_e);
+            if (rc) { return rc; }
+         }
          a.partials = c->vcg_partials;
          a.ticket = c->vcg_tickets;
          auto launch_k2p = [&]() { vcg_launch_k2p(c, plan, a, it); };
@@ -2718,7 +2759,7 @@ int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
                // rank is a neighbour of every other, by an all-reduce otherwise
                if (halo_can_piggyback(c))
                {
-                  rc = halo_sum(c, a.yL, kVC, ds->den, kVC, a.pack_halo != 0, alias);
+                  rc = halo_sum(c, a.yL, kVC, ds->den, a.nx_den > kVC ? a.nx_den : kVC, a.pack_halo != 0, alias);
                   if (rc) { return rc; }
                }
                else
@@ -2733,12 +2774,24 @@ int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
             if (mixed && k2p) { launch_k2p(); }
             else if (mixed) { hipLaunchKernelGGL((vcg_update_k<true, 8>), dim3(nb), dim3(256), 0, c->stream, a); }
             else { hipLaunchKernelGGL((vcg_update_k<false, 0>), dim3(nb), dim3(256), 0, c->stream, a); }
+            if (ls_it)
+            {
+               rc = l2_lockstep_update(c, it, &ds->den_e, a.rzl + (it % 3) * kLimbWords);
+               if (rc) { return rc; }
+            }
             if (multi && a.rzl)
             {
                // exact all-reduce of (r, z): the accumulator words K2 just added into go to every peer as they are - no fold,
                // no pack, no combine kernel; the next K1 (or vcg_rz_finish_k) adds own and peers' words before it folds
                rc = exchange_words(c, a.rzl + (it % 3) * kLimbWords, kLimbWords);
                if (rc) { return rc; }
+               if (ls_it && (it == ls_limit || it == upto))
+               {
+                  // the energy CG's last interleaved iteration of this chunk: its outcome is committed now, while the peers'
+                  // words of THIS exchange are still in the buffer (the next apply, if there is one, finds the same sum)
+                  rc = l2_lockstep_fold(c, it, ls_words(it));
+                  if (rc) { return rc; }
+               }
             }
             else if (multi)
             {

@@ -12,7 +12,9 @@ constexpr int kTraceRec = 16; // debug (LGH_VCG_TRACE): 64-bit words per workgro
 
 struct VcgScalars
 {
-   double rz[kVC], rz_prev[kVC], den[kVC], r0[kVC];
+   double rz[kVC], rz_prev[kVC], den[kVC];
+   double den_e;   // lockstep energy CG (lgh_mass.hip): its (d, M d), a fourth scalar right behind den[] - it rides on the halo messages with them
+   double r0[kVC];
    double rel_tol2;
    double alpha_last[kVC]; // vcg_update_p_k: alpha of the latest completed update of component c
    int done[kVC], iters[kVC], first;
@@ -259,6 +261,7 @@ struct VcgArgs
 constexpr int kLimbs = 4;      // 64-bit accumulators per sum
 constexpr int kLimbShards = 4; // copies of the accumulators (workgroup b adds to shard b % kLimbShards): ~64 atomics per word and launch
 constexpr int kLimbWords = kLimbShards * kVC * kLimbs + 8; // the accumulators, then the flag word (padded)
+static_assert(kLimbWords == kLsWordsPerSet && kLsWord > kLimbShards * kVC * kLimbs && kLsWord < kLimbWords, "the lockstep energy CG keeps its (r, r) in a padding word of a set");
 __device__ __forceinline__ int exact_scale(const double rz) // E for sums bounded by 64 rz (margin 2^5)
 {
    int e;

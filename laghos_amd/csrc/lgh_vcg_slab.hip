@@ -152,11 +152,17 @@ __global__ void slab_swap_probe_k(double *out)
 #pragma unroll
    for (int k = 0; k < 36; k++) { out[36 * 64 + 36 * lane + k] = w[k]; }
 }
+static bool slab_swaps_probe(lgh_ctx *c);
 static bool slab_swaps_ok(lgh_ctx *c)
 {
-   static int cached = -1;
-   if (cached >= 0) { return cached == 1; }
-   cached = 0;
+   // once per process, and thread-safe: the ranks of the in-process loop-back communicator are host threads, and a rank that
+   // asked while another one's probe was still running used to be told "unavailable" - its solve then took another form of K1
+   // than its peers' and the exchanges of the ranks no longer matched
+   static const bool ok = slab_swaps_probe(c);
+   return ok;
+}
+static bool slab_swaps_probe(lgh_ctx *c)
+{
    double *dev = nullptr;
    if (hipMalloc((void **)&dev, 2 * 36 * 64 * sizeof(double)) != hipSuccess) { return false; }
    hipLaunchKernelGGL(slab_swap_probe_k, dim3(1), dim3(64), 0, c->stream, dev);
@@ -183,7 +189,6 @@ static bool slab_swaps_ok(lgh_ctx *c)
          }
       }
    }
-   cached = good ? 1 : 0;
    return good;
 }
 

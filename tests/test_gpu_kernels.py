@@ -1025,6 +1025,11 @@ KERNEL_SWITCHES = [
     ((3, 2), {"LGH_Q_FORM": "0", "LGH_FUSED_FTV": "0", "LGH_FUSED_F1": "0"}, "tol"),
     ((4, 3), {"LGH_L2_PLANE": "0"}, "tol"),
     ((4, 3), {"LGH_K2P": "0"}, "tol"),
+    # round 6: the energy CG's update by cg_update_k on the stored M d instead of the Kronecker kernel forming it again (another
+    # kernel: x and r round differently); host looks through hipStreamSynchronize instead of the token spin
+    ((3, 2), {"LGH_L2_FUSED": "0"}, "tol"),
+    ((4, 3), {"LGH_L2_FUSED": "0"}, "tol"),
+    ((3, 2), {"LGH_SPIN": "0"}, "bits"),
 ]
 _switch_default = {}
 

@@ -67,12 +67,17 @@ def _in_process(nranks, pgrid, block, steps):
     return out[0]
 
 
-@pytest.mark.parametrize("nproc,pgrid,slab", [(2, (2, 1, 1), False), (4, (2, 2, 1), False), (2, (2, 1, 1), True)], ids=["2ranks", "4ranks", "2ranks-slab-words"])
+@pytest.mark.parametrize("nproc,pgrid,slab", [(2, (2, 1, 1), 0), (4, (2, 2, 1), 0), (2, (2, 1, 1), 1), (2, (2, 1, 1), 2), (4, (2, 2, 1), 2)],
+                         ids=["2ranks", "4ranks", "2ranks-slab-words", "2ranks-slab-words-one-communicator", "4ranks-slab-words-one-communicator"])
 def test_bench_gpus_n_over_the_cross_process_transport(nproc, pgrid, slab, monkeypatch):
     # slab: the kernels config 4's ranks run (slab K1 with the merged E-vector, exact accumulators) on 8^3-zone ranks -
     # (r, z) then crosses the ranks as accumulator WORDS (exchange_words, round 5), here through the shm transport
+    # slab == 2: no second channel (LGH_COMM2=0, what a run over RCCL has by default) - the energy CG in lockstep with the
+    # velocity CG, its sums on the velocity iteration's messages (round 6)
     if slab:
         monkeypatch.setenv("LGH_VCG_VARIANT", "4")
+    if slab == 2:
+        monkeypatch.setenv("LGH_COMM2", "0")
     steps, warmup, block = 3, 2, 8
     d = _torchrun_bench(nproc, ["--transport", "shm", "--block", str(block), "--steps", str(steps), "--warmup", str(warmup)])
     assert d["n_gpus"] == nproc and d["steps"] == steps and d["warmup"] == warmup and d["scaling"] == "weak"
@@ -87,6 +92,9 @@ def test_bench_gpus_n_over_the_cross_process_transport(nproc, pgrid, slab, monke
     m = d["comm"]
     assert m["ranks"] == nproc and m["neighbours"] == nproc - 1 and m["all_pairs_partition"] is True
     assert m["halo_exchange"]["per_rk_step"] > 0 and m["largest_message_bytes_3_components"] > 0
+    assert m["second_channel"] is (slab != 2)
+    ls = m["energy_lockstep"]
+    assert (ls["solves"] >= 4 * (steps + warmup) - 1 and ls["iterations_inside_velocity_solves"] > 4 * ls["solves"]) if slab == 2 else ls["solves"] == 0, ls
     ref = _in_process(nproc, pgrid, block, warmup + steps)
     assert c["rk_stages_executed"] == 4 * steps
     assert (c["e_norm"], c["t"], c["dt"]) == (ref["e"], ref["t"], ref["dt"]), (c["e_norm"], ref)

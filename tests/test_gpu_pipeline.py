@@ -513,11 +513,22 @@ MULTI_RANK_CASES = [
     (3, (9, 6, 6), 1, 1, (3, 2), {"LGH_RENUMBER": "random"}), (8, (8, 8, 8), 1, 0, (3, 2), {"LGH_RENUMBER": "mfem", "LGH_HALO_FUSED_PACK": "0"}),
     (4, (8, 8, 4), 7, 1, (3, 2), {"LGH_RENUMBER": "mfem"}), (8, (4, 4, 4), 3, 0, (5, 4), {"LGH_RENUMBER": "random"}),
     (2, (16, 8, 8), 1, 0, (3, 2), {"LGH_VCG_VARIANT": "4", "LGH_RENUMBER": "random", "LGH_ORDER_MULTI": "0"}),
+    # round 6: ONE communicator (LGH_COMM2=0: the default over RCCL) - the energy CG runs in lockstep with the velocity CG, its
+    # two sums per iteration on the velocity iteration's exchanges (lgh_energy_lockstep_stats; "_lockstep": what the run must
+    # report); LGH_ENERGY_LOCKSTEP=0: after the velocity solve, as before.  Problem 7: with the gravity source.
+    (2, (16, 8, 8), 1, 0, (3, 2), {"LGH_VCG_VARIANT": "4", "LGH_COMM2": "0", "_lockstep": "1"}),
+    (8, (16, 16, 16), 1, 0, (3, 2), {"LGH_VCG_VARIANT": "4", "LGH_COMM2": "0", "_lockstep": "1"}),
+    (8, (16, 16, 16), 1, 0, (3, 2), {"LGH_VCG_VARIANT": "4", "LGH_COMM2": "0", "LGH_ENERGY_LOCKSTEP": "0", "_lockstep": "0"}),
+    (4, (16, 16, 8), 7, 0, (3, 2), {"LGH_VCG_VARIANT": "4", "LGH_COMM2": "0", "_lockstep": "1"}),
+    (2, (16, 8, 8), 1, 0, (3, 2), {"LGH_VCG_VARIANT": "4", "LGH_COMM2": "0", "LGH_RENUMBER": "random", "_lockstep": "1"}),
+    (8, (16, 16, 16), 1, 0, (3, 2), {"LGH_VCG_VARIANT": "4", "LGH_COMM2": "0", "LGH_RENUMBER": "mfem", "LGH_HALO_FUSED_PACK": "0", "_lockstep": "0"}),
+    (8, (16, 16, 16), 1, 0, (3, 2), {"LGH_VCG_VARIANT": "4", "_lockstep": "0"}),  # (second channel: the energy solve beside the velocity solve)
+    (8, (16, 16, 16), 1, 1, (3, 2), {"LGH_VCG_VARIANT": "4", "LGH_COMM2": "0", "_lockstep": "0"}),  # (region timers: sequential semantics)
 ]
 
 
 @pytest.mark.parametrize("nranks,nel,problem,timers,order,env", MULTI_RANK_CASES,
-                         ids=[f"{c[0]}ranks-{'x'.join(map(str, c[1]))}-p{c[2]}-t{c[3]}-Q{c[4][0]}Q{c[4][1]}" + "".join(f"-{k[4:]}={v}" for k, v in c[5].items())
+                         ids=[f"{c[0]}ranks-{'x'.join(map(str, c[1]))}-p{c[2]}-t{c[3]}-Q{c[4][0]}Q{c[4][1]}" + "".join(f"-{k[4:] if k[0] != '_' else k[1:]}={v}" for k, v in c[5].items())
                               for c in MULTI_RANK_CASES])
 def test_multi_rank_run_on_one_gpu(nranks, nel, problem, timers, order, env, monkeypatch):
     """The complete multi-rank algorithm (block partition, owner-weighted dot products,
@@ -533,11 +544,14 @@ def test_multi_rank_run_on_one_gpu(nranks, nel, problem, timers, order, env, mon
     (vorticity-scaled viscosity, gravity source through the halo-summed MultFull).
     timers = 0: region timers off, as in bench.py - the energy solve then runs beside the velocity solve on
     the second stream, with its dot products summed over the ranks on the communicator's second channel."""
+    import ctypes
     import os
     import threading
     from laghos_amd import host_lib
+    from laghos_amd import _lib
     for k, v in env.items():
-        monkeypatch.setenv(k, v)
+        if k[0] != "_":
+            monkeypatch.setenv(k, v)
     args = ["-p", problem, "-dim", 3, "-nx", nel[0], "-ny", nel[1], "-nz", nel[2], "-Sx", 1, "-Sy", 1, "-Sz", 1, "-rs", 0,
             "-ok", order[0], "-ot", order[1], "-pa", "-tf", 0.6, "-ms", 6 if order == (3, 2) else 3, "-q"]
     ref = host_lib.Sim(args)
@@ -557,7 +571,9 @@ def test_multi_rank_run_on_one_gpu(nranks, nel, problem, timers, order, env, mon
             sim.enable_timers(timers)
             while sim.step() == 1:
                 pass
-            out[rank] = dict(e=sim.e_norm(), t=sim.t, dt=sim.dt, rk=sim.rk_steps, ti=sim.ti)
+            ls = (ctypes.c_long * 4)()
+            _lib.check(_lib.load().lgh_energy_lockstep_stats(sim.L.laghos_sim_context(sim.h), ls))
+            out[rank] = dict(e=sim.e_norm(), t=sim.t, dt=sim.dt, rk=sim.rk_steps, ti=sim.ti, ls=list(ls))
             sim.close()
         except Exception as ex:  # noqa: BLE001 - reported below
             err[rank] = repr(ex)
@@ -576,6 +592,59 @@ def test_multi_rank_run_on_one_gpu(nranks, nel, problem, timers, order, env, mon
         # (orders 4 and 5: the unpreconditioned L2 CG on the Bernstein mass matrix amplifies the rounding differences of
         #  the rank-ordered sums - cond ~ 1e6; the README runs themselves are held to 1e-9)
         assert abs(got["e"] - want["e"]) <= (1e-10 if order == (3, 2) else 1e-9) * want["e"], (r, got, want)
+        if "_lockstep" in env:
+            solves, inside, after, ready = got["ls"]
+            if env["_lockstep"] == "1":
+                # every energy solve from the second RK stage on (the first velocity solve of a run has not decided yet how
+                # (r, z) crosses the ranks), nearly all of their iterations inside the velocity solves
+                assert ready == 1 and solves >= 2 * want["rk"] - 1 and inside > 4 * solves and after <= inside // 4, (r, got)
+            else:
+                assert solves == 0 and inside == 0, (r, got)
+    assert len({(o["e"], o["dt"]) for o in out.values()}) == 1, out  # every rank holds the same numbers, bit for bit
+
+
+@pytest.mark.parametrize("nranks,nel", [(2, (16, 8, 8)), (8, (16, 16, 16))], ids=["2ranks", "8ranks"])
+def test_lockstep_energy_solve_is_bit_identical_to_the_sequential_order(nranks, nel, monkeypatch):
+    """One communicator (LGH_COMM2=0), slab K1: the energy CG interleaved with the velocity CG, its (d, M d) on the halo messages
+    and its (r, r) in the accumulator-word exchange, forms its sums in the order the all-pairs all-reduce of the sequential order
+    forms them (ascending rank) - so the two runs must agree in every bit of |e|, t and dt, on every rank."""
+    import ctypes
+    import os
+    import threading
+    from laghos_amd import host_lib, _lib
+    monkeypatch.setenv("LGH_VCG_VARIANT", "4")
+    monkeypatch.setenv("LGH_COMM2", "0")
+    args = ["-p", 1, "-dim", 3, "-nx", nel[0], "-ny", nel[1], "-nz", nel[2], "-Sx", 1, "-Sy", 1, "-Sz", 1, "-rs", 0,
+            "-ok", 3, "-ot", 2, "-pa", "-tf", 0.6, "-ms", 5, "-q"]
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("LGH_ENERGY_LOCKSTEP", mode)
+        cid = (b"LGHLOCAL" + os.urandom(16).hex().encode()).ljust(128, b"\0")
+        out, err = {}, {}
+
+        def rank_main(rank):
+            try:
+                sim = host_lib.Sim(args, nranks=nranks, rank=rank, nccl_id=cid)
+                sim.enable_timers(0)
+                while sim.step() == 1:
+                    pass
+                ls = (ctypes.c_long * 4)()
+                _lib.check(_lib.load().lgh_energy_lockstep_stats(sim.L.laghos_sim_context(sim.h), ls))
+                out[rank] = (sim.e_norm(), sim.t, sim.dt, sim.rk_steps, ls[0] > 0)
+                sim.close()
+            except Exception as ex:  # noqa: BLE001 - reported below
+                err[rank] = repr(ex)
+
+        th = [threading.Thread(target=rank_main, args=(r,), daemon=True) for r in range(nranks)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(timeout=240)
+        assert not any(t.is_alive() for t in th) and not err, err
+        assert len(set(out.values())) == 1, out
+        res[mode] = out[0]
+    assert res["1"][4] and not res["0"][4]
+    assert res["1"][:4] == res["0"][:4], res
 
 
 def test_cpp_driver_print_dumps(tmp_path):
