@@ -613,6 +613,7 @@ int lgh_destroy(lgh_ctx *c)
       (void)hipEventDestroy(c->ev_fork);
       (void)hipEventDestroy(c->ev_join);
    }
+   for (auto &ring : c->ls_ev) { for (hipEvent_t e : ring) { if (e) { (void)hipEventDestroy(e); } } }
    extern void lgh_comm_free(lgh_ctx *);
    lgh_comm_free(c);
    if (c->own_stream) { (void)hipStreamDestroy(c->stream); }
@@ -1136,6 +1137,21 @@ int lgh_solve_energy_begin(lgh_ctx *c, const double *S, const double *v_h1, doub
          if (rc == LGH_OK && e_source) { rc = vec_axpby(c, e_rhs, 1.0, e_rhs, 1.0, e_source, c->L2V); } // :477
          if (rc == LGH_OK) { rc = cg_l2_begin_lockstep(c, e_rhs, dS_dt + 2 * (size_t)c->H1V, rel_tol, max_iter); }
          if (rc) { return rc; }
+         // its iterations exchange nothing themselves, so their kernels may run BESIDE K1 / K2 on the second stream (no second
+         // communicator needed), ordered by four events per iteration (vcg_solve): LGH_LOCKSTEP_STREAM2=1.  Not the default: the
+         // cross-stream waits cost more than the overlap hides (11.0-11.2 against 10.1 ms per step through the N-rank path on one
+         // rank, profiles/r6_lockstep.txt)
+         c->ls_side = (getenv("LGH_LOCKSTEP_STREAM2") && getenv("LGH_LOCKSTEP_STREAM2")[0] == '1') ? 1 : 0;
+         if (c->ls_side)
+         {
+            if (!c->stream2)
+            {
+               LGH_HIP_CHECK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+               LGH_HIP_CHECK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+               LGH_HIP_CHECK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+            }
+            for (auto &ring : c->ls_ev) { for (hipEvent_t &e : ring) { if (!e) { LGH_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); } } }
+         }
          c->e_async = 3;
          c->e_lockstep = 1;
          return LGH_OK;

@@ -104,6 +104,9 @@ struct lgh_ctx
    const double *accel_src; // dim*N acceleration source of SolveVelocity (source_type 2) or nullptr
    int e_async;          // 1: lgh_solve_energy_begin enqueued the solve, 2: deferred to _end
    int e_lockstep;       // lgh_solve_energy_begin has set the energy CG up for LOCKSTEP with the velocity CG on the one stream and communicator
+   int ls_side = 0;      // ... with its kernels on the second stream (they exchange nothing themselves), ordered against the velocity iteration by
+   hipEvent_t ls_ev[4][4] = {}; // events: [0] main -> side after the word exchange, [1] side -> main after the apply, [2] main -> side after the
+                         // halo sums, [3] side -> main after the update; rings of four (iteration & 3).  LGH_LOCKSTEP_STREAM2=1 (default: one stream)
    long ls_stats[3] = {0, 0, 0}; // lockstep energy solves; their iterations enqueued inside the velocity solve; ... and after it (lgh_energy_lockstep_stats)
                          // (several ranks without a second channel; lgh_mass.hip "lockstep"): lgh_solve_velocity interleaves its iterations
    int e_polled, e_iters; // the enqueued solve has already been completed (energy_overlap_poll, from inside the velocity solve): its iteration count

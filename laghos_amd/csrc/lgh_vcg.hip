@@ -2668,6 +2668,26 @@ int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
    const int ls_limit = ls ? std::min(l2_lockstep_limit(c), max_iter) : 0;
    const int ls_before = ls ? comm_ranks_before(c) : 0;
    auto ls_words = [&](const int set_it) { return LockstepWords{a.rzl + (set_it % 3) * kLimbWords, a.rzl_peers, a.n_rz_peers, ls_before}; };
+   // ... with its kernels on the second stream (c->ls_side): `side(f)` enqueues f there; the velocity iteration and the energy
+   // iteration meet at four events - the apply after the word exchange of the iteration before (whose words it reads) and before
+   // the halo messages are packed (its (d, M d) rides on them), the update after the halo sums and before the word exchange
+   // (which carries its (r, r)).  In between the apply runs beside K1 and the update beside K2.
+   const bool ls_side = ls && c->ls_side != 0 && c->stream2 != nullptr;
+   auto side = [&](auto &&f) -> int {
+      if (!ls_side) { return f(); }
+      std::swap(c->stream, c->stream2);
+      const int r = f();
+      std::swap(c->stream, c->stream2);
+      return r;
+   };
+   // (record on `from`, wait on the other stream)
+   auto hand_over = [&](hipEvent_t ev, const bool from_side) -> int {
+      if (!ls_side) { return LGH_OK; }
+      LGH_HIP_CHECK(hipEventRecord(ev, from_side ? c->stream2 : c->stream));
+      LGH_HIP_CHECK(hipStreamWaitEvent(from_side ? c->stream : c->stream2, ev, 0));
+      return LGH_OK;
+   };
+   if (ls_side) { rc = hand_over(c->ev_fork, false); if (rc) { return rc; } } // (the energy solve's set-up and this solve's are on the main stream)
    // first chunk = iteration count of the previous velocity solve (see cg_solve)
    int chunk = c->vcg_last > 0 ? c->vcg_last : 8;
    bool first_look = true;
@@ -2721,7 +2741,9 @@ int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
          const bool ls_it = ls && it <= ls_limit;
          if (ls_it)
          {
-            rc = l2_lockstep_apply(c, it, ls_words(it - 1), &ds->den_e);
+            rc = side([&] { return l2_lockstep_apply(c, it, ls_words(it - 1), &ds->den_e); });
+            if (rc) { return rc; }
+            rc = hand_over(c->ls_ev[1][it & 3], true); // (the messages are packed after this)
             if (rc) { return rc; }
          }
          a.partials = c->vcg_partials;
@@ -2770,13 +2792,16 @@ int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
                   if (rc) { return rc; }
                }
             }
+            if (ls_it) { rc = hand_over(c->ls_ev[2][it & 3], false); if (rc) { return rc; } } // (the energy update reads the summed (d, M d))
             // (the bounded-grid K2 knows the shared nodes and the owner weights from its flag bytes)
             if (mixed && k2p) { launch_k2p(); }
             else if (mixed) { hipLaunchKernelGGL((vcg_update_k<true, 8>), dim3(nb), dim3(256), 0, c->stream, a); }
             else { hipLaunchKernelGGL((vcg_update_k<false, 0>), dim3(nb), dim3(256), 0, c->stream, a); }
             if (ls_it)
             {
-               rc = l2_lockstep_update(c, it, &ds->den_e, a.rzl + (it % 3) * kLimbWords);
+               rc = side([&] { return l2_lockstep_update(c, it, &ds->den_e, a.rzl + (it % 3) * kLimbWords); });
+               if (rc) { return rc; }
+               rc = hand_over(c->ls_ev[3][it & 3], true); // (the word exchange carries its (r, r))
                if (rc) { return rc; }
             }
             if (multi && a.rzl)
@@ -2785,11 +2810,12 @@ int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
                // no pack, no combine kernel; the next K1 (or vcg_rz_finish_k) adds own and peers' words before it folds
                rc = exchange_words(c, a.rzl + (it % 3) * kLimbWords, kLimbWords);
                if (rc) { return rc; }
+               if (ls_it) { rc = hand_over(c->ls_ev[0][it & 3], false); if (rc) { return rc; } } // (the next apply, or the fold, reads these words)
                if (ls_it && (it == ls_limit || it == upto))
                {
                   // the energy CG's last interleaved iteration of this chunk: its outcome is committed now, while the peers'
                   // words of THIS exchange are still in the buffer (the next apply, if there is one, finds the same sum)
-                  rc = l2_lockstep_fold(c, it, ls_words(it));
+                  rc = side([&] { return l2_lockstep_fold(c, it, ls_words(it)); });
                   if (rc) { return rc; }
                }
             }
@@ -2802,6 +2828,7 @@ int vcg_solve(lgh_ctx *c, double *B, double *X, double rel_tol, int max_iter, in
          LGH_HIP_CHECK(hipGetLastError());
       }
    }
+   if (ls_side) { rc = hand_over(c->ev_join, true); if (rc) { return rc; } } // (lgh_solve_energy_end continues on the main stream)
    if (aux->ord)
    {
       // the solution, in the caller's numbering, into the caller's vector (with the pending update of vcg_xfix_k)

@@ -519,6 +519,10 @@ MULTI_RANK_CASES = [
     (2, (16, 8, 8), 1, 0, (3, 2), {"LGH_VCG_VARIANT": "4", "LGH_COMM2": "0", "_lockstep": "1"}),
     (8, (16, 16, 16), 1, 0, (3, 2), {"LGH_VCG_VARIANT": "4", "LGH_COMM2": "0", "_lockstep": "1"}),
     (8, (16, 16, 16), 1, 0, (3, 2), {"LGH_VCG_VARIANT": "4", "LGH_COMM2": "0", "LGH_ENERGY_LOCKSTEP": "0", "_lockstep": "0"}),
+    # ... with the energy kernels beside K1 / K2 on the second stream instead of behind them on the one (four events per iteration;
+    # measured slower, kept as a switch: profiles/r6_lockstep.txt)
+    (8, (16, 16, 16), 1, 0, (3, 2), {"LGH_VCG_VARIANT": "4", "LGH_COMM2": "0", "LGH_LOCKSTEP_STREAM2": "1", "_lockstep": "1"}),
+    (2, (16, 8, 8), 1, 0, (3, 2), {"LGH_VCG_VARIANT": "4", "LGH_COMM2": "0", "LGH_LOCKSTEP_STREAM2": "1", "LGH_RENUMBER": "mfem", "_lockstep": "1"}),
     (4, (16, 16, 8), 7, 0, (3, 2), {"LGH_VCG_VARIANT": "4", "LGH_COMM2": "0", "_lockstep": "1"}),
     (2, (16, 8, 8), 1, 0, (3, 2), {"LGH_VCG_VARIANT": "4", "LGH_COMM2": "0", "LGH_RENUMBER": "random", "_lockstep": "1"}),
     (8, (16, 16, 16), 1, 0, (3, 2), {"LGH_VCG_VARIANT": "4", "LGH_COMM2": "0", "LGH_RENUMBER": "mfem", "LGH_HALO_FUSED_PACK": "0", "_lockstep": "0"}),

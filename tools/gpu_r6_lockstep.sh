@@ -14,4 +14,14 @@ for n,g in d["legs"].items():
     print(n, g.get("value"), g.get("ms_per_step"), g.get("ms_per_step_minus_single_rank_path"), g.get("energy_lockstep"), g.get("error"))
 PY
 done
+# A/B: the lockstep energy kernels beside K1 / K2 on the second stream (four events per iteration)
+for i in 1 2; do
+LGH_LOCKSTEP_STREAM2=1 timeout 600 python bench.py --no-cpu-baseline --legs c2multi1c --detail $O/d1s_$i.json > $O/b1s_$i.json 2>> $O/bench.err
+python - <<PY
+import json
+d=json.load(open("$O/d1s_$i.json"))
+for n,g in d["legs"].items():
+    print("second stream:", n, g.get("value"), g.get("ms_per_step"), g.get("ms_per_step_minus_single_rank_path"), g.get("energy_lockstep"), g.get("error"))
+PY
+done
 tail -3 $O/bench.err
