@@ -864,6 +864,11 @@ mass_apply_l2_kron(const MassArgs a)
 }
 
 template <int Q> constexpr int neb_for() { return (256 / (Q * Q)) > 0 ? (256 / (Q * Q)) : 1; }
+static bool l2_one_round(const lgh_ctx *c)
+{
+   const char *e = getenv("LGH_L2_NEB");
+   return c->L1D >= 5 && !(e && e[0] == '0');
+}
 
 // Which kernel the L2 mass apply (modes 0 / 3: the energy CG) launches, decided in ONE place for the dispatch below
 // and for lgh_l2_mass_form(): 2 = mass_apply_l2_kron (needs compact data on a tensor-product rule), 1 = the plane form,
@@ -917,13 +922,21 @@ template <int MODE> static int launch_mass(lgh_ctx *c, int space, const MassArgs
          constexpr int M = (MODE == 3 ? 3 : 0);
          a.M1 = c->M1l;
 #define LGH_L2K(L_, NEB_) hipLaunchKernelGGL((mass_apply_l2_kron<L_, NEB_, M>), dim3(ceil_div(c->NE, NEB_)), dim3(256), 0, c->stream, a)
-         switch (c->L1D)
+         // zones per workgroup.  L = 5 (round 6): ten, so that every thread has ONE row of a stage (25 rows per zone) and five
+         // workgroups fit a CU's LDS, instead of sixteen (400 rows: a second round with 144 of 256 threads, three workgroups per
+         // CU): 53 -> 46 us per apply at config 5, the leg 501 -> 534 (profiles/r6_l2_neb.txt); at L = 3 the same choice (28
+         // zones instead of 64) changes nothing.  LGH_L2_NEB=0: sixteen.
+         if (l2_one_round(c)) { LGH_L2K(5, 10); }
+         else
          {
-            case 1: LGH_L2K(1, 256); break;
-            case 2: LGH_L2K(2, 128); break;
-            case 3: LGH_L2K(3, 64); break;
-            case 4: LGH_L2K(4, 32); break;
-            default: LGH_L2K(5, 16); break;
+            switch (c->L1D)
+            {
+               case 1: LGH_L2K(1, 256); break;
+               case 2: LGH_L2K(2, 128); break;
+               case 3: LGH_L2K(3, 64); break;
+               case 4: LGH_L2K(4, 32); break;
+               default: LGH_L2K(5, 16); break;
+            }
          }
 #undef LGH_L2K
          LGH_HIP_CHECK(hipGetLastError());
@@ -1399,13 +1412,17 @@ static int launch_l2_update(lgh_ctx *c, const MassArgs &m, const CgVecArgs &v)
    a.ticket = v.ticket;
    a.iter = v.iter;
 #define LGH_L2U(L_, NEB_) hipLaunchKernelGGL((mass_apply_l2_kron<L_, NEB_, 4>), dim3(ceil_div(c->NE, NEB_)), dim3(256), 0, c->stream, a)
-   switch (c->L1D)
+   if (l2_one_round(c)) { LGH_L2U(5, 10); }
+   else
    {
-      case 1: LGH_L2U(1, 256); break;
-      case 2: LGH_L2U(2, 128); break;
-      case 3: LGH_L2U(3, 64); break;
-      case 4: LGH_L2U(4, 32); break;
-      default: LGH_L2U(5, 16); break;
+      switch (c->L1D)
+      {
+         case 1: LGH_L2U(1, 256); break;
+         case 2: LGH_L2U(2, 128); break;
+         case 3: LGH_L2U(3, 64); break;
+         case 4: LGH_L2U(4, 32); break;
+         default: LGH_L2U(5, 16); break;
+      }
    }
 #undef LGH_L2U
    LGH_HIP_CHECK(hipGetLastError());

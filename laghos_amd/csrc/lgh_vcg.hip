@@ -2566,6 +2566,8 @@ static void vcg_launch_k1(lgh_ctx *c, const VcgPlan &plan, const VcgArgs &a)
 {
    VcgAux *aux = plan.aux;
    const int k1form = plan.k1form;
+   const char *knenv = getenv("LGH_KRON_NEB");
+   const bool kron_small = !(knenv && knenv[0] == '0');
    if (k1form == 5)
    {
       switch (c->D1D)
@@ -2573,8 +2575,11 @@ static void vcg_launch_k1(lgh_ctx *c, const VcgPlan &plan, const VcgArgs &a)
          case 2: launch_vcg_kron<2, 64>(c, a); break;
          case 3: launch_vcg_kron<3, 32>(c, a); break;
          case 4: launch_vcg_kron<4, 16>(c, a); break;
-         case 5: launch_vcg_kron<5, 8>(c, a); break;
-         default: launch_vcg_kron<6, 4>(c, a); break;
+         // (zones per workgroup at D = 5, 6, round 6: three / two - every thread at most one row of a stage and five workgroups
+         //  in a CU's LDS - instead of eight / four (two workgroups per CU): 433 -> 345 us per launch at config 5, Q4Q3 steps
+         //  - 2 %, profiles/r6_kron_neb.txt; LGH_KRON_NEB=0: eight / four)
+         case 5: if (kron_small) { launch_vcg_kron<5, 3>(c, a); } else { launch_vcg_kron<5, 8>(c, a); } break;
+         default: if (kron_small) { launch_vcg_kron<6, 2>(c, a); } else { launch_vcg_kron<6, 4>(c, a); } break;
       }
       return;
    }

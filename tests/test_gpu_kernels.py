@@ -1030,6 +1030,9 @@ KERNEL_SWITCHES = [
     ((3, 2), {"LGH_L2_FUSED": "0"}, "tol"),
     ((4, 3), {"LGH_L2_FUSED": "0"}, "tol"),
     ((3, 2), {"LGH_SPIN": "0"}, "bits"),
+    ((5, 4), {"LGH_KRON_NEB": "0"}, "tol"),  # four / eight instead of two / three zones per workgroup of the Kronecker K1
+    ((4, 3), {"LGH_KRON_NEB": "0"}, "tol"),
+    ((5, 4), {"LGH_L2_NEB": "0"}, "tol"),  # sixteen instead of ten zones per workgroup of the L2 Kronecker kernel (other partial sums)
 ]
 _switch_default = {}
 
