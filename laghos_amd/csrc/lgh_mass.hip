@@ -1665,8 +1665,10 @@ int cg_l2_begin(lgh_ctx *c, const double *b, double *x, double rel_tol, int max_
 bool l2_lockstep_possible(lgh_ctx *c) { return l2_fused_update(c); }
 int l2_lockstep_limit(lgh_ctx *c)
 {
+   const L2Run *r = (const L2Run *)c->l2run;
    const int last = c->cg_last_iters[1][0];
-   return last > 0 ? last : 8;
+   const int want = last > 0 ? last : 8;
+   return (r && r->active) ? std::min(want, r->max_iter) : 0; // (never past the cap this solve was given)
 }
 int cg_l2_begin_lockstep(lgh_ctx *c, const double *b, double *x, double rel_tol, int max_iter) { return cg_l2_begin_impl(c, b, x, rel_tol, max_iter, false); }
 int l2_lockstep_apply(lgh_ctx *c, int it, const LockstepWords &prev, double *den_mirror)

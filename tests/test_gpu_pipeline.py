@@ -4,7 +4,7 @@ full sizes the size-independent properties of the operators are checked."""
 import numpy as np
 import pytest
 
-from helpers import make_gpu, rel_err, seeded
+from helpers import deformed_state, make_gpu, rel_err, seeded
 
 pytestmark = pytest.mark.gpu
 
@@ -649,6 +649,51 @@ def test_lockstep_energy_solve_is_bit_identical_to_the_sequential_order(nranks, 
         res[mode] = out[0]
     assert res["1"][4] and not res["0"][4]
     assert res["1"][:4] == res["0"][:4], res
+
+
+def test_lockstep_energy_solve_with_its_own_iteration_cap(monkeypatch):
+    """The energy solve in lockstep is interleaved for as many iterations as it needed last time - but never past the cap THIS
+    solve was given (lgh_solve_energy_begin's max_iter may be smaller than the velocity solve's): the rest of the sequence must
+    be that of the sequential order, bit for bit.  One rank through the N-rank path (communicator of size 1, no second channel)."""
+    import ctypes
+    import os
+    from oracle.fem import Problem
+    from laghos_amd import _lib
+    for k, v in (("LGH_FORCE_MULTI", "1"), ("LGH_COMM2", "0"), ("LGH_VCG_VARIANT", "4")):
+        monkeypatch.setenv(k, v)
+    prob = Problem(mesh="cube01_hex", rs=3, order_v=3, order_e=2, problem=1)
+    S = deformed_state(prob, seed=5)
+    H1V = prob.H1V
+
+    def run(lockstep):
+        monkeypatch.setenv("LGH_ENERGY_LOCKSTEP", lockstep)
+        g = make_gpu(prob)
+        try:
+            g.ctx.comm_init(1, 0, (b"LGHLOCAL" + os.urandom(16).hex().encode()).ljust(128, b"\0"))
+            ctx = g.ctx
+            ctx.enable_timers(False)  # (region timers have sequential semantics: no overlap, no lockstep)
+            Sd, dS = ctx.to_dev(S), ctx.zeros(S.size)
+            out = []
+            for e_cap in (300, 300, 3, 300, 1):
+                ctx.vec_copy(dS[:H1V], Sd[H1V:2 * H1V])
+                g.reset_quadrature_data()
+                g.update_quadrature_data(Sd)
+                ctx.solve_energy_begin(Sd, Sd[H1V:2 * H1V], dS, g.e_rhs, 1e-14, e_cap)
+                ctx.solve_velocity(Sd, dS, None, g.rhs, g.work, 1e-14, 300)
+                ctx.solve_energy_end()
+                ctx.sync()
+                out.append(dS.cpu().numpy().copy())
+            ls = (ctypes.c_long * 4)()
+            _lib.check(_lib.load().lgh_energy_lockstep_stats(ctx.h, ls))
+            return out, list(ls)
+        finally:
+            g.close()
+
+    a, sa = run("1")
+    b, sb = run("0")
+    assert sa[0] == 4 and sa[1] > 8 and sb[0] == 0, (sa, sb)  # (the first solve of a context is sequential)
+    for k, (x, y) in enumerate(zip(a, b)):
+        assert np.array_equal(x, y), k
 
 
 def test_cpp_driver_print_dumps(tmp_path):
