@@ -1111,6 +1111,25 @@ int lgh_solve_energy(lgh_ctx *c, const double *S, const double *v_h1, double *dS
 // (one RCCL communicator must not be driven from two streams: lgh_comm_init creates a
 // second one for this), or when the velocity solve would use the scalar CG (shared
 // scratch).  LGH_OVERLAP=0 switches it off.
+// The second stream, for the energy solve beside the velocity solve - at the LOWEST priority the device offers (round 6): the
+// velocity solve is the longer of the two at every order up to Q4Q3 and its kernels fill the device; the energy solve's small
+// kernels then take what is left instead of an equal share of the dispatch slots: 8.81 -> 8.75 ms per step at C2 on one box,
+// 8.85 -> 8.78 on another; config 5, where the energy CG is the longer one, does not lose (372 -> 367 ms), the highest priority
+// gains nothing anywhere (profiles/r6_stream_priority.txt).  LGH_STREAM2_PRIORITY=d / h: the default / the highest priority.
+static int create_stream2(lgh_ctx *c)
+{
+   const char *penv = getenv("LGH_STREAM2_PRIORITY");
+   const char want = (penv && (penv[0] == 'd' || penv[0] == 'h')) ? penv[0] : 'l';
+   int least = 0, greatest = 0;
+   if (want != 'd' && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest)
+   {
+      LGH_HIP_CHECK(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, want == 'h' ? greatest : least));
+   }
+   else { LGH_HIP_CHECK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking)); }
+   LGH_HIP_CHECK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+   LGH_HIP_CHECK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+   return LGH_OK;
+}
 static bool energy_overlap_ok(const lgh_ctx *c)
 {
    const bool on = !(getenv("LGH_OVERLAP") && getenv("LGH_OVERLAP")[0] == '0');
@@ -1146,9 +1165,8 @@ int lgh_solve_energy_begin(lgh_ctx *c, const double *S, const double *v_h1, doub
          {
             if (!c->stream2)
             {
-               LGH_HIP_CHECK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
-               LGH_HIP_CHECK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-               LGH_HIP_CHECK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+               const int rc2 = create_stream2(c);
+               if (rc2) { return rc2; }
             }
             for (auto &ring : c->ls_ev) { for (hipEvent_t &e : ring) { if (!e) { LGH_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); } } }
          }
@@ -1161,9 +1179,8 @@ int lgh_solve_energy_begin(lgh_ctx *c, const double *S, const double *v_h1, doub
    }
    if (!c->stream2)
    {
-      LGH_HIP_CHECK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
-      LGH_HIP_CHECK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-      LGH_HIP_CHECK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+      const int rc2 = create_stream2(c);
+      if (rc2) { return rc2; }
    }
    LGH_HIP_CHECK(hipEventRecord(c->ev_fork, c->stream));
    LGH_HIP_CHECK(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
